@@ -1,0 +1,202 @@
+// Self-attention for the U-Net attention blocks on gfx950: MFMA QK^T and PV, online softmax.
+//
+// Work split: a workgroup = 4 waves = 128 queries of one (image, head); each wave owns 32
+// queries.  Keys/values are streamed in blocks of 64 through LDS.
+//   S^T[key][query] = K . Q^T      A = K block (LDS, row = key, k = d), B = Q (registers)
+//   O^T[d][query]  += V^T . P^T    A = V^T block (LDS image transposed while staging),
+//                                  B = P^T taken straight from the S^T accumulators (the k
+//                                  order of an accumulator tile is permuted: element j of
+//                                  lane-half h is key 16s + 8(j>>2) + 4h + (j&3); the V^T
+//                                  fragment is read in the same order).
+// With the query on the lane (column of every accumulator), the running max / sum are
+// lane-local apart from one lane<->lane+32 exchange.
+//
+// Reference: AttnBlock.forward models/DxMI/unet_small.py:175-187 (scale C^-0.5, softmax over
+// keys); QKVAttentionLegacy models/cm/unet.py:413-441.
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+    const bf16* qkv;
+    bf16* out;
+    int N, T, C, heads;
+    int q_off, k_off, v_off, head_stride;  // channel offsets inside the 3C-wide row
+    float scale;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
+    constexpr int KB = 64;               // keys per block
+    constexpr int DK = D / 16;           // k-steps over d
+    constexpr int DB = D / 32;           // 32-row blocks of O^T
+    constexpr int KPITCH = D * 2 + 16;   // bytes per key row of the K image
+    constexpr int VPITCH = KB * 2 + 8;   // bytes per d row of the V^T image
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* kimg = smem;
+    char* vimg = smem + KB * KPITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qblocks = (p.T + 127) / 128;
+    const int qb = blockIdx.x % qblocks;
+    const int hd = (blockIdx.x / qblocks) % p.heads;
+    const int n = blockIdx.x / (qblocks * p.heads);
+    const int C3 = 3 * p.C;
+    const bf16* base = p.qkv + (size_t)n * p.T * C3;
+    const int qc = p.q_off + hd * p.head_stride;
+    const int kc = p.k_off + hd * p.head_stride;
+    const int vc = p.v_off + hd * p.head_stride;
+
+    const int h = lane >> 5;
+    const int query = qb * 128 + wave * 32 + (lane & 31);
+    const bool qvalid = query < p.T;
+
+    // Q fragments (B operand): lane = query, elements d = ks*16 + 8h + j
+    bf16x8 qf[DK];
+#pragma unroll
+    for (int ks = 0; ks < DK; ++ks) {
+        bf16x8 z;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
+        qf[ks] = qvalid ? *reinterpret_cast<const bf16x8*>(base + (size_t)query * C3 + qc + ks * 16 + 8 * h) : z;
+    }
+
+    f32x16 o[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    const int nkb = (p.T + KB - 1) / KB;
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();
+        // ---- stage K block (row-major) and V block (transposed) into LDS, zero-filled past T
+        constexpr int PIECES = KB * (D / 8);  // 16-byte pieces per operand block
+        for (int i = tid; i < PIECES; i += 256) {
+            const int key = i / (D / 8), pc = i % (D / 8);
+            const int gk = kb * KB + key;
+            bf16x8 kv, vv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kv[e] = (bf16)0.f; vv[e] = (bf16)0.f; }
+            if (gk < p.T) {
+                kv = *reinterpret_cast<const bf16x8*>(base + (size_t)gk * C3 + kc + pc * 8);
+                vv = *reinterpret_cast<const bf16x8*>(base + (size_t)gk * C3 + vc + pc * 8);
+            }
+            *reinterpret_cast<bf16x8*>(kimg + key * KPITCH + pc * 16) = kv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16*>(vimg + (pc * 8 + e) * VPITCH + key * 2) = vv[e];
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T for the 2 x 32 keys of this block
+        f32x16 s[2];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kh][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(kimg + (kh * 32 + (lane & 31)) * KPITCH + ks * 32 + h * 16);
+                s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kh], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (query on the lane; this lane holds 32 of the 64 keys)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * KB + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = (key < p.T) ? s[kh][r] * p.scale : -INFINITY;
+                s[kh][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = __expf(m - m_new);  // m = -inf on the first block -> 0
+        float psum = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(s[kh][r] - m_new);
+                s[kh][r] = e;
+                psum += e;
+            }
+        l = l * alpha + psum;
+        m = m_new;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+        // ---- O^T += V^T . P^T ; 4 k-steps of 16 keys
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int kh = st >> 1, sl = st & 1;  // accumulator tile, k-step inside it
+            bf16x8 pb;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) pb[jj] = (bf16)s[kh][8 * sl + jj];
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const char* row = vimg + (db * 32 + (lane & 31)) * VPITCH + (kh * 32 + 16 * sl + 4 * h) * 2;
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row);
+                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + 16);
+                bf16x8 a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = lo[e]; a[4 + e] = hi[e]; }
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+            }
+        }
+    }
+
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    if (qvalid) {
+        bf16* orow = p.out + ((size_t)n * p.T + query) * p.C + hd * D;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (bf16)(o[db][4 * g + e] * inv);
+                *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * g + 4 * h) = ov;
+            }
+    }
+}
+
+template <int D>
+int launch_attn(const AttnArgs& a, hipStream_t st) {
+    auto kern = attention_kernel<D>;
+    const size_t lds = 64 * (D * 2 + 16) + D * (64 * 2 + 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int qblocks = (a.T + 127) / 128;
+    hipLaunchKernelGGL(kern, dim3(a.N * a.heads * qblocks), dim3(256), lds, st, a);
+    DXMI_CHECK_LAUNCH("dxmi_attention_fwd");
+    return DXMI_OK;
+}
+
+}  // namespace
+
+extern "C" int dxmi_attention_fwd(const void* qkv, void* out, int32_t N, int32_t T, int32_t C, int32_t heads,
+                                  float scale, void* stream) {
+    DXMI_CHECK_ARG(qkv && out, "dxmi_attention_fwd: null pointer");
+    DXMI_CHECK_ARG(N > 0 && T > 0 && heads > 0 && C % heads == 0, "dxmi_attention_fwd: bad shape N=%d T=%d C=%d heads=%d", N, T, C, heads);
+    const int D = C / heads;
+    AttnArgs a;
+    a.qkv = (const bf16*)qkv; a.out = (bf16*)out; a.N = N; a.T = T; a.C = C; a.heads = heads;
+    a.q_off = 0; a.k_off = C; a.v_off = 2 * C; a.head_stride = D; a.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 256) return launch_attn<256>(a, st);
+    if (D == 128) return launch_attn<128>(a, st);
+    if (D == 64) return launch_attn<64>(a, st);
+    dxmi_set_error("dxmi_attention_fwd: head dim %d unsupported (64, 128, 256)", D);
+    return DXMI_EINVAL;
+}

@@ -1,0 +1,55 @@
+// Shared device/host helpers for the gfx950 kernels (wave64, MFMA 32x32x16 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/dxmi_hip.h"
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+void dxmi_set_error(const char* fmt, ...);
+
+#define DXMI_CHECK_ARG(cond, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            dxmi_set_error(__VA_ARGS__);          \
+            return DXMI_EINVAL;                   \
+        }                                         \
+    } while (0)
+
+#define DXMI_CHECK_LAUNCH(name)                                                     \
+    do {                                                                            \
+        hipError_t e_ = hipGetLastError();                                          \
+        if (e_ != hipSuccess) {                                                     \
+            dxmi_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));   \
+            return DXMI_ELAUNCH;                                                    \
+        }                                                                           \
+    } while (0)
+
+__device__ __forceinline__ float dxmi_act(float v, int act) {
+    switch (act) {
+        case DXMI_ACT_LEAKY02: return v > 0.f ? v : 0.2f * v;
+        case DXMI_ACT_RELU:    return v > 0.f ? v : 0.f;
+        case DXMI_ACT_SILU:    return v / (1.f + __expf(-v));
+        default:               return v;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,487 @@
+// Implicit-GEMM convolution for gfx950: bf16 operands on v_mfma_f32_32x32x16_bf16, fp32
+// accumulate, NHWC activations.
+//
+// GEMM view   D[co][pixel] = sum_{tap,ci} W[tap][co][ci] * X[pixel + tap][ci]
+//   A operand = weights, pre-packed on the host side into MFMA A-fragment order so that one
+//               wave-instruction loads one contiguous 1 KiB fragment straight into VGPRs
+//               (weights are wave-private here, so they never go through LDS);
+//   B operand = input pixels.  A workgroup owns a 256-pixel output tile and stages the
+//               tile's input halo for CK input channels into LDS ONCE per channel chunk; the
+//               ksize*ksize taps then read shifted windows of that one LDS image (9x reuse of
+//               every staged byte for 3x3) with conflict-free ds_read_b128 (row pitch
+//               CK*2+16 B: an odd number of 16-B slots).
+// Fused into staging: zero padding (incl. the DDPM asymmetric (0,1,0,1) stride-2 pad),
+// nearest x2 upsampling, channel concat of two sources, fp32-NCHW -> K=27 im2col for the
+// 3-channel image convs.  Fused into the epilogue: bias, per-(n,co) temb term, residual
+// add, activation, bf16 pack (NHWC) or fp32 NCHW store.
+//
+// Reference call sites: see include/dxmi_hip.h (dxmi_conv2d_fwd).
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+    const bf16* in0;
+    const bf16* in1;
+    const bf16* w;
+    const float* bias;
+    const float* addvec;
+    const bf16* residual;
+    void* out;
+    int N, IH, IW, C0, C1, OH, OW, Cout;
+    int ksize, stride, pad, ups, act, addvec_ld, in_mode, out_mode;
+    int P, pre_act;          // ROWS mode: number of rows; activation applied to the input while staging
+    int TWl, THl, SUBS;      // tile geometry (log2 width, log2 height, images per tile)
+    int HH, HWd;             // halo height / width
+    int PT, CT, CB, KST;     // pixel tiles, cout tiles, 32-co blocks (padded), total 16-ci k-steps
+};
+
+template <int MB, int NB, int CK, int PMAX>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
+    constexpr int WAVES_PX = 8 / NB;
+    constexpr int WAVES_CO = 4 / WAVES_PX;
+    constexpr int BN = 32 * MB * WAVES_CO;
+    constexpr int ROWB = CK * 2 + 16;
+    constexpr int KSTEPS = CK / 16;
+    constexpr int PPP = CK / 8;  // 16-byte pieces per staged pixel
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave % WAVES_CO;
+    const int wpx = wave / WAVES_CO;
+
+    // XCD-aware block mapping: blocks b and b+8 share an XCD (round-robin dispatch), so the
+    // CT cout-tiles of one pixel tile are made consecutive *within* an XCD and re-read the
+    // input halo from that XCD's L2.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int j = bid >> 3;
+    const int pt = (j / p.CT) * 8 + xcd;
+    const int cot = j % p.CT;
+    if (pt >= p.PT) return;
+
+    const bool k27 = p.in_mode == DXMI_IN_NCHW_F32_K27;
+    const bool rows = p.in_mode == DXMI_IN_ROWS_F32;
+    const int TW = 1 << p.TWl, TH = 1 << p.THl;
+    int n0 = 0, oy0 = 0, ox0 = 0;
+    if (!rows) {
+        const int txn = p.OW >> p.TWl, tyn = p.OH >> p.THl;
+        const int tx = pt % txn;
+        const int ty = (pt / txn) % tyn;
+        n0 = (pt / (txn * tyn)) * p.SUBS;
+        oy0 = ty << p.THl;
+        ox0 = tx << p.TWl;
+    }
+    const int S = p.stride;
+    const int Cin = p.C0 + p.C1;
+    const int nchunks = k27 ? 1 : Cin / CK;
+    const int ntaps = (k27 || rows) ? 1 : p.ksize * p.ksize;
+    const int HHW = p.HH * p.HWd;
+    const int HP = p.SUBS * HHW;
+    const int npieces = HP * PPP;
+
+    // ---- per-lane LDS base offsets of the B fragments (pixel = lane&31, k-half = lane>>5)
+    int hoff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int pix = (wpx * NB + nb) * 32 + (lane & 31);
+        const int x = pix & (TW - 1);
+        const int y = (pix >> p.TWl) & (TH - 1);
+        const int sub = pix >> (p.TWl + p.THl);
+        int hp;
+        if (k27 || rows) hp = pix;
+        else hp = (sub * p.HH + y * S) * p.HWd + x * S;
+        hoff[nb] = hp * ROWB + (lane >> 5) * 16;
+    }
+
+    // ---- source pixel of every staging piece this thread owns (same for all chunks)
+    auto piece_src = [&](int i) -> int {
+        const int hp = i / PPP;
+        const int sub = hp / HHW;
+        const int rem = hp - sub * HHW;
+        const int hy = rem / p.HWd;
+        const int hx = rem - hy * p.HWd;
+        const int iy = oy0 * S - p.pad + hy;
+        const int ix = ox0 * S - p.pad + hx;
+        const int n = n0 + sub;
+        const bool ok = (iy >= 0) && (ix >= 0) && (iy < (p.IH << p.ups)) && (ix < (p.IW << p.ups)) && (n < p.N);
+        return ok ? ((n * p.IH + (iy >> p.ups)) * p.IW + (ix >> p.ups)) : -1;
+    };
+    int srcpix[PMAX > 0 ? PMAX : 1];
+    if (PMAX > 0 && p.in_mode == DXMI_IN_NHWC_BF16) {
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q) {
+            const int i = tid + q * 256;
+            srcpix[q] = (i < npieces) ? piece_src(i) : -1;
+        }
+    }
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+    const int cb0 = cot * (BN / 32) + wco * MB;  // first 32-co block of this wave
+    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(p.w);
+
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();  // everyone is done reading the previous chunk's LDS image
+        if (rows) {
+            // fp32 row-major [P][Cin] -> bf16, optional pre-activation (swish on the temb path)
+            const float* xin = reinterpret_cast<const float*>(p.in0);
+            for (int i = tid; i < 256 * PPP; i += 256) {
+                const int r = i / PPP, pc = i % PPP;
+                const long grow = (long)pt * 256 + r;
+                bf16x8 v;
+                if (grow < p.P) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(xin + grow * Cin + c * CK + pc * 8);
+                    const f32x4 hi = *reinterpret_cast<const f32x4*>(xin + grow * Cin + c * CK + pc * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = (bf16)dxmi_act(lo[e], p.pre_act);
+                        v[4 + e] = (bf16)dxmi_act(hi[e], p.pre_act);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+                }
+                *reinterpret_cast<bf16x8*>(smem + r * ROWB + pc * 16) = v;
+            }
+        } else if (k27) {
+            // one thread per output pixel: gather the 27 taps (k = ci*9 + ky*3 + kx)
+            const float* xin = reinterpret_cast<const float*>(p.in0);
+            const int pix = tid;
+            const int x = pix & (TW - 1);
+            const int y = (pix >> p.TWl) & (TH - 1);
+            const int sub = pix >> (p.TWl + p.THl);
+            const int n = n0 + sub, oy = oy0 + y, ox = ox0 + x;
+            bf16 v[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                float f = 0.f;
+                if (k < 27) {
+                    const int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
+                    const int iy = oy + ky - 1, ix = ox + kx - 1;
+                    if (n < p.N && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+                        f = xin[((n * 3 + ci) * p.IH + iy) * p.IW + ix];
+                }
+                v[k] = (bf16)f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf16x8 pk;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk[e] = v[q * 8 + e];
+                *reinterpret_cast<bf16x8*>(smem + pix * ROWB + q * 16) = pk;
+            }
+        } else {
+            const int cbase = c * CK;
+            const bool first = cbase < p.C0;
+            const bf16* src = first ? p.in0 : p.in1;
+            const int Cs = first ? p.C0 : p.C1;
+            const int coff = first ? cbase : cbase - p.C0;
+            if (PMAX > 0) {
+                bf16x8 v[PMAX > 0 ? PMAX : 1];
+#pragma unroll
+                for (int q = 0; q < PMAX; ++q) {
+                    const int i = tid + q * 256;
+                    const int pc = i % PPP;
+                    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    v[q] = z;
+                    if (srcpix[q] >= 0)
+                        v[q] = *reinterpret_cast<const bf16x8*>(src + (size_t)srcpix[q] * Cs + coff + pc * 8);
+                }
+#pragma unroll
+                for (int q = 0; q < PMAX; ++q) {
+                    const int i = tid + q * 256;
+                    if (i < npieces)
+                        *reinterpret_cast<bf16x8*>(smem + (i / PPP) * ROWB + (i % PPP) * 16) = v[q];
+                }
+            } else {
+                for (int i = tid; i < npieces; i += 256) {
+                    const int sp = piece_src(i);
+                    const int pc = i % PPP;
+                    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (sp >= 0) v = *reinterpret_cast<const bf16x8*>(src + (size_t)sp * Cs + coff + pc * 8);
+                    *reinterpret_cast<bf16x8*>(smem + (i / PPP) * ROWB + pc * 16) = v;
+                }
+            }
+        }
+        __syncthreads();
+
+        for (int tap = 0; tap < ntaps; ++tap) {
+            const int ky = tap / p.ksize, kx = tap - ky * p.ksize;
+            const int toff = (k27 || rows) ? 0 : (ky * p.HWd + kx) * ROWB;
+            bf16x8 a[MB][KSTEPS];
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    a[mb][ks] = wfrag[((size_t)(tap * p.KST + c * KSTEPS + ks) * p.CB + cb0 + mb) * 64 + lane];
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                bf16x8 b[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    b[nb] = *reinterpret_cast<const bf16x8*>(smem + hoff[nb] + toff + ks * 32);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][ks], b[nb], acc[mb][nb], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: D[co][pixel]; lane holds pixel = lane&31, co = 8g + 4h + {0..3}
+    const int h = lane >> 5;
+    // wide (BN = 128) instantiations only carry the vector path (the host never routes NCHW-fp32 or
+    // Cout%4 != 0 outputs to them); the scalar path lives in the narrow BN = 32 kernels.
+    const bool vec_ok = (BN == 128) || ((p.out_mode != DXMI_OUT_NCHW_F32) && ((p.Cout & 3) == 0));
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int pix = (wpx * NB + nb) * 32 + (lane & 31);
+        size_t opix;
+        int n = 0, oy = 0, ox = 0;
+        bool pvalid;
+        if (rows) {
+            const long grow = (long)pt * 256 + pix;
+            pvalid = grow < p.P;
+            opix = (size_t)grow;
+        } else {
+            const int x = pix & (TW - 1);
+            const int y = (pix >> p.TWl) & (TH - 1);
+            const int sub = pix >> (p.TWl + p.THl);
+            n = n0 + sub; oy = oy0 + y; ox = ox0 + x;
+            pvalid = n < p.N;
+            opix = ((size_t)n * p.OH + oy) * p.OW + ox;
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = (cb0 + mb) * 32 + 8 * g + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mb][nb][4 * g + e];
+                if (pvalid && co < p.Cout) {
+                    if (vec_ok) {
+                        if (p.bias) {
+                            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                        }
+                        if (p.addvec) {
+                            const f32x4 av = *reinterpret_cast<const f32x4*>(p.addvec + (size_t)n * p.addvec_ld + co);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += av[e];
+                        }
+                        if (p.residual) {
+                            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.residual + opix * p.Cout + co);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = dxmi_act(v[e], p.act);
+                        if (p.out_mode == DXMI_OUT_ROWS_F32) {
+                            f32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = v[e];
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + opix * p.Cout + co) = o;
+                        } else {
+                            bf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.out) + opix * p.Cout + co) = o;
+                        }
+                    } else if constexpr (BN != 128) {
+                        // narrow heads (conv_out Cout=3) / NCHW fp32 output: scalar stores
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (co + e < p.Cout) {
+                                float r = v[e] + (p.bias ? p.bias[co + e] : 0.f);
+                                if (p.addvec) r += p.addvec[(size_t)n * p.addvec_ld + co + e];
+                                r = dxmi_act(r, p.act);
+                                if (p.out_mode == DXMI_OUT_NCHW_F32)
+                                    reinterpret_cast<float*>(p.out)[(((size_t)n * p.Cout + co + e) * p.OH + oy) * p.OW + ox] = r;
+                                else if (p.out_mode == DXMI_OUT_ROWS_F32)
+                                    reinterpret_cast<float*>(p.out)[opix * p.Cout + co + e] = r;
+                                else
+                                    reinterpret_cast<bf16*>(p.out)[opix * p.Cout + co + e] = (bf16)r;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- weight packing: OIHW fp32 -> [tap][kstep][cb][lane][8] bf16
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, bf16* __restrict__ dst, int Cout, int Cin,
+                                        int ks, int flip, int k27, int CB, int KST, long total) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int jj = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    long r = idx >> 9;
+    const int cb = r % CB; r /= CB;
+    const int kst = r % KST; r /= KST;
+    const int tap = (int)r;
+    const int co = cb * 32 + (lane & 31);
+    const int k = kst * 16 + 8 * (lane >> 5) + jj;
+    float v = 0.f;
+    if (k27) {
+        // logical GEMM: Cout x 27(+5 zero); weight OIHW flattened over (ci,ky,kx)
+        if (co < Cout && k < 27) v = w[(long)co * 27 + k];
+    } else if (!flip) {
+        if (co < Cout && k < Cin) {
+            const int ky = tap / ks, kx = tap % ks;
+            v = w[(((long)co * Cin + k) * ks + ky) * ks + kx];
+        }
+    } else {
+        // data-gradient operator: output channels = original Cin (= "Cout" arg here is the
+        // logical output count), taps flipped, in/out swapped.  w is [Cin_logical_out? ...]
+        // Here: logical Cout = original Cin, logical Cin = original Cout, w is the ORIGINAL
+        // OIHW tensor [origCout=Cin][origCin=Cout][ks][ks].
+        if (co < Cout && k < Cin) {
+            const int ky = tap / ks, kx = tap % ks;
+            v = w[(((long)k * Cout + co) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
+        }
+    }
+    dst[idx] = (bf16)v;
+}
+
+template <int MB, int NB, int CK, int PMAX>
+int launch_conv(const ConvArgs& a, size_t lds, hipStream_t st) {
+    auto kern = conv_igemm_kernel<MB, NB, CK, PMAX>;
+    static bool attr_set = false;  // benign race: idempotent
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    const int PT8 = (a.PT + 7) / 8 * 8;
+    dim3 grid(PT8 * a.CT), block(256);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);
+    DXMI_CHECK_LAUNCH("dxmi_conv2d_fwd");
+    return DXMI_OK;
+}
+
+int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+}  // namespace
+
+extern "C" int64_t dxmi_packed_conv_weight_bytes(int32_t Cout, int32_t Cin, int32_t ksize, int32_t k27) {
+    const int64_t CB = (Cout + 31) / 32;
+    if (k27) return CB * 2 * 64 * 8 * 2;
+    const int64_t KST = (Cin + 15) / 16;
+    return (int64_t)ksize * ksize * KST * CB * 64 * 8 * 2;
+}
+
+extern "C" int dxmi_pack_conv_weight(const float* w, void* dst, int32_t Cout, int32_t Cin, int32_t ksize,
+                                     int32_t transpose_flip, int32_t k27, void* stream) {
+    DXMI_CHECK_ARG(w && dst, "dxmi_pack_conv_weight: null pointer");
+    DXMI_CHECK_ARG(ksize == 1 || ksize == 3, "dxmi_pack_conv_weight: ksize must be 1 or 3");
+    DXMI_CHECK_ARG(!k27 || (Cin == 3 && ksize == 3 && !transpose_flip), "dxmi_pack_conv_weight: k27 needs Cin=3,k=3");
+    const int CB = (Cout + 31) / 32;
+    const int KST = k27 ? 2 : (Cin + 15) / 16;
+    const int taps = k27 ? 1 : ksize * ksize;
+    const long total = (long)taps * KST * CB * 512;
+    const int threads = 256;
+    const long blocks = (total + threads - 1) / threads;
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)blocks), dim3(threads), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<bf16*>(dst), Cout, Cin, ksize, transpose_flip, k27, CB, KST, total);
+    DXMI_CHECK_LAUNCH("dxmi_pack_conv_weight");
+    return DXMI_OK;
+}
+
+namespace {
+
+int dispatch_conv(ConvArgs& a, int variant, hipStream_t st) {
+    constexpr int CK = 32;
+    const bool flat = a.in_mode != DXMI_IN_NHWC_BF16;
+    const int HP = flat ? 256 : a.SUBS * a.HH * a.HWd;
+    const size_t lds = (size_t)HP * (CK * 2 + 16);
+    DXMI_CHECK_ARG(lds <= 160 * 1024, "dxmi_conv2d_fwd: LDS image %zu too large", lds);
+    const int npieces = HP * (CK / 8);
+    const bool small_halo = npieces <= 6 * 256;
+    // Tiling variants: cout tile BN = 128 when Cout allows it, else 32 (conv_out, heads).
+    if (a.Cout % 128 == 0 && a.out_mode != DXMI_OUT_NCHW_F32) {
+        a.CT = a.Cout / 128;
+        if (variant == 1) return small_halo ? launch_conv<2, 4, CK, 6>(a, lds, st) : launch_conv<2, 4, CK, 0>(a, lds, st);
+        return small_halo ? launch_conv<1, 8, CK, 6>(a, lds, st) : launch_conv<1, 8, CK, 0>(a, lds, st);
+    }
+    a.CT = a.CB;  // one 32-co block per workgroup, 4 waves split the 256 pixels
+    return small_halo ? launch_conv<1, 2, CK, 6>(a, lds, st) : launch_conv<1, 2, CK, 0>(a, lds, st);
+}
+
+}  // namespace
+
+extern "C" int dxmi_conv2d_fwd(const dxmi_conv_desc* d, void* stream) {
+    DXMI_CHECK_ARG(d && d->in0 && d->wpacked && d->out, "dxmi_conv2d_fwd: null pointer");
+    const bool k27 = d->in_mode == DXMI_IN_NCHW_F32_K27;
+    DXMI_CHECK_ARG(d->in_mode == DXMI_IN_NHWC_BF16 || k27, "dxmi_conv2d_fwd: in_mode %d unsupported", d->in_mode);
+    DXMI_CHECK_ARG(d->out_mode == DXMI_OUT_NHWC_BF16 || d->out_mode == DXMI_OUT_NCHW_F32, "dxmi_conv2d_fwd: out_mode %d unsupported", d->out_mode);
+    const int Cin = d->C0 + d->C1;
+    DXMI_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "dxmi_conv2d_fwd: ksize %d unsupported", d->ksize);
+    DXMI_CHECK_ARG(d->stride == 1 || d->stride == 2, "dxmi_conv2d_fwd: stride %d unsupported", d->stride);
+    DXMI_CHECK_ARG(d->N > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0, "dxmi_conv2d_fwd: empty shape");
+    DXMI_CHECK_ARG((d->OW & (d->OW - 1)) == 0 && (d->OH & (d->OH - 1)) == 0 && d->OW >= 4 && d->OH >= 4,
+                   "dxmi_conv2d_fwd: OH/OW must be powers of two >= 4 (got %dx%d)", d->OH, d->OW);
+    if (k27) {
+        DXMI_CHECK_ARG(d->C0 == 3 && d->C1 == 0 && d->ksize == 3 && d->stride == 1 && d->pad == 1 && !d->upsample &&
+                           d->IH == d->OH && d->IW == d->OW,
+                       "dxmi_conv2d_fwd: K27 mode needs a 3-channel 3x3/s1/p1 conv");
+    } else {
+        DXMI_CHECK_ARG(Cin % 32 == 0 && d->C0 % 32 == 0, "dxmi_conv2d_fwd: Cin (%d+%d) must be a multiple of 32", d->C0, d->C1);
+        DXMI_CHECK_ARG(d->C1 == 0 || d->in1, "dxmi_conv2d_fwd: C1>0 but in1 is NULL");
+        const int VIH = d->IH << (d->upsample ? 1 : 0), VIW = d->IW << (d->upsample ? 1 : 0);
+        DXMI_CHECK_ARG((d->OH - 1) * d->stride - d->pad < VIH && (d->OW - 1) * d->stride - d->pad < VIW && d->pad >= 0 && d->pad < d->ksize,
+                       "dxmi_conv2d_fwd: output %dx%d inconsistent with input %dx%d", d->OH, d->OW, VIH, VIW);
+    }
+    DXMI_CHECK_ARG(d->out_mode != DXMI_OUT_NCHW_F32 || !d->residual, "dxmi_conv2d_fwd: residual unsupported with NCHW output");
+    DXMI_CHECK_ARG(!d->residual || d->Cout % 4 == 0, "dxmi_conv2d_fwd: residual needs Cout%%4==0");
+
+    ConvArgs a;
+    a.in0 = (const bf16*)d->in0; a.in1 = (const bf16*)d->in1; a.w = (const bf16*)d->wpacked;
+    a.bias = d->bias; a.addvec = d->addvec; a.residual = (const bf16*)d->residual; a.out = d->out;
+    a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.C0 = d->C0; a.C1 = d->C1; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
+    a.ksize = d->ksize; a.stride = d->stride; a.pad = d->pad; a.ups = d->upsample ? 1 : 0; a.act = d->act;
+    a.addvec_ld = d->addvec_ld; a.in_mode = d->in_mode; a.out_mode = d->out_mode; a.P = 0; a.pre_act = 0;
+    const int TW = d->OW < 32 ? d->OW : 32;
+    int TH = 256 / TW; if (TH > d->OH) TH = d->OH;
+    a.TWl = ilog2(TW); a.THl = ilog2(TH); a.SUBS = 256 / (TW * TH);
+    if (k27) { a.HH = TH; a.HWd = TW; }
+    else { a.HH = (TH - 1) * d->stride + d->ksize; a.HWd = (TW - 1) * d->stride + d->ksize; }
+    const int ngroups = (d->N + a.SUBS - 1) / a.SUBS;
+    a.PT = ngroups * (d->OH / TH) * (d->OW / TW);
+    a.CB = (d->Cout + 31) / 32;
+    a.KST = k27 ? 2 : Cin / 16;
+    return dispatch_conv(a, d->variant, (hipStream_t)stream);
+}
+
+// Dense layer on the same MFMA path: out[P][M] = post(pre(x[P][K]) @ W[M][K]^T + b), fp32 rows
+// in/out, bf16 operands.  W packed by dxmi_pack_conv_weight(ksize=1).
+extern "C" int dxmi_linear_fwd(const float* x, const void* wpacked, const float* bias, float* out, int32_t P,
+                               int32_t K, int32_t M, int32_t pre_act, int32_t post_act, void* stream) {
+    DXMI_CHECK_ARG(x && wpacked && out, "dxmi_linear_fwd: null pointer");
+    DXMI_CHECK_ARG(P > 0 && M > 0 && K > 0 && K % 32 == 0, "dxmi_linear_fwd: K (%d) must be a positive multiple of 32", K);
+    ConvArgs a;
+    a.in0 = (const bf16*)x; a.in1 = nullptr; a.w = (const bf16*)wpacked; a.bias = bias; a.addvec = nullptr;
+    a.residual = nullptr; a.out = out;
+    a.N = 1; a.IH = 1; a.IW = P; a.C0 = K; a.C1 = 0; a.OH = 1; a.OW = P; a.Cout = M;
+    a.ksize = 1; a.stride = 1; a.pad = 0; a.ups = 0; a.act = post_act; a.addvec_ld = 0;
+    a.in_mode = DXMI_IN_ROWS_F32; a.out_mode = DXMI_OUT_ROWS_F32; a.P = P; a.pre_act = pre_act;
+    a.TWl = 5; a.THl = 3; a.SUBS = 1; a.HH = 8; a.HWd = 32;
+    a.PT = (P + 255) / 256; a.CB = (M + 31) / 32; a.KST = K / 16;
+    return dispatch_conv(a, 0, (hipStream_t)stream);
+}

@@ -1,0 +1,239 @@
+// HBM-bound / tiny kernels of the DxMI hot path for gfx950: sampler transition, schedule
+// gathers (integer index path), timestep sinusoid, value-net pooling + head, layout edges.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// sinusoidal timestep embedding (unet_small.py:9-27 / models/cm/nn.py:119-137)
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, float* __restrict__ out, int N, int dim,
+                                          int order, float log_period) {
+    const int half = dim / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * half) return;
+    const int n = idx / half, i = idx % half;
+    const float denom = order == 0 ? (float)(half - 1) : (float)half;
+    // same fp32 evaluation order as the reference: exp(arange * -(log(P)/denom)) (order 0) or
+    // exp(-log(P) * arange / denom) (order 1)
+    float freq;
+    if (order == 0) freq = expf((float)i * -(log_period / denom));
+    else freq = expf(-log_period * (float)i / denom);
+    const float arg = t[n] * freq;
+    const float s = sinf(arg), c = cosf(arg);
+    float* o = out + (size_t)n * dim;
+    if (order == 0) { o[i] = s; o[half + i] = c; }
+    else { o[i] = c; o[half + i] = s; }
+    if ((dim & 1) && i == 0) o[dim - 1] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------
+// INT path: gather the per-sample schedule scalars by integer timestep.
+__global__ void var_gather_sched_kernel(const int64_t* __restrict__ t, const float* __restrict__ cont,
+                                        const float* __restrict__ xmul_tab, const float* __restrict__ cmul_tab,
+                                        const float* __restrict__ log_betas_all, float* __restrict__ tau,
+                                        float* __restrict__ xmul, float* __restrict__ cmul, float* __restrict__ sigma,
+                                        int N, int T) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= N) return;
+    long ti = t[b];
+    if (ti < 0) ti += T;  // python-style wrap, as torch indexing does
+    tau[b] = cont[ti];
+    xmul[b] = xmul_tab[ti];
+    cmul[b] = cmul_tab[ti];
+    sigma[b] = expf(log_betas_all[ti]);
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused sampler transition.  One workgroup per sample: x, eps, z are read once; x', mean,
+// control written once; the CHW log-prob mean is reduced in-kernel (fp32, fixed order).
+__global__ __launch_bounds__(256) void var_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                      const float* __restrict__ z, const float* __restrict__ xmul,
+                                                      const float* __restrict__ cmul, const float* __restrict__ sigma,
+                                                      float* __restrict__ x_next, float* __restrict__ mean,
+                                                      float* __restrict__ control, float* __restrict__ logp, int CHW) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float xm = xmul[b], cm = cmul[b], sg = sigma[b];
+    const float var2 = 2.f * sg * sg;
+    const float log_sg = logf(sg);
+    const float half_log_2pi = 0.918938533204672742f;  // log(sqrt(2*pi))
+    const size_t base = (size_t)b * CHW;
+    float acc = 0.f;
+    for (int i = threadIdx.x * 4; i < CHW; i += 256 * 4) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + i);
+        const f32x4 ev = *reinterpret_cast<const f32x4*>(eps + base + i);
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + base + i);
+        f32x4 xn, mu, ct;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xs = xv[e] * xm;
+            ct[e] = cm * ev[e];
+            mu[e] = xs + ct[e];
+            xn[e] = mu[e] + sg * zv[e];
+            const float d = xn[e] - mu[e];
+            acc += -(d * d) / var2 - log_sg - half_log_2pi;
+        }
+        *reinterpret_cast<f32x4*>(x_next + base + i) = xn;
+        if (mean) *reinterpret_cast<f32x4*>(mean + base + i) = mu;
+        if (control) *reinterpret_cast<f32x4*>(control + base + i) = ct;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && logp) logp[b] = (red[0] + red[1] + red[2] + red[3]) / (float)CHW;
+}
+
+// ---------------------------------------------------------------------------------------
+// value net: optional 2x2 average pool then activation, NHWC bf16, 8 channels per thread
+__global__ void pool_act_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int N, int H, int W, int C,
+                                int pool, int act) {
+    const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
+    const int C8 = C / 8;
+    const long total = (long)N * OH * OW * C8;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c8 = idx % C8;
+        long r = idx / C8;
+        const int ox = r % OW; r /= OW;
+        const int oy = r % OH;
+        const int n = (int)(r / OH);
+        float v[8];
+        if (pool) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(in + (((size_t)n * H + 2 * oy + dy) * W + 2 * ox + dx) * C + c8 * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)a[e];
+                }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= 0.25f;
+        } else {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(in + (((size_t)n * H + oy) * W + ox) * C + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)a[e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)dxmi_act(v[e], act);
+        *reinterpret_cast<bf16x8*>(out + (((size_t)n * OH + oy) * OW + ox) * C + c8 * 8) = o;
+    }
+}
+
+// value head: relu -> sum over HW -> dot(w[C]) + b -> out_w*y + out_b ; one wave per image
+__global__ __launch_bounds__(64) void value_head_kernel(const bf16* __restrict__ in, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float out_w, float out_b,
+                                                       float* __restrict__ out, int HW, int C) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        float s = 0.f;
+        for (int px = 0; px < HW; ++px) {
+            const float v = (float)in[((size_t)n * HW + px) * C + c];
+            s += v > 0.f ? v : 0.f;
+        }
+        acc += s * w[c];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[n] = (acc + b[0]) * out_w + out_b;
+}
+
+// ---------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, bf16* __restrict__ out, int N, int C, int HW) {
+    const long total = (long)N * C * HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = idx % C;
+        const long r = idx / C;
+        const int px = r % HW;
+        const int n = (int)(r / HW);
+        out[idx] = (bf16)in[((size_t)n * C + c) * HW + px];
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const bf16* __restrict__ in, float* __restrict__ out, int N, int C, int HW) {
+    const long total = (long)N * C * HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int px = idx % HW;
+        const long r = idx / HW;
+        const int c = r % C;
+        const int n = (int)(r / C);
+        out[idx] = (float)in[((size_t)n * HW + px) * C + c];
+    }
+}
+
+inline unsigned grid_for(long total, int threads) {
+    long b = (total + threads - 1) / threads;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int dxmi_timestep_embedding(const float* t, float* out, int32_t N, int32_t dim, int32_t order,
+                                       float max_period, void* stream) {
+    DXMI_CHECK_ARG(t && out && N > 0 && dim >= 4, "dxmi_timestep_embedding: bad arguments");
+    const int total = N * (dim / 2);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, out,
+                       N, dim, order, logf(max_period));
+    DXMI_CHECK_LAUNCH("dxmi_timestep_embedding");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_var_gather_sched(const int64_t* t, const float* continuous_steps, const float* xmul_tab,
+                                     const float* cmul_tab, const float* log_betas_all, float* tau, float* xmul,
+                                     float* cmul, float* sigma, int32_t N, int32_t T, void* stream) {
+    DXMI_CHECK_ARG(t && continuous_steps && xmul_tab && cmul_tab && log_betas_all && tau && xmul && cmul && sigma,
+                   "dxmi_var_gather_sched: null pointer");
+    hipLaunchKernelGGL(var_gather_sched_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, t,
+                       continuous_steps, xmul_tab, cmul_tab, log_betas_all, tau, xmul, cmul, sigma, N, T);
+    DXMI_CHECK_LAUNCH("dxmi_var_gather_sched");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_var_step_fwd(const float* x, const float* eps, const float* z, const float* xmul,
+                                 const float* cmul, const float* sigma, float* x_next, float* mean, float* control,
+                                 float* logp, int32_t N, int32_t CHW, void* stream) {
+    DXMI_CHECK_ARG(x && eps && z && xmul && cmul && sigma && x_next, "dxmi_var_step_fwd: null pointer");
+    DXMI_CHECK_ARG(N > 0 && CHW > 0 && CHW % 4 == 0, "dxmi_var_step_fwd: CHW (%d) must be a multiple of 4", CHW);
+    hipLaunchKernelGGL(var_step_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, eps, z, xmul, cmul, sigma,
+                       x_next, mean, control, logp, CHW);
+    DXMI_CHECK_LAUNCH("dxmi_var_step_fwd");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_pool_act(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pool,
+                             int32_t act, void* stream) {
+    DXMI_CHECK_ARG(in && out && C % 8 == 0 && (!pool || (H % 2 == 0 && W % 2 == 0)), "dxmi_pool_act: bad arguments");
+    const long total = (long)N * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C / 8);
+    hipLaunchKernelGGL(pool_act_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)in,
+                       (bf16*)out, N, H, W, C, pool, act);
+    DXMI_CHECK_LAUNCH("dxmi_pool_act");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_value_head(const void* in, const float* w, const float* b, float out_w, float out_b, float* out,
+                               int32_t N, int32_t HW, int32_t C, void* stream) {
+    DXMI_CHECK_ARG(in && w && b && out, "dxmi_value_head: null pointer");
+    hipLaunchKernelGGL(value_head_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, (const bf16*)in, w, b, out_w,
+                       out_b, out, HW, C);
+    DXMI_CHECK_LAUNCH("dxmi_value_head");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_nchw_f32_to_nhwc_bf16(const float* in, void* out, int32_t N, int32_t C, int32_t HW, void* stream) {
+    DXMI_CHECK_ARG(in && out, "dxmi_nchw_f32_to_nhwc_bf16: null pointer");
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long)N * C * HW, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                       (bf16*)out, N, C, HW);
+    DXMI_CHECK_LAUNCH("dxmi_nchw_f32_to_nhwc_bf16");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_nhwc_bf16_to_nchw_f32(const void* in, float* out, int32_t N, int32_t C, int32_t HW, void* stream) {
+    DXMI_CHECK_ARG(in && out, "dxmi_nhwc_bf16_to_nchw_f32: null pointer");
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long)N * C * HW, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)in, out, N, C, HW);
+    DXMI_CHECK_LAUNCH("dxmi_nhwc_bf16_to_nchw_f32");
+    return DXMI_OK;
+}

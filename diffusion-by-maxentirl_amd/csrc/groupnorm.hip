@@ -1,0 +1,218 @@
+// GroupNorm (+SiLU) over NHWC bf16 for gfx950 — the HBM-bound kernel of the U-Net.
+//
+// One workgroup owns one (image, channel-slice): every thread loads all of its 8- or
+// 16-byte pieces up front (whole slice resident in VGPRs, >= 16 KB in flight per wave), so
+// HBM sees exactly one read and one write of the tensor.  Statistics are two-pass in fp32
+// (mean, then centred sum of squares) from registers: wavefront __shfl_xor reduction, then a
+// fixed-order cross-wave sum through LDS, so results are bitwise reproducible.
+// The input may be a virtual channel concat [in0 | in1] (U-Net skip connections); the
+// output is always one dense NHWC tensor.
+//
+// Reference: Normalize()/nonlinearity, models/DxMI/unet_small.py:30-36,119-126,169,329-330;
+// GroupNorm32, models/cm/nn.py:19-21.
+#include "common.h"
+
+namespace {
+
+struct GnArgs {
+    const bf16* in0;
+    const bf16* in1;
+    const float* gamma;
+    const float* beta;
+    bf16* out;
+    int C0, C1, HW, groups, slices, ppp, cpg, gps;  // ppp = pieces per pixel in slice, gps = groups per slice
+    float eps;
+    int silu;
+    int fast;  // xor-shuffle group reduction applies
+};
+
+template <int VEC>
+struct PieceT;
+template <>
+struct PieceT<8> { typedef bf16x8 type; };
+template <>
+struct PieceT<4> { typedef bf16x4 type; };
+
+// VEC channels per piece; PIECES pieces per thread; blockDim.x is a multiple of lcm(ppp,64)
+template <int VEC, int PIECES>
+__global__ __launch_bounds__(512) void gn_silu_kernel(GnArgs p) {
+    typedef typename PieceT<VEC>::type piece_t;
+    __shared__ float red[512 / 64][32];  // [wave][group in slice] partial sums
+    __shared__ float stat[32];
+
+    const int C = p.C0 + p.C1;
+    const int n = blockIdx.x / p.slices;
+    const int s = blockIdx.x % p.slices;
+    const int Csl = C / p.slices;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+    const int pc = tid % p.ppp;           // constant per thread since nthr % ppp == 0
+    const int prow = tid / p.ppp;
+    const int rows_per_iter = nthr / p.ppp;
+    const int c = s * Csl + pc * VEC;     // first channel of this thread's pieces
+    const int gl = (pc * VEC) / p.cpg;    // group index within the slice
+    const bool from0 = c < p.C0;
+    const bf16* src = from0 ? p.in0 : p.in1;
+    const int Cs = from0 ? p.C0 : p.C1;
+    const int cs = from0 ? c : c - p.C0;
+
+    // The whole slice stays resident as RAW bf16 pairs; every pass re-expands them (2 VALU per
+    // pair).  The empty asm keeps hipcc from hoisting the fp32 expansions out of the passes, which
+    // would triple the register footprint.
+    constexpr int W = VEC / 2;
+    uint32_t v[PIECES][W];
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        const int px = prow + q * rows_per_iter;
+        if (px < p.HW) {
+            const piece_t t = *reinterpret_cast<const piece_t*>(src + ((size_t)n * p.HW + px) * Cs + cs);
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[q][e] = reinterpret_cast<const uint32_t*>(&t)[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < W; ++e) v[q][e] = 0u;
+        }
+    }
+#define GN_LO(w) __uint_as_float((w) << 16)
+#define GN_HI(w) __uint_as_float((w) & 0xffff0000u)
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            asm volatile("" : "+v"(v[q][e]));
+            sum += GN_LO(v[q][e]) + GN_HI(v[q][e]);  // rows past HW hold zeros
+        }
+    }
+    const float inv_cnt = 1.f / (float)(p.HW * p.cpg);
+
+    // ---- block reduction per group, fixed order (bitwise reproducible).
+    // Fast path (ppp and pieces-per-group powers of two, ppp <= 64): lanes l, l+ppp, ... share a
+    // channel piece and ppt adjacent pieces share a group -> xor-shuffles; otherwise a masked
+    // wave sum per group.
+    const int ppt = p.cpg / VEC;  // pieces per group per pixel
+    auto group_reduce = [&](float val) -> float {
+        if (p.fast) {
+            float t = val;
+            for (int o = 32; o >= p.ppp; o >>= 1) t += __shfl_xor(t, o, 64);
+            for (int o = ppt >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (lane < p.ppp && (lane % ppt) == 0) red[wave][gl] = t;
+        } else {
+            for (int g = 0; g < p.gps; ++g) {
+                float t = wave_sum(gl == g ? val : 0.f);
+                if (lane == 0) red[wave][g] = t;
+            }
+        }
+        __syncthreads();
+        if (tid < p.gps) {
+            float t = 0.f;
+            for (int w = 0; w < nwaves; ++w) t += red[w][tid];
+            stat[tid] = t;
+        }
+        __syncthreads();
+        const float r = stat[gl];
+        __syncthreads();
+        return r;
+    };
+
+    const float mean = group_reduce(sum) * inv_cnt;
+    float ssq = 0.f;
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        const int px = prow + q * rows_per_iter;
+        if (px < p.HW) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                asm volatile("" : "+v"(v[q][e]));
+                const float d0 = GN_LO(v[q][e]) - mean, d1 = GN_HI(v[q][e]) - mean;
+                ssq += d0 * d0 + d1 * d1;
+            }
+        }
+    }
+    const float var = group_reduce(ssq) * inv_cnt;
+    const float rstd = rsqrtf(var + p.eps);
+
+    float ga[VEC], be[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        ga[e] = p.gamma[c + e] * rstd;
+        be[e] = p.beta[c + e] - mean * ga[e];
+    }
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        const int px = prow + q * rows_per_iter;
+        if (px < p.HW) {
+            piece_t o;
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                asm volatile("" : "+v"(v[q][e]));
+                float y0 = GN_LO(v[q][e]) * ga[2 * e] + be[2 * e];
+                float y1 = GN_HI(v[q][e]) * ga[2 * e + 1] + be[2 * e + 1];
+                if (p.silu) {
+                    y0 = y0 / (1.f + __expf(-y0));
+                    y1 = y1 / (1.f + __expf(-y1));
+                }
+                o[2 * e] = (bf16)y0;
+                o[2 * e + 1] = (bf16)y1;
+            }
+            *reinterpret_cast<piece_t*>(p.out + ((size_t)n * p.HW + px) * C + c) = o;
+        }
+    }
+}
+
+int gcd(int a, int b) { return b ? gcd(b, a % b) : a; }
+
+template <int VEC>
+int launch_gn(const GnArgs& a, int N, int pieces, int threads, hipStream_t st) {
+    dim3 grid(N * a.slices), block(threads);
+#define GN_CASE(P)                                                                   \
+    if (pieces <= P) {                                                               \
+        hipLaunchKernelGGL((gn_silu_kernel<VEC, P>), grid, block, 0, st, a);         \
+        DXMI_CHECK_LAUNCH("dxmi_groupnorm_silu_fwd");                                \
+        return DXMI_OK;                                                              \
+    }
+    GN_CASE(1) GN_CASE(2) GN_CASE(4) GN_CASE(8) GN_CASE(12) GN_CASE(16) GN_CASE(24) GN_CASE(32)
+#undef GN_CASE
+    dxmi_set_error("dxmi_groupnorm_silu_fwd: %d pieces per thread unsupported", pieces);
+    return DXMI_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int dxmi_groupnorm_silu_fwd(const void* in0, int32_t C0, const void* in1, int32_t C1, const float* gamma,
+                                       const float* beta, void* out, int32_t N, int32_t HW, int32_t groups, float eps,
+                                       int32_t apply_silu, void* stream) {
+    DXMI_CHECK_ARG(in0 && out && gamma && beta, "dxmi_groupnorm_silu_fwd: null pointer");
+    DXMI_CHECK_ARG(C1 == 0 || in1, "dxmi_groupnorm_silu_fwd: C1>0 but in1 NULL");
+    const int C = C0 + C1;
+    DXMI_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0, "dxmi_groupnorm_silu_fwd: C=%d groups=%d", C, groups);
+    const int cpg = C / groups;
+    DXMI_CHECK_ARG(cpg % 4 == 0 && C0 % 4 == 0, "dxmi_groupnorm_silu_fwd: channels per group (%d) must be a multiple of 4", cpg);
+    const int VEC = (cpg % 8 == 0 && C0 % 8 == 0) ? 8 : 4;
+    // choose the number of channel slices (whole groups each) so a thread holds <= 16 pieces (VEC 8)
+    // or <= 32 pieces (VEC 4) at ~512 threads.
+    int slices = 1;
+    const int max_pieces = VEC == 8 ? 16 : 32;
+    int threads = 0, pieces = 0, ppp = 0;
+    for (;; slices *= 2) {
+        DXMI_CHECK_ARG(groups % slices == 0, "dxmi_groupnorm_silu_fwd: cannot slice %d groups for HW=%d C=%d", groups, HW, C);
+        const int Csl = C / slices;
+        ppp = Csl / VEC;
+        const int unit = ppp / gcd(ppp, 64) * 64;  // lcm(ppp, 64)
+        DXMI_CHECK_ARG(unit <= 512, "dxmi_groupnorm_silu_fwd: slice of %d channels unsupported", Csl);
+        long total = (long)HW * ppp;
+        threads = (512 / unit) * unit;
+        if (total < threads) threads = (int)((total + unit - 1) / unit) * unit;
+        pieces = (int)((total + threads - 1) / threads);
+        if (pieces <= max_pieces || slices == groups) break;
+    }
+    DXMI_CHECK_ARG(pieces <= 32, "dxmi_groupnorm_silu_fwd: tensor slice too large (HW=%d C=%d)", HW, C);
+    GnArgs a;
+    a.in0 = (const bf16*)in0; a.in1 = (const bf16*)in1; a.gamma = gamma; a.beta = beta; a.out = (bf16*)out;
+    a.C0 = C0; a.C1 = C1; a.HW = HW; a.groups = groups; a.slices = slices; a.ppp = ppp; a.cpg = cpg;
+    a.gps = groups / slices; a.eps = eps; a.silu = apply_silu;
+    const int ppt = cpg / VEC;
+    a.fast = (ppp <= 64) && ((ppp & (ppp - 1)) == 0) && ((ppt & (ppt - 1)) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    return VEC == 8 ? launch_gn<8>(a, N, pieces, threads, st) : launch_gn<4>(a, N, pieces, threads, st);
+}

@@ -1,0 +1,77 @@
+"""ctypes binding of libdxmi_hip.so (the C-ABI declared in include/dxmi_hip.h).
+
+The library is the ONLY compute path of this package: if it is missing, or no gfx950 device is
+visible when a kernel is requested, we raise — there is no CPU or torch fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdxmi_hip.so")
+
+c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_int64
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of struct dxmi_conv_desc (include/dxmi_hip.h)."""
+
+    _fields_ = [
+        ("in0", c_void_p), ("in1", c_void_p), ("wpacked", c_void_p), ("bias", c_void_p),
+        ("addvec", c_void_p), ("residual", c_void_p), ("out", c_void_p),
+        ("N", c_int), ("IH", c_int), ("IW", c_int), ("C0", c_int), ("C1", c_int),
+        ("OH", c_int), ("OW", c_int), ("Cout", c_int),
+        ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int), ("act", c_int),
+        ("addvec_ld", c_int), ("in_mode", c_int), ("out_mode", c_int), ("variant", c_int),
+    ]
+
+
+# symbol -> (restype, argtypes); kept in one table so tests can check it against the header.
+SIGNATURES = {
+    "dxmi_last_error": (ctypes.c_char_p, []),
+    "dxmi_version": (c_int, []),
+    "dxmi_device_check": (c_int, []),
+    "dxmi_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
+    "dxmi_packed_conv_weight_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "dxmi_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dxmi_groupnorm_silu_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "dxmi_attention_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "dxmi_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "dxmi_linear_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dxmi_var_step_fwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p]),
+    "dxmi_var_gather_sched": (c_int, [c_void_p] * 9 + [c_int, c_int, c_void_p]),
+    "dxmi_pool_act": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dxmi_value_head": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dxmi_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dxmi_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class DxmiError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and declare every prototype."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DxmiError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C diffusion-by-maxentirl_amd/csrc`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().dxmi_last_error().decode("utf-8", "replace")
+        raise DxmiError(f"{what} failed ({status}): {msg}")

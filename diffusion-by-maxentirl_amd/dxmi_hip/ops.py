@@ -1,0 +1,230 @@
+"""Tensor-level wrappers over the C-ABI.  torch is used only for device memory and streams.
+
+Activations are torch.bfloat16 NHWC tensors of shape [N, H, W, C]; network edges are fp32 NCHW.
+Every function launches asynchronously on torch's current stream and allocates its output with
+torch.empty unless `out=` is given (pass `out=` inside hipGraph capture to keep addresses fixed).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, load
+
+ACT_NONE, ACT_LEAKY02, ACT_RELU, ACT_SILU = 0, 1, 2, 3
+IN_NHWC_BF16, IN_NCHW_F32_K27 = 0, 1
+OUT_NHWC_BF16, OUT_NCHW_F32 = 0, 1
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.DxmiError("dxmi_hip ops need device tensors: the HIP library is the only compute path "
+                                 "(the CPU oracle lives under oracle/ and is test infrastructure)")
+
+
+def device_check():
+    check(load().dxmi_device_check(), "dxmi_device_check")
+
+
+class PackedConvWeight:
+    """bf16 MFMA-fragment-ordered copy of an OIHW fp32 weight."""
+
+    __slots__ = ("buf", "Cout", "Cin", "ksize", "k27")
+
+    def __init__(self, buf, Cout, Cin, ksize, k27):
+        self.buf, self.Cout, self.Cin, self.ksize, self.k27 = buf, Cout, Cin, ksize, k27
+
+
+def pack_conv_weight(w, transpose_flip=False, k27=False, out=None):
+    """w: fp32 [Cout, Cin, k, k] (or [M, K] for a linear layer) on the device."""
+    _need_cuda(w)
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    w = w.detach().contiguous().float()
+    O, I, k, _ = w.shape
+    Cout, Cin = (I, O) if transpose_flip else (O, I)
+    lib = load()
+    nbytes = lib.dxmi_packed_conv_weight_bytes(Cout, Cin, k, int(k27))
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    assert out.numel() == nbytes
+    check(lib.dxmi_pack_conv_weight(_ptr(w), _ptr(out), Cout, Cin, k, int(transpose_flip), int(k27), _stream()),
+          "dxmi_pack_conv_weight")
+    return PackedConvWeight(out, Cout, Cin, k, k27)
+
+
+def conv2d(x, pw, *, in1=None, bias=None, addvec=None, residual=None, stride=1, pad=None, pad_br=None, upsample=False,
+           act=ACT_NONE, out=None, out_nchw_f32=False, variant=0):
+    """x: NHWC bf16 [N,IH,IW,C0] (or NCHW fp32 [N,3,H,W] when pw.k27)."""
+    _need_cuda(x, in1, bias, addvec, residual, out)
+    k = pw.ksize
+    if pad is None:
+        pad = k // 2
+    d = ConvDesc()
+    if pw.k27:
+        N, _, IH, IW = x.shape
+        C0, C1 = 3, 0
+        assert x.dtype == torch.float32 and x.is_contiguous()
+    else:
+        N, IH, IW, C0 = x.shape
+        C1 = in1.shape[3] if in1 is not None else 0
+        assert x.dtype == torch.bfloat16 and x.is_contiguous()
+        assert in1 is None or (in1.dtype == torch.bfloat16 and in1.is_contiguous() and in1.shape[:3] == x.shape[:3])
+        assert C0 + C1 == pw.Cin, f"conv2d: input channels {C0}+{C1} != packed Cin {pw.Cin}"
+    VIH, VIW = (IH * 2, IW * 2) if upsample else (IH, IW)
+    if pad_br is None:
+        pad_br = pad
+    # pad = top/left zeros, pad_br = bottom/right zeros (DDPM Downsample: pad=0, pad_br=1, k3 s2;
+    # unet_small.py:69-76)
+    OH, OW = (VIH + pad + pad_br - k) // stride + 1, (VIW + pad + pad_br - k) // stride + 1
+    Cout = pw.Cout
+    if out is None:
+        if out_nchw_f32:
+            out = torch.empty((N, Cout, OH, OW), dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty((N, OH, OW, Cout), dtype=torch.bfloat16, device=x.device)
+    d.in0, d.in1, d.wpacked = x.data_ptr(), (in1.data_ptr() if in1 is not None else None), pw.buf.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    if addvec is not None:
+        assert addvec.dtype == torch.float32 and addvec.stride(-1) == 1
+        d.addvec = addvec.data_ptr()
+        d.addvec_ld = addvec.stride(0) if addvec.dim() == 2 else 0
+    else:
+        d.addvec, d.addvec_ld = None, 0
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and tuple(residual.shape) == (N, OH, OW, Cout)
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.out = out.data_ptr()
+    d.N, d.IH, d.IW, d.C0, d.C1, d.OH, d.OW, d.Cout = N, IH, IW, C0, C1, OH, OW, Cout
+    d.ksize, d.stride, d.pad, d.upsample, d.act = k, stride, pad, int(upsample), act
+    d.in_mode = IN_NCHW_F32_K27 if pw.k27 else IN_NHWC_BF16
+    d.out_mode = OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC_BF16
+    d.variant = variant
+    check(load().dxmi_conv2d_fwd(ctypes.byref(d), _stream()), "dxmi_conv2d_fwd")
+    return out
+
+
+def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, out=None):
+    _need_cuda(x, in1, gamma, beta, out)
+    N, H, W, C0 = x.shape
+    C1 = in1.shape[3] if in1 is not None else 0
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C0 + C1
+    if out is None:
+        out = torch.empty((N, H, W, C0 + C1), dtype=torch.bfloat16, device=x.device)
+    check(load().dxmi_groupnorm_silu_fwd(_ptr(x), C0, _ptr(in1), C1, _ptr(gamma), _ptr(beta), _ptr(out), N, H * W,
+                                         groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_silu_fwd")
+    return out
+
+
+def attention(qkv, heads, scale, out=None):
+    """qkv: [N, T, 3C] bf16 laid out [q|k|v]; returns [N, T, C] bf16."""
+    _need_cuda(qkv, out)
+    N, T, C3 = qkv.shape
+    C = C3 // 3
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
+    if out is None:
+        out = torch.empty((N, T, C), dtype=torch.bfloat16, device=qkv.device)
+    check(load().dxmi_attention_fwd(_ptr(qkv), _ptr(out), N, T, C, heads, float(scale), _stream()), "dxmi_attention_fwd")
+    return out
+
+
+def timestep_embedding(t, dim, order=0, max_period=10000.0, out=None):
+    _need_cuda(t, out)
+    t = t.float().contiguous()
+    if out is None:
+        out = torch.empty((t.numel(), dim), dtype=torch.float32, device=t.device)
+    check(load().dxmi_timestep_embedding(_ptr(t), _ptr(out), t.numel(), dim, order, float(max_period), _stream()),
+          "dxmi_timestep_embedding")
+    return out
+
+
+def linear(x, pw, bias=None, pre_act=ACT_NONE, post_act=ACT_NONE, out=None):
+    """x fp32 [P, K] -> fp32 [P, M]; pw = pack_conv_weight(W[M, K])."""
+    _need_cuda(x, bias, out)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == pw.Cin
+    P, K = x.shape
+    if out is None:
+        out = torch.empty((P, pw.Cout), dtype=torch.float32, device=x.device)
+    check(load().dxmi_linear_fwd(_ptr(x), _ptr(pw.buf), _ptr(bias), _ptr(out), P, K, pw.Cout, pre_act, post_act,
+                                 _stream()), "dxmi_linear_fwd")
+    return out
+
+
+def var_gather_sched(t, continuous_steps, xmul_tab, cmul_tab, log_betas_all):
+    _need_cuda(t, continuous_steps, xmul_tab, cmul_tab, log_betas_all)
+    assert t.dtype == torch.int64
+    N, T = t.numel(), continuous_steps.numel()
+    outs = [torch.empty(N, dtype=torch.float32, device=t.device) for _ in range(4)]
+    check(load().dxmi_var_gather_sched(_ptr(t), _ptr(continuous_steps), _ptr(xmul_tab), _ptr(cmul_tab),
+                                       _ptr(log_betas_all), *[_ptr(o) for o in outs], N, T, _stream()),
+          "dxmi_var_gather_sched")
+    return outs  # tau, xmul, cmul, sigma
+
+
+def var_step(x, eps, z, xmul, cmul, sigma, want_mean=True, want_control=True, outs=None):
+    """Fused sampler transition; all tensors fp32, x/eps/z [N,C,H,W], per-sample scalars [N]."""
+    _need_cuda(x, eps, z, xmul, cmul, sigma)
+    N = x.shape[0]
+    CHW = x.numel() // N
+    for t_ in (x, eps, z):
+        assert t_.dtype == torch.float32 and t_.is_contiguous()
+    if outs is None:
+        x_next = torch.empty_like(x)
+        mean = torch.empty_like(x) if want_mean else None
+        control = torch.empty_like(x) if want_control else None
+        logp = torch.empty(N, dtype=torch.float32, device=x.device)
+    else:
+        x_next, mean, control, logp = outs
+    check(load().dxmi_var_step_fwd(_ptr(x), _ptr(eps), _ptr(z), _ptr(xmul), _ptr(cmul), _ptr(sigma), _ptr(x_next),
+                                   _ptr(mean), _ptr(control), _ptr(logp), N, CHW, _stream()), "dxmi_var_step_fwd")
+    return x_next, mean, control, logp
+
+
+def pool_act(x, pool, act, out=None):
+    _need_cuda(x, out)
+    N, H, W, C = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    if out is None:
+        out = torch.empty((N, H // 2, W // 2, C) if pool else (N, H, W, C), dtype=torch.bfloat16, device=x.device)
+    check(load().dxmi_pool_act(_ptr(x), _ptr(out), N, H, W, C, int(pool), act, _stream()), "dxmi_pool_act")
+    return out
+
+
+def value_head(x, w, b, out_w=1.0, out_b=0.0, out=None):
+    _need_cuda(x, w, b, out)
+    N, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((N, 1), dtype=torch.float32, device=x.device)
+    check(load().dxmi_value_head(_ptr(x), _ptr(w), _ptr(b), float(out_w), float(out_b), _ptr(out), N, H * W, C,
+                                 _stream()), "dxmi_value_head")
+    return out
+
+
+def nchw_f32_to_nhwc_bf16(x, out=None):
+    _need_cuda(x, out)
+    N, C, H, W = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device)
+    check(load().dxmi_nchw_f32_to_nhwc_bf16(_ptr(x), _ptr(out), N, C, H * W, _stream()), "dxmi_nchw_f32_to_nhwc_bf16")
+    return out
+
+
+def nhwc_bf16_to_nchw_f32(x, out=None):
+    _need_cuda(x, out)
+    N, H, W, C = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    if out is None:
+        out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
+    check(load().dxmi_nhwc_bf16_to_nchw_f32(_ptr(x), _ptr(out), N, C, H * W, _stream()), "dxmi_nhwc_bf16_to_nchw_f32")
+    return out

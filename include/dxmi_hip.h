@@ -1,0 +1,169 @@
+/*
+ * dxmi_hip.h — C-ABI of libdxmi_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for
+ * the DxMI few-step sampling / training hot path.
+ *
+ * The reference (swyoon/Diffusion-by-MaxEntIRL) is pure Python on torch.nn and has NO FFI of
+ * its own; every entry point below therefore names the reference *Python* call site whose
+ * torch ops it replaces (file:line relative to the reference root).  The Python host modules
+ * under diffusion-by-maxentirl_amd/models/ bind these symbols through ctypes
+ * (diffusion-by-maxentirl_amd/dxmi_hip/_lib.py); INTEGRATION.md shows the stub a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = DXMI_E* ; dxmi_last_error() gives text.
+ *   - pointers are raw DEVICE pointers (tensor.data_ptr()); the caller owns all memory.
+ *     The library allocates nothing on the device and never synchronises.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every launch is asynchronous on it, so all calls are hipGraph-capturable.
+ *   - activations between kernels: NHWC bf16.  Sampler state / network edges: NCHW fp32.
+ *   - no exceptions cross the boundary; functions are re-entrant.
+ */
+#ifndef DXMI_HIP_H
+#define DXMI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DXMI_OK            0
+#define DXMI_EINVAL       -1   /* bad shape / unsupported configuration */
+#define DXMI_ELAUNCH      -2   /* hipLaunch failed */
+#define DXMI_ENODEV       -3   /* no gfx950 device visible */
+
+#define DXMI_ACT_NONE      0
+#define DXMI_ACT_LEAKY02   1   /* leaky_relu(x, 0.2)  — models/modules.py:84,101,145 */
+#define DXMI_ACT_RELU      2   /* relu               — models/modules.py:150 */
+#define DXMI_ACT_SILU      3   /* x*sigmoid(x)       — models/DxMI/unet_small.py:30 */
+
+#define DXMI_IN_NHWC_BF16     0
+#define DXMI_IN_NCHW_F32_K27  1  /* 3-channel NCHW fp32 image, 3x3/s1/p1 im2col'd to K=27(+5 zero) */
+#define DXMI_IN_ROWS_F32      2  /* internal: fp32 row-major [P,K] (dxmi_linear_fwd) */
+#define DXMI_OUT_NHWC_BF16    0
+#define DXMI_OUT_NCHW_F32     1
+#define DXMI_OUT_ROWS_F32     2  /* internal: fp32 row-major [P,M] (dxmi_linear_fwd) */
+
+const char* dxmi_last_error(void);
+int dxmi_version(void);
+/* 0 when a gfx950 device is usable; DXMI_ENODEV otherwise (never falls back to CPU). */
+int dxmi_device_check(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution as MFMA implicit GEMM (bf16 operands, fp32 accumulate), fused epilogue.
+ * Replaces torch.nn.Conv2d / F.pad+conv / F.interpolate+conv / torch.cat+conv at
+ *   models/DxMI/unet_small.py:50-54 (Upsample), :69-76 (Downsample, pad (0,1,0,1) + k3 s2),
+ *   :117-136 (ResnetBlock conv1/conv2/nin_shortcut + temb add + residual),
+ *   :167-191 (AttnBlock q,k,v,proj_out 1x1), :302, :321-322 (cat(h, skip)), :331 (conv_out);
+ *   models/modules.py:71-101 (ResBlockV2 conv1/conv2/skip), :142-145 (IGEBMEncoderV2.conv1).
+ * Weights are pre-packed into MFMA A-fragment order by dxmi_pack_conv_weight().
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dxmi_conv_desc {
+    const void*  in0;        /* NHWC bf16 [N,IH,IW,C0]  (or NCHW f32 [N,3,IH,IW] for K27 mode) */
+    const void*  in1;        /* second concat source NHWC bf16 [N,IH,IW,C1] or NULL */
+    const void*  wpacked;    /* from dxmi_pack_conv_weight */
+    const float* bias;       /* [Cout] or NULL */
+    const float* addvec;     /* per-(n,co) additive term (temb_proj output) [N,addvec_ld] or NULL */
+    const void*  residual;   /* NHWC bf16 [N,OH,OW,Cout] added before activation, or NULL */
+    void*        out;        /* NHWC bf16 [N,OH,OW,Cout] or NCHW f32 [N,Cout,OH,OW] */
+    int32_t N, IH, IW, C0, C1;
+    int32_t OH, OW, Cout;
+    int32_t ksize;           /* 1 or 3 */
+    int32_t stride;          /* 1 or 2 */
+    int32_t pad;             /* top/left zero padding (bottom/right padding is implied by OH/OW) */
+    int32_t upsample;        /* 1: input is nearest-upsampled x2 before the conv */
+    int32_t act;             /* DXMI_ACT_* applied last */
+    int32_t addvec_ld;
+    int32_t in_mode;         /* DXMI_IN_*  */
+    int32_t out_mode;        /* DXMI_OUT_* */
+    int32_t variant;         /* 0 = default tiling; >0 selects an alternative (tuning / tests) */
+} dxmi_conv_desc;
+
+int dxmi_conv2d_fwd(const dxmi_conv_desc* d, void* stream);
+
+/* Packs an fp32 OIHW weight [Cout,Cin,k,k] (device) into bf16 A-fragment order
+ * [tap][Cin/16][ceil(Cout/32)][64 lanes][8].  transpose_flip=1 packs the data-gradient
+ * (flipped, Cin<->Cout) operator instead.  k27=1 packs the Cin=3,k=3 im2col form.
+ * dst must hold dxmi_packed_conv_weight_bytes(...) bytes. */
+int64_t dxmi_packed_conv_weight_bytes(int32_t Cout, int32_t Cin, int32_t ksize, int32_t k27);
+int dxmi_pack_conv_weight(const float* w_oihw, void* dst, int32_t Cout, int32_t Cin,
+                          int32_t ksize, int32_t transpose_flip, int32_t k27, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU) over NHWC bf16, optionally over a virtual concat of two
+ * tensors.  One pass over HBM: a workgroup keeps its (image, channel-slice) in registers,
+ * two-pass mean/variance in fp32 with wavefront shuffles + LDS.
+ * Replaces Normalize()+nonlinearity at models/DxMI/unet_small.py:35-36,119-120,125-126,
+ * 169,329-330 (eps 1e-6) and GroupNorm32 at models/cm/nn.py:19-21 (eps 1e-5).
+ * ---------------------------------------------------------------------------------------- */
+int dxmi_groupnorm_silu_fwd(const void* in0, int32_t C0, const void* in1, int32_t C1,
+                            const float* gamma, const float* beta, void* out,
+                            int32_t N, int32_t HW, int32_t groups, float eps,
+                            int32_t apply_silu, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Single-/multi-head self-attention over a fused qkv tensor, MFMA QK^T and PV with an
+ * online softmax.  qkv: NHWC bf16 [N,T,3*C] laid out [q | k | v] along channels, heads are
+ * contiguous channel blocks of size C/heads.  out: [N,T,C] bf16.  scale multiplies q.k.
+ * Replaces models/DxMI/unet_small.py:175-187 (bmm/softmax/bmm, scale C^-0.5) and
+ * models/cm/unet.py:413-441 (QKVAttentionLegacy).
+ * ---------------------------------------------------------------------------------------- */
+int dxmi_attention_fwd(const void* qkv, void* out, int32_t N, int32_t T, int32_t C,
+                       int32_t heads, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Timestep-embedding path.
+ * dxmi_timestep_embedding: out[N,dim] fp32 sinusoid of t; freq_i = exp(-ln(max_period)*i/denom)
+ *   order 0 = [sin | cos], denom = dim/2 - 1   (get_timestep_embedding, unet_small.py:9-27)
+ *   order 1 = [cos | sin], denom = dim/2       (timestep_embedding, models/cm/nn.py:119-137)
+ * dxmi_linear_fwd: out[P,M] = post(pre(x[P,K]) @ W[M,K]^T + b): fp32 rows in/out, bf16 MFMA
+ *   operands (same kernel as the convs).  Serves temb.dense.{0,1} (unet_small.py:297-299), the
+ *   concatenation of all temb_proj layers in ONE launch (unet_small.py:123; pre = swish) and
+ *   the EDM time_embed / emb_layers (models/cm/unet.py:775-779, :249).
+ *   wpacked = dxmi_pack_conv_weight(W as [M,K,1,1]).
+ * ---------------------------------------------------------------------------------------- */
+int dxmi_timestep_embedding(const float* t, float* out, int32_t N, int32_t dim, int32_t order,
+                            float max_period, void* stream);
+int dxmi_linear_fwd(const float* x, const void* wpacked, const float* bias, float* out,
+                    int32_t P, int32_t K, int32_t M, int32_t pre_act, int32_t post_act,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused VAR sampler transition (models/DxMI/var_sampler.py:262-295 and :373-407):
+ *   xs = x*xmul[b]; control = cmul[b]*eps; mean = xs+control; x' = mean + sigma[b]*z;
+ *   logp[b] = mean_CHW Normal(mean, sigma).log_prob(x').
+ * Per-sample scalars are read from device vectors, so one kernel serves both the T-step
+ * loop (all entries equal) and sample_step with per-sample integer t.
+ * ---------------------------------------------------------------------------------------- */
+int dxmi_var_step_fwd(const float* x, const float* eps, const float* z,
+                      const float* xmul, const float* cmul, const float* sigma,
+                      float* x_next, float* mean, float* control, float* logp,
+                      int32_t N, int32_t CHW, void* stream);
+
+/* INT path: per-sample gather of schedule tables by integer timestep
+ * (var_sampler.py:363-376,389; models/diffusion.py:18-22).  Writes
+ *   tau[b] = continuous_steps[t[b]], xmul[b], cmul[b] (theta multiplier), sigma[b] =
+ *   exp(log_betas_all[t[b]]).  Bit-exact w.r.t. the fp32 tables. */
+int dxmi_var_gather_sched(const int64_t* t, const float* continuous_steps,
+                          const float* xmul_tab, const float* cmul_tab,
+                          const float* log_betas_all, float* tau, float* xmul, float* cmul,
+                          float* sigma, int32_t N, int32_t T, void* stream);
+
+/* Elementwise helpers of the value network (models/modules.py:96-101): 2x2 average pool
+ * (optional) followed by activation, NHWC bf16. */
+int dxmi_pool_act(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C,
+                  int32_t pool, int32_t act, void* stream);
+/* Value head (models/modules.py:150-158): relu -> sum over HxW -> Linear(C,1) -> a*y+b. */
+int dxmi_value_head(const void* in, const float* w, const float* b, float out_w, float out_b,
+                    float* out, int32_t N, int32_t HW, int32_t C, void* stream);
+
+/* Layout converters at the network edge. */
+int dxmi_nchw_f32_to_nhwc_bf16(const float* in, void* out, int32_t N, int32_t C, int32_t HW,
+                               void* stream);
+int dxmi_nhwc_bf16_to_nchw_f32(const void* in, float* out, int32_t N, int32_t C, int32_t HW,
+                               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DXMI_HIP_H */
