@@ -1,0 +1,167 @@
+"""bench.py — DxMI hot-path throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch: a complete T=10 VARSampler generation
+(10 DDPM U-Net forwards + 10 fused sampler transitions) of 256 CIFAR-10-shaped images per GPU
+(BASELINE.json configs[1]), bf16 MFMA operands / fp32 accumulate / fp32 sampler state, random-init
+weights, synthetic Gaussian noise already resident in HBM.  Generation shards by images with no
+data-path collective (each rank draws its own trajectories: reference generate_cifar10.py:193-204),
+so scaling is "weak" and `value` = all ranks' images / max-over-ranks time.
+
+The JSON line also carries
+  roofline     — the dominant kernel (MFMA implicit-GEMM conv, template <1,8,32,6>): algorithmic
+                 conv FLOPs per launch / average launch duration, measured with HIP events on the
+                 launch stream inside the timed region, against the dense bf16 MFMA peak.
+  cpu_baseline — the oracle (torch-CPU fp32 restatement of the reference) timed on this box's host
+                 cores on a bounded sample (rank 0, N = 1 only).  Baseline only, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "diffusion-by-maxentirl_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, chip-level table
+UNET_KW = dict(ch=128, out_ch=3, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=[16], dropout=0.1,
+               in_channels=3, resolution=32)  # reference configs/cifar10/T10.yaml:1-10
+
+
+def build_sampler(device, T):
+    from models.DxMI.unet_small import Model
+    from models.DxMI.var_sampler import VARSampler
+    torch.manual_seed(0)
+    net = Model(**UNET_KW)
+    sampler = VARSampler(net, T, [3, 32, 32], trainable_beta="fix_last")
+    return sampler.to(device).eval()
+
+
+def cpu_baseline(T, batch, reps):
+    """Oracle (oracle/, torch-CPU fp32) generating `batch` images with T steps, `reps` times."""
+    from oracle import unet_small as ounet
+    from oracle import var_sampler as ovs
+    from oracle import schedule as osched
+    from oracle.weights import formula_tensor
+    from models.DxMI.unet_small import Model
+    shapes = {k: v.shape for k, v in Model(**UNET_KW).state_dict().items()}
+    sd = {k: formula_tensor(k, s) for k, s in shapes.items()}
+    s = osched.var_schedule(T)
+    sched = {k: torch.from_numpy(v) for k, v in s.items() if k != "user_defined_eta"}
+    cfg = ounet.UNetSmallConfig()
+    g = torch.Generator().manual_seed(0)
+    noise = [torch.randn(batch, 3, 32, 32, generator=g) for _ in range(T + 1)]
+    best = float("inf")
+    with torch.no_grad():
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ovs.sample(lambda x, t: ounet.forward(sd, cfg, x, t), sched, sched["log_betas"], noise)
+            best = min(best, time.perf_counter() - t0)
+    return batch / best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--T", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-conv-events", action="store_true", help="skip the per-launch HIP events (roofline leg)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")  # RCCL
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from dxmi_hip import ops
+    ops.device_check()
+    sampler = build_sampler(device, args.T)
+    B, T = args.batch, args.T
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    # synthetic inputs resident in HBM before the timed region: x_T and one z per step
+    noise = [torch.randn(B, 3, 32, 32, device=device, generator=g) for _ in range(T + 1)]
+
+    def step():
+        return sampler.sample(B, device=device, noise=noise)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = None
+    if not args.no_conv_events:
+        prof = ops.ConvProfiler()
+        ops.CONV_PROFILER = prof
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ops.CONV_PROFILER = None
+    assert torch.isfinite(out["sample"]).all()
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    if rank != 0:
+        return
+    images = B * args.steps * world
+    line = {
+        "metric": "images/sec (CIFAR-10 DDPM T=10 generation)", "value": images / elapsed, "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"CIFAR-10 DDPM U-Net (35.7M params) VARSampler T={T} generation, "
+                               f"{B} images/GPU/step, 3x32x32 (BASELINE configs[1])",
+                   "images_per_gpu_per_step": B, "T": T, "parallelism": f"dp{world} (independent trajectories, no collective)"},
+        "train_steps_per_sec": None,
+    }
+    if prof is not None:
+        summ = prof.summary()
+        if summ:
+            kid, s = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            tflops = s["flops"] / (s["ms"] * 1e-3) / 1e12
+            line["roofline"] = {
+                "bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                "kernel": f"conv_igemm_kernel<{kid // 1000},{(kid // 100) % 10},32,{kid % 100}>",
+                "launches": s["launches"], "avg_launch_us": 1e3 * s["ms"] / s["launches"],
+                "algorithmic_gflop_per_launch": s["flops"] / s["launches"] / 1e9,
+                "algorithmic_gbps": s["bytes"] / (s["ms"] * 1e-3) / 1e9,
+                "share_of_step_time": s["ms"] * 1e-3 / elapsed,
+            }
+            line["conv_kernels"] = {str(k): {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                             "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}
+    if world == 1 and not args.no_cpu_baseline:
+        cb = 16
+        v = cpu_baseline(T, cb, reps=2)
+        line["cpu_baseline"] = {"value": v, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                                "sample": f"oracle (torch-CPU fp32 restatement), {cb} images x T={T}, best of 2 "
+                                          f"(BASELINE configs[0] shape); host has {os.cpu_count()} logical cores"}
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -406,27 +406,39 @@ extern "C" int dxmi_pack_conv_weight(const float* w, void* dst, int32_t Cout, in
 
 namespace {
 
-int dispatch_conv(ConvArgs& a, int variant, hipStream_t st) {
+int dispatch_conv(ConvArgs& a, int variant, hipStream_t st, int* kernel_id = nullptr) {
     constexpr int CK = 32;
     const bool flat = a.in_mode != DXMI_IN_NHWC_BF16;
     const int HP = flat ? 256 : a.SUBS * a.HH * a.HWd;
     const size_t lds = (size_t)HP * (CK * 2 + 16);
     DXMI_CHECK_ARG(lds <= 160 * 1024, "dxmi_conv2d_fwd: LDS image %zu too large", lds);
     const int npieces = HP * (CK / 8);
-    const bool small_halo = npieces <= 6 * 256;
+    // staging pieces per thread cached in registers: 6 covers the 32x8 / 16x16 tiles, 9 the
+    // multi-image 8x8 / 4x4 tiles; larger halos (stride 2) recompute their addresses per chunk.
+    const int pmax = npieces <= 6 * 256 ? 6 : (npieces <= 9 * 256 ? 9 : 0);
     // Tiling variants: cout tile BN = 128 when Cout allows it, else 32 (conv_out, heads).
+    if (kernel_id) {
+        // id = MB*1000 + NB*100 + (small_halo ? 6 : 0): names the template instantiation that runs
+        if (a.Cout % 128 == 0 && a.out_mode != DXMI_OUT_NCHW_F32) *kernel_id = (variant == 1 ? 2400 : 1800) + pmax;
+        else *kernel_id = 1200 + pmax;
+        return DXMI_OK;
+    }
     if (a.Cout % 128 == 0 && a.out_mode != DXMI_OUT_NCHW_F32) {
         a.CT = a.Cout / 128;
-        if (variant == 1) return small_halo ? launch_conv<2, 4, CK, 6>(a, lds, st) : launch_conv<2, 4, CK, 0>(a, lds, st);
-        return small_halo ? launch_conv<1, 8, CK, 6>(a, lds, st) : launch_conv<1, 8, CK, 0>(a, lds, st);
+#define DXMI_CONV_PM(MB_, NB_)                                           \
+    (pmax == 6 ? launch_conv<MB_, NB_, CK, 6>(a, lds, st)                \
+               : pmax == 9 ? launch_conv<MB_, NB_, CK, 9>(a, lds, st) : launch_conv<MB_, NB_, CK, 0>(a, lds, st))
+        if (variant == 1) return DXMI_CONV_PM(2, 4);
+        return DXMI_CONV_PM(1, 8);
     }
     a.CT = a.CB;  // one 32-co block per workgroup, 4 waves split the 256 pixels
-    return small_halo ? launch_conv<1, 2, CK, 6>(a, lds, st) : launch_conv<1, 2, CK, 0>(a, lds, st);
+    return DXMI_CONV_PM(1, 2);
+#undef DXMI_CONV_PM
 }
 
 }  // namespace
 
-extern "C" int dxmi_conv2d_fwd(const dxmi_conv_desc* d, void* stream) {
+static int conv2d_impl(const dxmi_conv_desc* d, void* stream, int* kernel_id) {
     DXMI_CHECK_ARG(d && d->in0 && d->wpacked && d->out, "dxmi_conv2d_fwd: null pointer");
     const bool k27 = d->in_mode == DXMI_IN_NCHW_F32_K27;
     DXMI_CHECK_ARG(d->in_mode == DXMI_IN_NHWC_BF16 || k27, "dxmi_conv2d_fwd: in_mode %d unsupported", d->in_mode);
@@ -466,7 +478,18 @@ extern "C" int dxmi_conv2d_fwd(const dxmi_conv_desc* d, void* stream) {
     a.PT = ngroups * (d->OH / TH) * (d->OW / TW);
     a.CB = (d->Cout + 31) / 32;
     a.KST = k27 ? 2 : Cin / 16;
-    return dispatch_conv(a, d->variant, (hipStream_t)stream);
+    return dispatch_conv(a, d->variant, (hipStream_t)stream, kernel_id);
+}
+
+extern "C" int dxmi_conv2d_fwd(const dxmi_conv_desc* d, void* stream) { return conv2d_impl(d, stream, nullptr); }
+
+// Which template instantiation dxmi_conv2d_fwd would launch for this descriptor (no launch):
+// MB*1000 + NB*100 + PMAX, e.g. 1806 = conv_igemm_kernel<1,8,32,6>.  Used by bench.py to attribute
+// HIP-event timings to the kernel named in the rocprof summary.
+extern "C" int dxmi_conv2d_kernel_id(const dxmi_conv_desc* d) {
+    int id = 0;
+    const int rc = conv2d_impl(d, nullptr, &id);
+    return rc == DXMI_OK ? id : rc;
 }
 
 // Dense layer on the same MFMA path: out[P][M] = post(pre(x[P][K]) @ W[M][K]^T + b), fp32 rows

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void var_step_kernel(const float* __restrict__
                                                       const float* __restrict__ z, const float* __restrict__ xmul,
                                                       const float* __restrict__ cmul, const float* __restrict__ sigma,
                                                       float* __restrict__ x_next, float* __restrict__ mean,
-                                                      float* __restrict__ control, float* __restrict__ logp, int CHW) {
+                                                      float* __restrict__ control, float* __restrict__ logp, int CHW, int assoc) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     const float xm = xmul[b], cm = cmul[b], sg = sigma[b];
@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void var_step_kernel(const float* __restrict__
             const float xs = xv[e] * xm;
             ct[e] = cm * ev[e];
             mu[e] = xs + ct[e];
-            xn[e] = mu[e] + sg * zv[e];
+            // assoc 1: x += control + sigma*z (var_sampler.py:285); assoc 0: mean + sigma*z (:399)
+            xn[e] = assoc ? xs + (ct[e] + sg * zv[e]) : mu[e] + sg * zv[e];
             const float d = xn[e] - mu[e];
             acc += -(d * d) / var2 - log_sg - half_log_2pi;
         }
@@ -124,8 +125,8 @@ __global__ void pool_act_kernel(const bf16* __restrict__ in, bf16* __restrict__ 
 
 // value head: relu -> sum over HW -> dot(w[C]) + b -> out_w*y + out_b ; one wave per image
 __global__ __launch_bounds__(64) void value_head_kernel(const bf16* __restrict__ in, const float* __restrict__ w,
-                                                       const float* __restrict__ b, float out_w, float out_b,
-                                                       float* __restrict__ out, int HW, int C) {
+                                                       const float* __restrict__ b, const float* __restrict__ out_w,
+                                                       const float* __restrict__ out_b, float* __restrict__ out, int HW, int C) {
     const int n = blockIdx.x, lane = threadIdx.x;
     float acc = 0.f;
     for (int c = lane; c < C; c += 64) {
@@ -137,7 +138,11 @@ __global__ __launch_bounds__(64) void value_head_kernel(const bf16* __restrict__
         acc += s * w[c];
     }
     acc = wave_sum(acc);
-    if (lane == 0) out[n] = (acc + b[0]) * out_w + out_b;
+    if (lane == 0) {
+        float y = acc + b[0];
+        if (out_w) y = y * out_w[0] + out_b[0];  // out_scale = Linear(1,1), models/modules.py:157-158
+        out[n] = y;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -194,11 +199,11 @@ extern "C" int dxmi_var_gather_sched(const int64_t* t, const float* continuous_s
 
 extern "C" int dxmi_var_step_fwd(const float* x, const float* eps, const float* z, const float* xmul,
                                  const float* cmul, const float* sigma, float* x_next, float* mean, float* control,
-                                 float* logp, int32_t N, int32_t CHW, void* stream) {
+                                 float* logp, int32_t N, int32_t CHW, int32_t assoc, void* stream) {
     DXMI_CHECK_ARG(x && eps && z && xmul && cmul && sigma && x_next, "dxmi_var_step_fwd: null pointer");
     DXMI_CHECK_ARG(N > 0 && CHW > 0 && CHW % 4 == 0, "dxmi_var_step_fwd: CHW (%d) must be a multiple of 4", CHW);
     hipLaunchKernelGGL(var_step_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, eps, z, xmul, cmul, sigma,
-                       x_next, mean, control, logp, CHW);
+                       x_next, mean, control, logp, CHW, assoc);
     DXMI_CHECK_LAUNCH("dxmi_var_step_fwd");
     return DXMI_OK;
 }
@@ -213,9 +218,9 @@ extern "C" int dxmi_pool_act(const void* in, void* out, int32_t N, int32_t H, in
     return DXMI_OK;
 }
 
-extern "C" int dxmi_value_head(const void* in, const float* w, const float* b, float out_w, float out_b, float* out,
-                               int32_t N, int32_t HW, int32_t C, void* stream) {
-    DXMI_CHECK_ARG(in && w && b && out, "dxmi_value_head: null pointer");
+extern "C" int dxmi_value_head(const void* in, const float* w, const float* b, const float* out_w, const float* out_b,
+                               float* out, int32_t N, int32_t HW, int32_t C, void* stream) {
+    DXMI_CHECK_ARG(in && w && b && out && (!out_w == !out_b), "dxmi_value_head: null pointer");
     hipLaunchKernelGGL(value_head_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, (const bf16*)in, w, b, out_w,
                        out_b, out, HW, C);
     DXMI_CHECK_LAUNCH("dxmi_value_head");

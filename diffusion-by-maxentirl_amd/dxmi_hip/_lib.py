@@ -31,6 +31,7 @@ SIGNATURES = {
     "dxmi_version": (c_int, []),
     "dxmi_device_check": (c_int, []),
     "dxmi_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
+    "dxmi_conv2d_kernel_id": (c_int, [ctypes.POINTER(ConvDesc)]),
     "dxmi_packed_conv_weight_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "dxmi_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_groupnorm_silu_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
@@ -38,10 +39,10 @@ SIGNATURES = {
     "dxmi_attention_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dxmi_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "dxmi_linear_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dxmi_var_step_fwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_void_p]),
+    "dxmi_var_step_fwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_void_p]),
     "dxmi_var_gather_sched": (c_int, [c_void_p] * 9 + [c_int, c_int, c_void_p]),
     "dxmi_pool_act": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "dxmi_value_head": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dxmi_value_head": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dxmi_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dxmi_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 }

@@ -109,8 +109,48 @@ def conv2d(x, pw, *, in1=None, bias=None, addvec=None, residual=None, stride=1, 
     d.in_mode = IN_NCHW_F32_K27 if pw.k27 else IN_NHWC_BF16
     d.out_mode = OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC_BF16
     d.variant = variant
-    check(load().dxmi_conv2d_fwd(ctypes.byref(d), _stream()), "dxmi_conv2d_fwd")
+    if CONV_PROFILER is not None:
+        CONV_PROFILER.launch(d)
+    else:
+        check(load().dxmi_conv2d_fwd(ctypes.byref(d), _stream()), "dxmi_conv2d_fwd")
     return out
+
+
+class ConvProfiler:
+    """Brackets every conv launch with HIP events on the launch stream (bench.py roofline leg):
+    records (kernel_id, algorithmic FLOPs, algorithmic bytes, start, end)."""
+
+    def __init__(self):
+        self.records = []
+
+    def launch(self, d):
+        lib = load()
+        kid = lib.dxmi_conv2d_kernel_id(ctypes.byref(d))
+        cin = 27 if d.in_mode == IN_NCHW_F32_K27 else (d.C0 + d.C1) * d.ksize * d.ksize
+        flops = 2.0 * d.N * d.OH * d.OW * d.Cout * cin
+        in_b = d.N * d.IH * d.IW * (d.C0 + d.C1) * (4 if d.in_mode == IN_NCHW_F32_K27 else 2)
+        out_b = d.N * d.OH * d.OW * d.Cout * (4 if d.out_mode == OUT_NCHW_F32 else 2)
+        res_b = out_b if d.residual else 0
+        w_b = d.Cout * cin * 2
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.dxmi_conv2d_fwd(ctypes.byref(d), _stream()), "dxmi_conv2d_fwd")
+        e1.record()
+        self.records.append((kid, flops, float(in_b + out_b + res_b + w_b), e0, e1))
+
+    def summary(self):
+        """kernel_id -> dict(launches, ms, flops, bytes); call after torch.cuda.synchronize()."""
+        out = {}
+        for kid, fl, by, e0, e1 in self.records:
+            s = out.setdefault(kid, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            s["launches"] += 1
+            s["ms"] += e0.elapsed_time(e1)
+            s["flops"] += fl
+            s["bytes"] += by
+        return out
+
+
+CONV_PROFILER = None
 
 
 def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, out=None):
@@ -171,7 +211,7 @@ def var_gather_sched(t, continuous_steps, xmul_tab, cmul_tab, log_betas_all):
     return outs  # tau, xmul, cmul, sigma
 
 
-def var_step(x, eps, z, xmul, cmul, sigma, want_mean=True, want_control=True, outs=None):
+def var_step(x, eps, z, xmul, cmul, sigma, want_mean=True, want_control=True, outs=None, assoc=0):
     """Fused sampler transition; all tensors fp32, x/eps/z [N,C,H,W], per-sample scalars [N]."""
     _need_cuda(x, eps, z, xmul, cmul, sigma)
     N = x.shape[0]
@@ -186,7 +226,7 @@ def var_step(x, eps, z, xmul, cmul, sigma, want_mean=True, want_control=True, ou
     else:
         x_next, mean, control, logp = outs
     check(load().dxmi_var_step_fwd(_ptr(x), _ptr(eps), _ptr(z), _ptr(xmul), _ptr(cmul), _ptr(sigma), _ptr(x_next),
-                                   _ptr(mean), _ptr(control), _ptr(logp), N, CHW, _stream()), "dxmi_var_step_fwd")
+                                   _ptr(mean), _ptr(control), _ptr(logp), N, CHW, assoc, _stream()), "dxmi_var_step_fwd")
     return x_next, mean, control, logp
 
 
@@ -200,12 +240,13 @@ def pool_act(x, pool, act, out=None):
     return out
 
 
-def value_head(x, w, b, out_w=1.0, out_b=0.0, out=None):
-    _need_cuda(x, w, b, out)
+def value_head(x, w, b, out_w=None, out_b=None, out=None):
+    """out_w / out_b: device scalars of the Linear(1,1) out_scale, or None."""
+    _need_cuda(x, w, b, out_w, out_b, out)
     N, H, W, C = x.shape
     if out is None:
         out = torch.empty((N, 1), dtype=torch.float32, device=x.device)
-    check(load().dxmi_value_head(_ptr(x), _ptr(w), _ptr(b), float(out_w), float(out_b), _ptr(out), N, H * W, C,
+    check(load().dxmi_value_head(_ptr(x), _ptr(w), _ptr(b), _ptr(out_w), _ptr(out_b), _ptr(out), N, H * W, C,
                                  _stream()), "dxmi_value_head")
     return out
 

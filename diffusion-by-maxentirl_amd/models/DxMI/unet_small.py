@@ -1,0 +1,283 @@
+"""DDPM U-Net (`models.DxMI.unet_small.Model`) on the gfx950 kernel library.
+
+Drop-in for the reference class of the same dotted name (reference: models/DxMI/unet_small.py:194-332):
+same constructor keywords, same parameter names/shapes (state dicts load both ways, including the
+`log_betas` parameter and `std` buffer that VARSampler hangs on the net), same
+forward(x [B,C,H,W] fp32, t [B] float) -> [B,out_ch,H,W] fp32 contract.
+
+The torch.nn layers below are parameter CONTAINERS only (fp32 master weights, reference
+initialisation order).  forward() never calls them: it runs a fused HIP program —
+  GroupNorm+SiLU (1 kernel) -> 3x3 MFMA conv [+bias +temb +residual] ; fused q|k|v 1x1 conv ->
+  MFMA attention -> 1x1 conv + residual ; all 22 temb_proj layers as ONE linear launch —
+over NHWC bf16 activations, from bf16 weight fragments that are re-packed only when a
+parameter's version counter changes.  No CPU path: non-device tensors raise.
+"""
+import torch
+import torch.nn as nn
+
+from dxmi_hip import ops
+from dxmi_hip._lib import DxmiError
+
+
+def Normalize(in_channels):
+    """GroupNorm(32, eps=1e-6, affine) container (reference :35-36)."""
+    return nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+def _conv(cin, cout, k, stride=1, padding=0):
+    return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=padding)
+
+
+class Upsample(nn.Module):
+    """nearest x2 then 3x3 conv (reference :39-54); the upsample is fused into the conv's staging."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        self.with_conv = with_conv
+        if with_conv:
+            self.conv = _conv(in_channels, in_channels, 3, 1, 1)
+
+
+class Downsample(nn.Module):
+    """zero pad (0,1,0,1) then 3x3 stride-2 conv (reference :57-76)."""
+
+    def __init__(self, in_channels, with_conv):
+        super().__init__()
+        self.with_conv = with_conv
+        if with_conv:
+            self.conv = _conv(in_channels, in_channels, 3, 2, 0)
+
+
+class ResnetBlock(nn.Module):
+    """Parameter container of the reference block (:79-136)."""
+
+    def __init__(self, *, in_channels, out_channels=None, conv_shortcut=False, dropout, temb_channels=512):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        self.in_channels, self.out_channels, self.use_conv_shortcut = in_channels, out_channels, conv_shortcut
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = _conv(in_channels, out_channels, 3, 1, 1)
+        self.temb_proj = nn.Linear(temb_channels, out_channels)
+        self.norm2 = Normalize(out_channels)
+        self.dropout = nn.Dropout(dropout)
+        self.conv2 = _conv(out_channels, out_channels, 3, 1, 1)
+        if in_channels != out_channels:
+            if conv_shortcut:
+                self.conv_shortcut = _conv(in_channels, out_channels, 3, 1, 1)
+            else:
+                self.nin_shortcut = _conv(in_channels, out_channels, 1, 1, 0)
+
+
+class AttnBlock(nn.Module):
+    """Parameter container of the single-head attention block (:139-191)."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.in_channels = in_channels
+        self.norm = Normalize(in_channels)
+        self.q = _conv(in_channels, in_channels, 1)
+        self.k = _conv(in_channels, in_channels, 1)
+        self.v = _conv(in_channels, in_channels, 1)
+        self.proj_out = _conv(in_channels, in_channels, 1)
+
+
+class Model(nn.Module):
+    def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
+                 resamp_with_conv=True, in_channels, resolution):
+        super().__init__()
+        ch_mult = tuple(ch_mult)  # YAML loaders hand over lists
+        self.ch, self.temb_ch = ch, ch * 4
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.resolution, self.in_channels, self.out_ch = resolution, in_channels, out_ch
+        self.ch_mult, self.attn_resolutions = ch_mult, tuple(attn_resolutions)
+        self.dropout_p = dropout
+        if not resamp_with_conv:
+            raise NotImplementedError("resamp_with_conv=False is not used by any DxMI config")
+
+        self.temb = nn.Module()
+        self.temb.dense = nn.ModuleList([nn.Linear(ch, self.temb_ch), nn.Linear(self.temb_ch, self.temb_ch)])
+        self.conv_in = _conv(in_channels, ch, 3, 1, 1)
+
+        curr_res = resolution
+        in_ch_mult = (1,) + ch_mult
+        self.down = nn.ModuleList()
+        block_in = ch
+        for i_level in range(self.num_resolutions):
+            level = nn.Module()
+            level.block, level.attn = nn.ModuleList(), nn.ModuleList()
+            block_in, block_out = ch * in_ch_mult[i_level], ch * ch_mult[i_level]
+            for _ in range(num_res_blocks):
+                level.block.append(ResnetBlock(in_channels=block_in, out_channels=block_out,
+                                               temb_channels=self.temb_ch, dropout=dropout))
+                block_in = block_out
+                if curr_res in self.attn_resolutions:
+                    level.attn.append(AttnBlock(block_in))
+            if i_level != self.num_resolutions - 1:
+                level.downsample = Downsample(block_in, resamp_with_conv)
+                curr_res //= 2
+            self.down.append(level)
+
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=self.temb_ch, dropout=dropout)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(in_channels=block_in, out_channels=block_in, temb_channels=self.temb_ch, dropout=dropout)
+
+        self.up = nn.ModuleList()
+        for i_level in reversed(range(self.num_resolutions)):
+            level = nn.Module()
+            level.block, level.attn = nn.ModuleList(), nn.ModuleList()
+            block_out = skip_in = ch * ch_mult[i_level]
+            for i_block in range(num_res_blocks + 1):
+                if i_block == num_res_blocks:
+                    skip_in = ch * in_ch_mult[i_level]
+                level.block.append(ResnetBlock(in_channels=block_in + skip_in, out_channels=block_out,
+                                               temb_channels=self.temb_ch, dropout=dropout))
+                block_in = block_out
+                if curr_res in self.attn_resolutions:
+                    level.attn.append(AttnBlock(block_in))
+            if i_level != 0:
+                level.upsample = Upsample(block_in, resamp_with_conv)
+                curr_res *= 2
+            self.up.insert(0, level)
+
+        self.norm_out = Normalize(block_in)
+        self.conv_out = _conv(block_in, out_ch, 3, 1, 1)
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ weight fragments
+    def _resblocks(self):
+        for lvl in self.down:
+            yield from lvl.block
+        yield self.mid.block_1
+        yield self.mid.block_2
+        for lvl in reversed(self.up):
+            yield from lvl.block
+
+    def _param_key(self):
+        # torch bumps _version on every in-place update (optimizer.step, load_state_dict, .to())
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _pack(self):
+        """(Re)build the bf16 MFMA weight fragments from the fp32 master parameters."""
+        pk = {}
+        dev = self.conv_in.weight.device
+        pk["dense0"] = ops.pack_conv_weight(self.temb.dense[0].weight)
+        pk["dense1"] = ops.pack_conv_weight(self.temb.dense[1].weight)
+        blocks = list(self._resblocks())
+        # every temb_proj of the net in ONE [sum(Cout), temb_ch] operator (reference :123)
+        pk["tproj"] = ops.pack_conv_weight(torch.cat([b.temb_proj.weight for b in blocks], 0))
+        pk["tproj_bias"] = torch.cat([b.temb_proj.bias for b in blocks], 0).detach().float().contiguous()
+        off = 0
+        for b in blocks:
+            pk[id(b), "toff"] = off
+            off += b.out_channels
+            pk[id(b), "conv1"] = ops.pack_conv_weight(b.conv1.weight)
+            pk[id(b), "conv2"] = ops.pack_conv_weight(b.conv2.weight)
+            if b.in_channels != b.out_channels:
+                sc = b.conv_shortcut if b.use_conv_shortcut else b.nin_shortcut
+                pk[id(b), "short"] = ops.pack_conv_weight(sc.weight)
+        for m in self.modules():
+            if isinstance(m, AttnBlock):
+                pk[id(m), "qkv"] = ops.pack_conv_weight(torch.cat([m.q.weight, m.k.weight, m.v.weight], 0))
+                pk[id(m), "qkv_bias"] = torch.cat([m.q.bias, m.k.bias, m.v.bias], 0).detach().float().contiguous()
+                pk[id(m), "proj"] = ops.pack_conv_weight(m.proj_out.weight)
+            elif isinstance(m, (Upsample, Downsample)):
+                pk[id(m), "conv"] = ops.pack_conv_weight(m.conv.weight)
+        pk["conv_in"] = ops.pack_conv_weight(self.conv_in.weight, k27=(self.in_channels == 3))
+        pk["conv_out"] = ops.pack_conv_weight(self.conv_out.weight)
+        assert dev.type == "cuda"
+        return pk
+
+    def packed(self):
+        key = self._param_key()
+        if self._packed is None or key != self._packed_key:
+            self._packed, self._packed_key = self._pack(), key
+        return self._packed
+
+    # ------------------------------------------------------------------ fused blocks
+    def _resblock(self, pk, b, x0, x1, tp):
+        """GN+SiLU -> conv1(+bias+temb) -> GN+SiLU -> conv2(+bias+shortcut); x = [x0 | x1] virtual concat."""
+        a = ops.groupnorm_silu(x0, b.norm1.weight, b.norm1.bias, in1=x1, eps=1e-6, silu=True)
+        off = pk[id(b), "toff"]
+        h = ops.conv2d(a, pk[id(b), "conv1"], bias=b.conv1.bias, addvec=tp[:, off:off + b.out_channels])
+        a = ops.groupnorm_silu(h, b.norm2.weight, b.norm2.bias, eps=1e-6, silu=True)
+        if b.in_channels != b.out_channels:
+            sc_mod = b.conv_shortcut if b.use_conv_shortcut else b.nin_shortcut
+            sc = ops.conv2d(x0, pk[id(b), "short"], in1=x1, bias=sc_mod.bias)
+        else:
+            assert x1 is None
+            sc = x0
+        return ops.conv2d(a, pk[id(b), "conv2"], bias=b.conv2.bias, residual=sc)
+
+    def _attn(self, pk, m, x):
+        N, H, W, C = x.shape
+        hn = ops.groupnorm_silu(x, m.norm.weight, m.norm.bias, eps=1e-6, silu=False)
+        qkv = ops.conv2d(hn, pk[id(m), "qkv"], bias=pk[id(m), "qkv_bias"])
+        a = ops.attention(qkv.view(N, H * W, 3 * C), heads=1, scale=float(int(C) ** (-0.5)))
+        return ops.conv2d(a.view(N, H, W, C), pk[id(m), "proj"], bias=m.proj_out.bias, residual=x)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, t):
+        assert x.shape[2] == x.shape[3] == self.resolution
+        if not x.is_cuda:
+            raise DxmiError("models.DxMI.unet_small.Model runs only on the HIP device path (no CPU fallback)")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .unet_small_train import forward_with_grad  # autograd wrapper around the HIP kernels
+            return forward_with_grad(self, x, t)
+        return self.forward_inference(x, t)
+
+    @torch.no_grad()
+    def forward_inference(self, x, t, trace=None):
+        """trace: optional list receiving (name, NHWC bf16 tensor) after every block (debugging aid)."""
+        tr = (lambda n, v: trace.append((n, v))) if trace is not None else (lambda n, v: None)
+        pk = self.packed()
+        x = x.contiguous().float()
+        emb = ops.timestep_embedding(t, self.ch, order=0)
+        h1 = ops.linear(emb, pk["dense0"], self.temb.dense[0].bias, post_act=ops.ACT_SILU)
+        s_temb = ops.linear(h1, pk["dense1"], self.temb.dense[1].bias, post_act=ops.ACT_SILU)  # swish(temb)
+        tp = ops.linear(s_temb, pk["tproj"], pk["tproj_bias"])
+        tr("s_temb", s_temb)
+
+        if pk["conv_in"].k27:
+            h = ops.conv2d(x, pk["conv_in"], bias=self.conv_in.bias)
+        else:
+            h = ops.conv2d(ops.nchw_f32_to_nhwc_bf16(x), pk["conv_in"], bias=self.conv_in.bias)
+        hs = [h]
+        tr("conv_in", h)
+        for i_level, lvl in enumerate(self.down):
+            for i_block, blk in enumerate(lvl.block):
+                h = self._resblock(pk, blk, hs[-1], None, tp)
+                tr(f"down.{i_level}.block.{i_block}", h)
+                if len(lvl.attn) > 0:
+                    h = self._attn(pk, lvl.attn[i_block], h)
+                    tr(f"down.{i_level}.attn.{i_block}", h)
+                hs.append(h)
+            if i_level != self.num_resolutions - 1:
+                ds = lvl.downsample
+                hs.append(ops.conv2d(hs[-1], pk[id(ds), "conv"], bias=ds.conv.bias, stride=2, pad=0, pad_br=1))
+                tr(f"down.{i_level}.downsample", hs[-1])
+
+        h = hs[-1]
+        h = self._resblock(pk, self.mid.block_1, h, None, tp)
+        tr("mid.block_1", h)
+        h = self._attn(pk, self.mid.attn_1, h)
+        tr("mid.attn_1", h)
+        h = self._resblock(pk, self.mid.block_2, h, None, tp)
+        tr("mid.block_2", h)
+
+        for i_level in reversed(range(self.num_resolutions)):
+            lvl = self.up[i_level]
+            for i_block, blk in enumerate(lvl.block):
+                h = self._resblock(pk, blk, h, hs.pop(), tp)  # cat(h, skip) is never materialised
+                tr(f"up.{i_level}.block.{i_block}", h)
+                if len(lvl.attn) > 0:
+                    h = self._attn(pk, lvl.attn[i_block], h)
+                    tr(f"up.{i_level}.attn.{i_block}", h)
+            if i_level != 0:
+                us = lvl.upsample
+                h = ops.conv2d(h, pk[id(us), "conv"], bias=us.conv.bias, upsample=True)
+                tr(f"up.{i_level}.upsample", h)
+
+        a = ops.groupnorm_silu(h, self.norm_out.weight, self.norm_out.bias, eps=1e-6, silu=True)
+        return ops.conv2d(a, pk["conv_out"], bias=self.conv_out.bias, out_nchw_f32=True)

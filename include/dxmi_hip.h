@@ -80,6 +80,8 @@ typedef struct dxmi_conv_desc {
 } dxmi_conv_desc;
 
 int dxmi_conv2d_fwd(const dxmi_conv_desc* d, void* stream);
+/* Template instantiation dxmi_conv2d_fwd would launch (MB*1000+NB*100+PMAX), no launch; <0 on error. */
+int dxmi_conv2d_kernel_id(const dxmi_conv_desc* d);
 
 /* Packs an fp32 OIHW weight [Cout,Cin,k,k] (device) into bf16 A-fragment order
  * [tap][Cin/16][ceil(Cout/32)][64 lanes][8].  transpose_flip=1 packs the data-gradient
@@ -132,13 +134,15 @@ int dxmi_linear_fwd(const float* x, const void* wpacked, const float* bias, floa
  * Fused VAR sampler transition (models/DxMI/var_sampler.py:262-295 and :373-407):
  *   xs = x*xmul[b]; control = cmul[b]*eps; mean = xs+control; x' = mean + sigma[b]*z;
  *   logp[b] = mean_CHW Normal(mean, sigma).log_prob(x').
+ * assoc selects the reference's floating-point association of the update: 0 = mean + sigma*z
+ * (sample_step, :399), 1 = xs + (control + sigma*z) (VAR_sampling, :285).
  * Per-sample scalars are read from device vectors, so one kernel serves both the T-step
  * loop (all entries equal) and sample_step with per-sample integer t.
  * ---------------------------------------------------------------------------------------- */
 int dxmi_var_step_fwd(const float* x, const float* eps, const float* z,
                       const float* xmul, const float* cmul, const float* sigma,
                       float* x_next, float* mean, float* control, float* logp,
-                      int32_t N, int32_t CHW, void* stream);
+                      int32_t N, int32_t CHW, int32_t assoc, void* stream);
 
 /* INT path: per-sample gather of schedule tables by integer timestep
  * (var_sampler.py:363-376,389; models/diffusion.py:18-22).  Writes
@@ -153,9 +157,10 @@ int dxmi_var_gather_sched(const int64_t* t, const float* continuous_steps,
  * (optional) followed by activation, NHWC bf16. */
 int dxmi_pool_act(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C,
                   int32_t pool, int32_t act, void* stream);
-/* Value head (models/modules.py:150-158): relu -> sum over HxW -> Linear(C,1) -> a*y+b. */
-int dxmi_value_head(const void* in, const float* w, const float* b, float out_w, float out_b,
-                    float* out, int32_t N, int32_t HW, int32_t C, void* stream);
+/* Value head (models/modules.py:150-158): relu -> sum over HxW -> Linear(C,1) -> out_scale
+ * (Linear(1,1): y*out_w[0]+out_b[0], both device scalars, or both NULL). */
+int dxmi_value_head(const void* in, const float* w, const float* b, const float* out_w,
+                    const float* out_b, float* out, int32_t N, int32_t HW, int32_t C, void* stream);
 
 /* Layout converters at the network edge. */
 int dxmi_nchw_f32_to_nhwc_bf16(const float* in, void* out, int32_t N, int32_t C, int32_t HW,

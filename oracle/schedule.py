@@ -16,28 +16,17 @@ spells that promotion out explicitly, which reproduces the eta table printed in
 models/DxMI/trainer.py:148-149.
 """
 import numpy as np
+import torch
 
 BETA_0, BETA_T, T_DDPM = 0.0001, 0.02, 1000
 f32 = np.float32
 
 
-def torch_linspace_f32(start, end, steps):
-    """torch.linspace(float32) semantics: symmetric evaluation from both ends with a float32 step."""
-    start, end = f32(start), f32(end)
-    step = f32((end - start) / f32(steps - 1))
-    out = np.empty(steps, dtype=np.float32)
-    half = steps // 2
-    for i in range(steps):
-        if i < half:
-            out[i] = f32(start + f32(step * f32(i)))
-        else:
-            out[i] = f32(end - f32(step * f32(steps - 1 - i)))
-    return out
-
-
 def ddpm_tables():
     """var_sampler.py:19-45 -> Beta, Alpha, Alpha_bar (float32, sequential products)."""
-    beta = torch_linspace_f32(BETA_0, BETA_T, T_DDPM)
+    # the one float32 op taken from torch itself: torch.linspace's two-ended evaluation is not
+    # reproducible to the last ulp from numpy
+    beta = torch.linspace(BETA_0, BETA_T, T_DDPM).numpy().copy()
     alpha = (f32(1) - beta).astype(np.float32)
     alpha_bar = alpha.copy()
     for t in range(1, T_DDPM):

@@ -85,8 +85,10 @@ def attn_block(sd, pre, x, prec):
     return prec.act(x + h_)
 
 
-def forward(sd, cfg, x, t, prec=None):
-    """Model.forward, unet_small.py:292-332.  x [B,C,H,W] fp32, t [B] float."""
+def forward(sd, cfg, x, t, prec=None, trace=None):
+    """Model.forward, unet_small.py:292-332.  x [B,C,H,W] fp32, t [B] float.
+    trace: optional list that receives (name, NCHW tensor) after every block (debugging aid)."""
+    tr = (lambda n, v: trace.append((n, v.clone()))) if trace is not None else (lambda n, v: None)
     prec = prec or Precision("fp32")
     assert x.shape[2] == x.shape[3] == cfg.resolution
     nres = len(cfg.ch_mult)
@@ -97,28 +99,36 @@ def forward(sd, cfg, x, t, prec=None):
     temb = swish(temb)
     temb = F.linear(prec.act(temb), prec.w(sd["temb.dense.1.weight"]), sd["temb.dense.1.bias"])
     s_temb = swish(temb)
+    tr("s_temb", s_temb)
 
     hs = [prec.act(_conv(sd, "conv_in", prec.act(x), prec, padding=1))]
+    tr("conv_in", hs[0])
     curr_res = cfg.resolution
     for i_level in range(nres):
         block_in = cfg.ch * in_ch_mult[i_level]
         block_out = cfg.ch * cfg.ch_mult[i_level]
         for i_block in range(cfg.num_res_blocks):
             h = resnet_block(sd, f"down.{i_level}.block.{i_block}", hs[-1], s_temb, block_in, block_out, prec)
+            tr(f"down.{i_level}.block.{i_block}", h)
             block_in = block_out
             if curr_res in cfg.attn_resolutions:
                 h = attn_block(sd, f"down.{i_level}.attn.{i_block}", h, prec)
+                tr(f"down.{i_level}.attn.{i_block}", h)
             hs.append(h)
         if i_level != nres - 1:
             # asymmetric zero pad (0,1,0,1) then 3x3 stride 2, unet_small.py:69-76
             hp = F.pad(hs[-1], (0, 1, 0, 1), mode="constant", value=0)
             hs.append(prec.act(_conv(sd, f"down.{i_level}.downsample.conv", hp, prec, stride=2)))
+            tr(f"down.{i_level}.downsample", hs[-1])
             curr_res //= 2
 
     h = hs[-1]
     h = resnet_block(sd, "mid.block_1", h, s_temb, block_in, block_in, prec)
+    tr("mid.block_1", h)
     h = attn_block(sd, "mid.attn_1", h, prec)
+    tr("mid.attn_1", h)
     h = resnet_block(sd, "mid.block_2", h, s_temb, block_in, block_in, prec)
+    tr("mid.block_2", h)
 
     for i_level in reversed(range(nres)):
         block_out = cfg.ch * cfg.ch_mult[i_level]
@@ -128,12 +138,15 @@ def forward(sd, cfg, x, t, prec=None):
                 skip_in = cfg.ch * in_ch_mult[i_level]
             h = resnet_block(sd, f"up.{i_level}.block.{i_block}", torch.cat([h, hs.pop()], dim=1), s_temb,
                              block_in + skip_in, block_out, prec)
+            tr(f"up.{i_level}.block.{i_block}", h)
             block_in = block_out
             if curr_res in cfg.attn_resolutions:
                 h = attn_block(sd, f"up.{i_level}.attn.{i_block}", h, prec)
+                tr(f"up.{i_level}.attn.{i_block}", h)
         if i_level != 0:
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
             h = prec.act(_conv(sd, f"up.{i_level}.upsample.conv", h, prec, padding=1))
+            tr(f"up.{i_level}.upsample", h)
             curr_res *= 2
 
     h = prec.act(swish(_gn(sd, "norm_out", h)))

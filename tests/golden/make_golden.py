@@ -1,0 +1,166 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs ONLY in the build container (needs /root/reference, read-only; nothing is written there and
+no reference source is copied: the outputs are data — inputs, seeds and expected outputs).
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--only NAME]
+
+Reference quirks handled here, and nowhere else:
+  * numpy>=2 breaks var_sampler._log_cont_noise (README.md:29): we install the NumPy-1
+    promotion emulation (float32 (bT-b0), everything after in float64) before building samplers.
+  * models/cm/karras_diffusion.py:11 imports torchvision.transforms.RandomCrop (never used):
+    a 3-line sys.modules stub lets the EDM modules import.
+Weights are formula-generated (oracle/weights.py) so fixtures hold no weight tensors.
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+
+tv = types.ModuleType("torchvision")
+tvt = types.ModuleType("torchvision.transforms")
+tvt.RandomCrop = object
+tv.transforms = tvt
+sys.modules.setdefault("torchvision", tv)
+sys.modules.setdefault("torchvision.transforms", tvt)
+
+import models.DxMI.var_sampler as ref_vs  # noqa: E402
+import models.DxMI.unet_small as ref_unet  # noqa: E402
+import models.modules as ref_modules  # noqa: E402
+import models.value as ref_value  # noqa: E402
+
+from oracle.weights import formula_state_dict  # noqa: E402
+
+
+def _log_cont_noise_numpy1(t, beta_0, beta_T, T):
+    b0, bT = np.float32(beta_0), np.float32(beta_T)
+    delta_beta = np.float64(np.float32(bT - b0)) / (T - 1)
+    _c = (1.0 - np.float64(b0)) / delta_beta
+    t_1 = np.float64(t) + 1
+    return t_1 * np.log(delta_beta) + ref_vs._log_gamma(_c + 1) - ref_vs._log_gamma(_c - t_1 + 1)
+
+
+ref_vs._log_cont_noise = _log_cont_noise_numpy1
+
+UNET_KW = dict(ch=128, out_ch=3, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=[16], dropout=0.1,
+               in_channels=3, resolution=32)  # configs/cifar10/T10.yaml:1-10
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def build_sampler(T, trainable_beta="fix_last"):
+    torch.manual_seed(0)
+    net = ref_unet.Model(**UNET_KW)
+    sampler = ref_vs.VARSampler(net, T, [3, 32, 32], trainable_beta=trainable_beta)
+    net.load_state_dict(formula_state_dict(net.state_dict()))
+    sampler.eval()
+    return net, sampler
+
+
+def gen_schedule():
+    out = {}
+    for T in (10, 4):
+        net, s = build_sampler(T)
+        xm, cm, std, dsl = ref_vs.VAR_get_params(s.diffusion_hyperparams, s.user_defined_eta, s.kappa, s.continuous_steps)
+        out.update({f"T{T}_user_defined_eta": s.user_defined_eta, f"T{T}_continuous_steps": s.continuous_steps,
+                    f"T{T}_Gamma_bar": s.Gamma_bar, f"T{T}_x_prev_multiplier": xm, f"T{T}_theta_multiplier": cm,
+                    f"T{T}_std": std, f"T{T}_log_betas": net.log_betas.detach(),
+                    f"T{T}_state_dict_keys": np.array(sorted(net.state_dict().keys()))})
+    dh = ref_vs.calc_diffusion_hyperparams(**ref_vs.diffusion_config)
+    out.update({"ddpm_Beta": dh["Beta"], "ddpm_Alpha_bar": dh["Alpha_bar"]})
+    save("schedule", **out)
+
+
+def gen_unet_forward():
+    net, _ = build_sampler(10)
+    g = torch.Generator().manual_seed(2024)
+    x = torch.randn(2, 3, 32, 32, generator=g)
+    t = torch.tensor([616.734131, 1.50696171e-4])
+    with torch.no_grad():
+        y = net(x, t)
+        temb = ref_unet.get_timestep_embedding(t, 128)
+    save("unet_small_forward", x=x, t=t, y=y, temb_sinusoid=temb,
+         n_params=sum(p.numel() for n, p in net.named_parameters() if "log_betas" not in n))
+
+
+def gen_var_sampling():
+    for T in (10, 4):
+        net, s = build_sampler(T)
+        seed, B = 1000 + T, 2
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            d = s.sample(B, device="cpu")
+        save(f"var_sampling_T{T}", seed=seed, B=B, sample=d["sample"], l_sample=torch.stack(d["l_sample"]),
+             logp=torch.stack(d["logp"]), mean=torch.stack(d["mean"]), sigma=torch.stack(d["sigma"]),
+             control=torch.stack(d["control"]), logp_terminal=d["logp_terminal"])
+
+
+def gen_sample_step():
+    net, s = build_sampler(10)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(6, 3, 32, 32, generator=g)
+    t = torch.tensor([0, 9, 3, 3, 7, 1])
+    seed = 4242
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        d = s.sample_step(x, t)
+    save("sample_step_T10", seed=seed, x=x, t=t, **{k: v for k, v in d.items()})
+    # trainable_beta False variant: exercises the is_last_t masking of sigma (var_sampler.py:396)
+    net2, s2 = build_sampler(10, trainable_beta=False)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        d2 = s2.sample_step(x, t)
+    save("sample_step_T10_fixedbeta", seed=seed, x=x, t=t, **{k: v for k, v in d2.items()})
+
+
+def build_value():
+    torch.manual_seed(0)
+    enc = ref_modules.IGEBMEncoderV2(in_chan=3, out_chan=1, use_spectral_norm=False, keepdim=False,
+                                     out_activation="linear", avg_pool_dim=1, learn_out_scale=True, nh=128)
+    v = ref_value.TimeIndependentValue(enc)
+    v.load_state_dict(formula_state_dict(v.state_dict()))
+    return v
+
+
+def gen_value():
+    v = build_value()
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(4, 3, 32, 32, generator=g).requires_grad_(True)
+    out = v(x, torch.zeros(4, dtype=torch.long))
+    out.sum().backward()
+    grads = {n: p.grad for n, p in v.named_parameters()}
+    save("value_forward", x=x.detach(), out=out.detach(), grad_x=x.grad,
+         grad_conv1_w=grads["net.conv1.weight"], grad_b5_conv2_w=grads["net.blocks.5.conv2.weight"][:4],
+         grad_b2_skip_w=grads["net.blocks.2.skip.0.weight"], grad_linear_w=grads["net.linear.weight"],
+         grad_out_scale_w=grads["net.out_scale.weight"], grad_out_scale_b=grads["net.out_scale.bias"],
+         n_params=sum(p.numel() for p in v.parameters()), keys=np.array(sorted(v.state_dict().keys())))
+    x64 = torch.randn(2, 3, 64, 64, generator=g)
+    with torch.no_grad():
+        save("value_forward_64", x=x64, out=v(x64, None))
+
+
+GENS = {"schedule": gen_schedule, "unet": gen_unet_forward, "var_sampling": gen_var_sampling,
+        "sample_step": gen_sample_step, "value": gen_value}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    for k, fn in GENS.items():
+        if a.only is None or a.only == k:
+            fn()

@@ -257,7 +257,7 @@ def test_value_tail_ops(ops):
     assert rel_l2(nchw(ops.pool_act(nhwc(x), False, ops.ACT_LEAKY02)), ref2) < 4e-3
     w, b = torch.randn(C, generator=g), torch.randn(1, generator=g)
     head = (F.relu(x).flatten(2).sum(2) @ w + b) * 1.5 - 0.25
-    got = ops.value_head(nhwc(x), w.to(DEV), b.to(DEV), 1.5, -0.25).cpu().flatten()
+    got = ops.value_head(nhwc(x), w.to(DEV), b.to(DEV), torch.tensor([1.5], device=DEV), torch.tensor([-0.25], device=DEV)).cpu().flatten()
     assert torch.allclose(got, head, rtol=1e-4, atol=1e-3)
 
 
