@@ -42,6 +42,12 @@ __device__ __forceinline__ float dxmi_act(float v, int act) {
     }
 }
 
+// Workgroup barrier for LDS hand-offs that does NOT drain the vector-memory queue: __syncthreads()
+// makes hipcc emit s_waitcnt vmcnt(0) first, which stalls on every prefetched global load and on every
+// outstanding global store (CDNA4's vmcnt counts stores too).  LDS traffic of this wave is complete
+// (lgkmcnt(0)) before the barrier; global memory ordering is NOT implied.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

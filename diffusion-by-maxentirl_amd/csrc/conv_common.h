@@ -1,0 +1,126 @@
+// Shared pieces of the implicit-GEMM convolution kernels (conv_igemm.hip, conv_pipe.hip).
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+    const bf16* in0;
+    const bf16* in1;
+    const bf16* w;
+    const float* bias;
+    const float* addvec;
+    const bf16* residual;
+    void* out;
+    int N, IH, IW, C0, C1, OH, OW, Cout;
+    int ksize, stride, pad, ups, act, addvec_ld, in_mode, out_mode;
+    int P, pre_act;          // ROWS mode: number of rows; activation applied to the input while staging
+    int TWl, THl, SUBS;      // tile geometry (log2 width, log2 height, images per tile)
+    int HH, HWd;             // halo height / width
+    int PT, CT, CB, KST;     // pixel tiles, cout tiles, 32-co blocks (padded), total 16-ci k-steps
+    int tile_px;             // output pixels per workgroup tile (256, 128 or 64)
+    int lds_buf;             // bytes of one LDS halo image (16-byte multiple)
+    int stagger;             // conv_pipe: start delay (units of s_sleep 127 ~ 8k cycles) of the second resident half
+    int RP, SP;              // conv_pipe: LDS pitch of a halo row / of a sub-image, bytes (bank-conflict-free choice)
+};
+
+// XCD-aware block mapping: blocks b and b+8 share an XCD (round-robin dispatch), so the CT
+// cout-tiles of one pixel tile are made consecutive *within* an XCD and re-read the input halo
+// from that XCD's L2.  Returns false for padding blocks.
+__device__ __forceinline__ bool conv_block_to_tile(const ConvArgs& p, int bid, int& pt, int& cot) {
+    const int xcd = bid & 7;
+    const int j = bid >> 3;
+    pt = (j / p.CT) * 8 + xcd;
+    cot = j % p.CT;
+    return pt < p.PT;
+}
+
+// Epilogue over D[co][pixel] accumulators (lane: pixel = lane&31, co = 8g + 4h + {0..3}):
+// bias, per-(n,co) temb term, residual, activation, then bf16 NHWC / fp32 rows (vector path) or the
+// scalar path for narrow heads and NCHW-fp32 output (compiled only when !WIDE).
+template <int MB, int NB, bool WIDE>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[MB][NB], int pt, int n0, int oy0,
+                                              int ox0, int pxblk0, int cb0, int lane) {
+    const bool rows = p.in_mode == DXMI_IN_ROWS_F32;
+    const int TW = 1 << p.TWl, TH = 1 << p.THl;
+    const int h = lane >> 5;
+    const bool vec_ok = WIDE || ((p.out_mode != DXMI_OUT_NCHW_F32) && ((p.Cout & 3) == 0));
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int pix = (pxblk0 + nb) * 32 + (lane & 31);
+        size_t opix;
+        int n = 0, oy = 0, ox = 0;
+        bool pvalid;
+        if (rows) {
+            const long grow = (long)pt * p.tile_px + pix;
+            pvalid = grow < p.P;
+            opix = (size_t)grow;
+        } else {
+            const int x = pix & (TW - 1);
+            const int y = (pix >> p.TWl) & (TH - 1);
+            const int sub = pix >> (p.TWl + p.THl);
+            n = n0 + sub; oy = oy0 + y; ox = ox0 + x;
+            pvalid = n < p.N;
+            opix = ((size_t)n * p.OH + oy) * p.OW + ox;
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = (cb0 + mb) * 32 + 8 * g + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[mb][nb][4 * g + e];
+                if (pvalid && co < p.Cout) {
+                    if (vec_ok) {
+                        if (p.bias) {
+                            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                        }
+                        if (p.addvec) {
+                            const f32x4 av = *reinterpret_cast<const f32x4*>(p.addvec + (size_t)n * p.addvec_ld + co);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += av[e];
+                        }
+                        if (p.residual) {
+                            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.residual + opix * p.Cout + co);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = dxmi_act(v[e], p.act);
+                        if (p.out_mode == DXMI_OUT_ROWS_F32) {
+                            f32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = v[e];
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + opix * p.Cout + co) = o;
+                        } else {
+                            bf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+                            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.out) + opix * p.Cout + co) = o;
+                        }
+                    } else if constexpr (!WIDE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (co + e < p.Cout) {
+                                float r = v[e] + (p.bias ? p.bias[co + e] : 0.f);
+                                if (p.addvec) r += p.addvec[(size_t)n * p.addvec_ld + co + e];
+                                r = dxmi_act(r, p.act);
+                                if (p.out_mode == DXMI_OUT_NCHW_F32)
+                                    reinterpret_cast<float*>(p.out)[(((size_t)n * p.Cout + co + e) * p.OH + oy) * p.OW + ox] = r;
+                                else if (p.out_mode == DXMI_OUT_ROWS_F32)
+                                    reinterpret_cast<float*>(p.out)[opix * p.Cout + co + e] = r;
+                                else
+                                    reinterpret_cast<bf16*>(p.out)[opix * p.Cout + co + e] = (bf16)r;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// conv_pipe.hip: software-pipelined kernel for stride-1 / upsampled convs with Cout % 128 == 0.
+// Returns DXMI_OK after launching, or 1 when the shape is not eligible (caller falls back).
+int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);

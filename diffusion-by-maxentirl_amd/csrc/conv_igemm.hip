@@ -16,25 +16,9 @@
 // add, activation, bf16 pack (NHWC) or fp32 NCHW store.
 //
 // Reference call sites: see include/dxmi_hip.h (dxmi_conv2d_fwd).
-#include "common.h"
+#include "conv_common.h"
 
 namespace {
-
-struct ConvArgs {
-    const bf16* in0;
-    const bf16* in1;
-    const bf16* w;
-    const float* bias;
-    const float* addvec;
-    const bf16* residual;
-    void* out;
-    int N, IH, IW, C0, C1, OH, OW, Cout;
-    int ksize, stride, pad, ups, act, addvec_ld, in_mode, out_mode;
-    int P, pre_act;          // ROWS mode: number of rows; activation applied to the input while staging
-    int TWl, THl, SUBS;      // tile geometry (log2 width, log2 height, images per tile)
-    int HH, HWd;             // halo height / width
-    int PT, CT, CB, KST;     // pixel tiles, cout tiles, 32-co blocks (padded), total 16-ci k-steps
-};
 
 template <int MB, int NB, int CK, int PMAX>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
@@ -52,15 +36,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
     const int wco = wave % WAVES_CO;
     const int wpx = wave / WAVES_CO;
 
-    // XCD-aware block mapping: blocks b and b+8 share an XCD (round-robin dispatch), so the
-    // CT cout-tiles of one pixel tile are made consecutive *within* an XCD and re-read the
-    // input halo from that XCD's L2.
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7;
-    const int j = bid >> 3;
-    const int pt = (j / p.CT) * 8 + xcd;
-    const int cot = j % p.CT;
-    if (pt >= p.PT) return;
+    int pt, cot;
+    if (!conv_block_to_tile(p, blockIdx.x, pt, cot)) return;
 
     const bool k27 = p.in_mode == DXMI_IN_NCHW_F32_K27;
     const bool rows = p.in_mode == DXMI_IN_ROWS_F32;
@@ -238,88 +215,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         }
     }
 
-    // ---- epilogue: D[co][pixel]; lane holds pixel = lane&31, co = 8g + 4h + {0..3}
-    const int h = lane >> 5;
-    // wide (BN = 128) instantiations only carry the vector path (the host never routes NCHW-fp32 or
-    // Cout%4 != 0 outputs to them); the scalar path lives in the narrow BN = 32 kernels.
-    const bool vec_ok = (BN == 128) || ((p.out_mode != DXMI_OUT_NCHW_F32) && ((p.Cout & 3) == 0));
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int pix = (wpx * NB + nb) * 32 + (lane & 31);
-        size_t opix;
-        int n = 0, oy = 0, ox = 0;
-        bool pvalid;
-        if (rows) {
-            const long grow = (long)pt * 256 + pix;
-            pvalid = grow < p.P;
-            opix = (size_t)grow;
-        } else {
-            const int x = pix & (TW - 1);
-            const int y = (pix >> p.TWl) & (TH - 1);
-            const int sub = pix >> (p.TWl + p.THl);
-            n = n0 + sub; oy = oy0 + y; ox = ox0 + x;
-            pvalid = n < p.N;
-            opix = ((size_t)n * p.OH + oy) * p.OW + ox;
-        }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = (cb0 + mb) * 32 + 8 * g + 4 * h;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[mb][nb][4 * g + e];
-                if (pvalid && co < p.Cout) {
-                    if (vec_ok) {
-                        if (p.bias) {
-                            const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + co);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += bv[e];
-                        }
-                        if (p.addvec) {
-                            const f32x4 av = *reinterpret_cast<const f32x4*>(p.addvec + (size_t)n * p.addvec_ld + co);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += av[e];
-                        }
-                        if (p.residual) {
-                            const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.residual + opix * p.Cout + co);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = dxmi_act(v[e], p.act);
-                        if (p.out_mode == DXMI_OUT_ROWS_F32) {
-                            f32x4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = v[e];
-                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + opix * p.Cout + co) = o;
-                        } else {
-                            bf16x4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-                            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(p.out) + opix * p.Cout + co) = o;
-                        }
-                    } else if constexpr (BN != 128) {
-                        // narrow heads (conv_out Cout=3) / NCHW fp32 output: scalar stores
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (co + e < p.Cout) {
-                                float r = v[e] + (p.bias ? p.bias[co + e] : 0.f);
-                                if (p.addvec) r += p.addvec[(size_t)n * p.addvec_ld + co + e];
-                                r = dxmi_act(r, p.act);
-                                if (p.out_mode == DXMI_OUT_NCHW_F32)
-                                    reinterpret_cast<float*>(p.out)[(((size_t)n * p.Cout + co + e) * p.OH + oy) * p.OW + ox] = r;
-                                else if (p.out_mode == DXMI_OUT_ROWS_F32)
-                                    reinterpret_cast<float*>(p.out)[opix * p.Cout + co + e] = r;
-                                else
-                                    reinterpret_cast<bf16*>(p.out)[opix * p.Cout + co + e] = (bf16)r;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
+    conv_epilogue<MB, NB, BN == 128>(p, acc, pt, n0, oy0, ox0, wpx * NB, cb0, lane);
 }
 
 // ---- weight packing: OIHW fp32 -> [tap][kstep][cb][lane][8] bf16
@@ -407,10 +303,17 @@ extern "C" int dxmi_pack_conv_weight(const float* w, void* dst, int32_t Cout, in
 namespace {
 
 int dispatch_conv(ConvArgs& a, int variant, hipStream_t st, int* kernel_id = nullptr) {
+    if (variant == 0) {
+        const int rc = conv_pipe_try_launch(a, st, kernel_id);
+        if (rc <= 0) return rc;  // launched (or failed loudly); rc == 1: not eligible
+    }
     constexpr int CK = 32;
+    a.tile_px = 256;
+    a.stagger = 0;
     const bool flat = a.in_mode != DXMI_IN_NHWC_BF16;
     const int HP = flat ? 256 : a.SUBS * a.HH * a.HWd;
     const size_t lds = (size_t)HP * (CK * 2 + 16);
+    a.lds_buf = (int)lds;
     DXMI_CHECK_ARG(lds <= 160 * 1024, "dxmi_conv2d_fwd: LDS image %zu too large", lds);
     const int npieces = HP * (CK / 8);
     // staging pieces per thread cached in registers: 6 covers the 32x8 / 16x16 tiles, 9 the

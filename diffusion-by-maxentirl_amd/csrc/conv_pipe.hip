@@ -1,0 +1,390 @@
+// Persistent, software-pipelined implicit-GEMM convolution for gfx950 (the U-Net's dominant kernel).
+//
+// Same GEMM mapping as conv_igemm.hip (A = weight fragments straight from global/L2 into VGPRs,
+// B = input halo image in LDS, D[co][pixel] accumulators), restructured so that the MFMA pipe is
+// not left waiting on memory:
+//   * a workgroup (4 waves = 128 output channels x 32*NB pixels) is PERSISTENT: it walks a strided
+//     list of pixel tiles for one cout tile, so the launch ramp, the first-chunk load latency and
+//     the drain are paid once per workgroup instead of once per tile (measured: 42 % of a
+//     128->128 @32x32 launch was per-tile prologue/epilogue);
+//   * the K loop is a stream of (chunk, tap) steps that runs ACROSS tiles: every step requests its
+//     successor's operands — the next tap's A fragments (global, wave-private, pre-packed in MFMA
+//     order) and B fragments (ds_read_b128 from the LDS halo image) — while its own 2*NB MFMAs
+//     run; two register sets ping-pong by unrolling (no copies), a sched_barrier per step keeps
+//     hipcc from sinking the requests next to their uses;
+//   * the next channel chunk's halo (of this tile, or chunk 0 of the NEXT tile) is loaded
+//     global->registers at the first tap of a chunk and written to the other LDS image at the
+//     last tap: HBM/L2 latency hides behind 8 taps of MFMAs, ONE barrier per 9*2*NB MFMAs;
+//   * LDS row / sub-image pitches are chosen per tile shape so the ds_read_b128 lane groups are
+//     bank-conflict free.
+// NB in {8,4,2} (pixels per tile = 32*NB) is chosen on the host; 2 workgroups per CU for NB <= 4.
+#include "conv_common.h"
+#include <stdlib.h>
+
+namespace {
+
+// Epilogue through LDS: the accumulators hold D[co][pixel] with only 4 consecutive couts per lane, so
+// a direct store scatters 8-byte pieces over 32 pixel rows per instruction (measured: 45 % of a
+// 128->128 @32x32 launch).  Instead each wave drops its fp32 tile (+bias +temb term) into a
+// [64 px][128 co] fp32 LDS slab (pitch 528 B: conflict-free for the b128 writes and reads), and after a
+// barrier every thread owns 16-byte output pieces: a wave then writes four full 256-byte NHWC pixel
+// rows per store instruction and reads the residual the same way.  Rounding is unchanged
+// (fp32 sum of conv + bias + temb + residual, activation, ONE rounding to bf16).
+constexpr int EPI_PITCH = 528;
+constexpr int EPI_BYTES = 64 * EPI_PITCH;
+
+template <int NB>
+__device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&acc)[1][NB], char* eb, int n0, int oy0,
+                                                  int ox0, int cot, int wave, int lane, int tid) {
+    constexpr int EPB = 2;  // 32-pixel blocks per pass (64 pixels)
+    const int TW = 1 << p.TWl, TH = 1 << p.THl;
+    const int h = lane >> 5;
+    const int co_l = wave * 32 + 4 * h;  // + 8g
+#pragma unroll
+    for (int pass = 0; pass < NB / EPB; ++pass) {
+#pragma unroll
+        for (int e2 = 0; e2 < EPB; ++e2) {
+            const int nb = pass * EPB + e2;
+            const int pix = nb * 32 + (lane & 31);
+            const int n = n0 + (pix >> (p.TWl + p.THl));
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[0][nb][4 * g + e];
+                if (p.bias) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cot * 128 + co_l + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bv[e];
+                }
+                if (p.addvec && n < p.N) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(p.addvec + (size_t)n * p.addvec_ld + cot * 128 + co_l + 8 * g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += t[e];
+                }
+                *reinterpret_cast<f32x4*>(eb + (e2 * 32 + (lane & 31)) * EPI_PITCH + (co_l + 8 * g) * 4) = v;
+            }
+        }
+        lds_barrier();
+        const int pc = tid & 15;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lp = (tid >> 4) + 16 * k;
+            const int pix = pass * 64 + lp;
+            const int x = pix & (TW - 1);
+            const int y = (pix >> p.TWl) & (TH - 1);
+            const int n = n0 + (pix >> (p.TWl + p.THl));
+            if (n < p.N) {
+                const size_t o = (((size_t)n * p.OH + oy0 + y) * p.OW + ox0 + x) * p.Cout + cot * 128 + pc * 8;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(eb + lp * EPI_PITCH + pc * 32);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(eb + lp * EPI_PITCH + pc * 32 + 16);
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+                if (p.residual) {
+                    const bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.residual + o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                }
+                bf16x8 ov;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (bf16)dxmi_act(v[e], p.act);
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + o) = ov;
+            }
+        }
+        lds_barrier();
+    }
+}
+
+template <int NB, int PMAX, int KS, int DBG = 0>  // DBG: timing-only ablations (wrong results)
+__global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvArgs p) {
+    constexpr int CK = 32, ROWB = CK * 2 + 16, PPP = CK / 8, TAPS = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // persistent schedule: this workgroup owns cout tile `cot` and pixel tiles pt0, pt0+nstreams, ...
+    const int cot = blockIdx.x % p.CT;
+    const int nstreams = gridDim.x / p.CT;
+    int pt = blockIdx.x / p.CT;
+    if (pt >= p.PT) return;
+
+    // the two workgroups that share a CU start in lockstep and would stay in lockstep (same tiles, same
+    // cost): both in their MFMA loops, then both in their memory-bound tile switch.  Delaying the second
+    // resident half once lets one's epilogue overlap the other's MFMAs for the rest of the launch.
+    if (p.stagger && blockIdx.x >= gridDim.x / 2)
+        for (int k = 0; k < p.stagger; ++k) __builtin_amdgcn_s_sleep(127);
+
+    const int TW = 1 << p.TWl, TH = 1 << p.THl;
+    const int txn = p.OW >> p.TWl, tyn = p.OH >> p.THl;
+    const int nchunks = (p.C0 + p.C1) / CK;  // even (host-checked)
+    const int HHW = p.HH * p.HWd;
+    const int npieces = p.SUBS * HHW * PPP;
+    const int BUF = p.lds_buf;
+
+    int hoff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int pix = nb * 32 + (lane & 31);
+        const int x = pix & (TW - 1);
+        const int y = (pix >> p.TWl) & (TH - 1);
+        const int sub = pix >> (p.TWl + p.THl);
+        hoff[nb] = sub * p.SP + y * p.RP + x * ROWB + (lane >> 5) * 16;
+    }
+
+    // per-piece halo geometry (tile independent): packed (sub, hy, hx) and the LDS byte offset
+    int geo[PMAX];
+#pragma unroll
+    for (int q = 0; q < PMAX; ++q) {
+        const int i = tid + q * 256;
+        geo[q] = -1;
+        if (i < npieces) {
+            const int hp = i / PPP;
+            const int sub = hp / HHW;
+            const int rem = hp - sub * HHW;
+            const int hy = rem / p.HWd;
+            const int hx = rem - hy * p.HWd;
+            geo[q] = (sub << 20) | (hy << 10) | hx;
+        }
+    }
+    auto tile_origin = [&](int t, int& n0, int& oy0, int& ox0) {
+        const int tx = t % txn;
+        const int ty = (t / txn) % tyn;
+        n0 = (t / (txn * tyn)) * p.SUBS;
+        oy0 = ty << p.THl;
+        ox0 = tx << p.TWl;
+    };
+    // source pixel of every staging piece for tile t (-1 = zero padding)
+    auto tile_srcpix = [&](int t, int (&sp)[PMAX]) {
+        int n0, oy0, ox0;
+        tile_origin(t, n0, oy0, ox0);
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q) {
+            const int gq = geo[q];
+            const int n = n0 + (gq >> 20);
+            const int iy = oy0 - p.pad + ((gq >> 10) & 1023);
+            const int ix = ox0 - p.pad + (gq & 1023);
+            const bool ok = gq >= 0 && iy >= 0 && ix >= 0 && iy < (p.IH << p.ups) && ix < (p.IW << p.ups) && n < p.N;
+            sp[q] = ok ? (n * p.IH + (iy >> p.ups)) * p.IW + (ix >> p.ups) : -1;
+        }
+    };
+
+    bf16x8 stg[PMAX];
+    auto stage_load = [&](int c, const int (&sp)[PMAX]) {
+        const int cbase = c * CK;
+        const bool first = cbase < p.C0;
+        const bf16* src = first ? p.in0 : p.in1;
+        const int Cs = first ? p.C0 : p.C1;
+        const int coff = (first ? cbase : cbase - p.C0) + (tid % PPP) * 8;  // 256 % PPP == 0: piece column fixed per thread
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) stg[q][e] = (bf16)0.f;
+            if (sp[q] >= 0) stg[q] = *reinterpret_cast<const bf16x8*>(src + (size_t)sp[q] * Cs + coff);
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q) {
+            const int gq = geo[q];
+            const int off = (gq >> 20) * p.SP + ((gq >> 10) & 1023) * p.RP + (gq & 1023) * ROWB + (tid % PPP) * 16;
+            if (gq >= 0) *reinterpret_cast<bf16x8*>(smem + buf + off) = stg[q];
+        }
+    };
+
+    f32x16 acc[1][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
+
+    const int cb0 = cot * 4 + wave;  // this wave's 32-co block
+    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(p.w) + (size_t)cb0 * 64 + lane;
+    const int wstep = p.CB * 64;  // fragments between consecutive k-steps
+
+    // register sets, ping-pong by the parity of the unrolled step index
+    bf16x8 A[2][2], B[2][2][NB];
+    int srcA[PMAX];  // staging sources of the tile being loaded
+
+    // ---- prologue: chunk 0 of the first tile into LDS image 0, operands of its first step into set 0
+    tile_srcpix(pt, srcA);
+    stage_load(0, srcA);
+    stage_store(0);
+    A[0][0] = wfrag[0];
+    A[0][1] = wfrag[wstep];
+    lds_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) B[0][ks][nb] = *reinterpret_cast<const bf16x8*>(smem + hoff[nb] + ks * 32);
+
+    const int clast = nchunks - 1;
+    for (;;) {
+        const int pt_next = pt + nstreams;
+        const bool more_tiles = pt_next < p.PT;
+        // ---- K loop of this tile: two chunks (2*TAPS steps) of straight-line code per iteration.
+        // Everything a step requests for its successor is unconditional, so the step body has no
+        // branches and hipcc can count its waits exactly.
+        for (int c = 0; c < ((DBG & 16) ? 0 : nchunks); c += 2) {
+            const bool last_pair = c + 2 >= nchunks;
+#pragma unroll
+            for (int u = 0; u < 2 * TAPS; ++u) {
+                const int half = u / TAPS;          // 0: chunk c (LDS image 0), 1: chunk c+1 (LDS image 1)
+                const int tap = u % TAPS;
+                const int u2 = u + 1;
+                const int half2 = (u2 / TAPS) & 1;  // LDS image of the successor step
+                const int tap2 = u2 % TAPS;
+                int cc2 = c + u2 / TAPS;            // chunk of the successor step (wraps into the next tile)
+                cc2 = cc2 > clast ? 0 : cc2;
+                const int set = u & 1;
+                if (tap == 0 && !(DBG & 2)) {
+                    if (half == 0) stage_load(c + 1, srcA);
+                    else {
+                        // the chunk after this pair: c+2 of this tile, or (last pair) chunk 0 of the next
+                        // tile — its sources replace srcA by select, not by branch (on the very last tile
+                        // this re-loads chunk 0 of the same tile, harmlessly)
+                        int srcN[PMAX];
+                        tile_srcpix(more_tiles ? pt_next : pt, srcN);
+#pragma unroll
+                        for (int q = 0; q < PMAX; ++q) srcA[q] = last_pair ? srcN[q] : srcA[q];
+                        stage_load(last_pair ? 0 : c + 2, srcA);
+                    }
+                }
+                if (!(DBG & 1)) {
+                    const bf16x8* w0 = wfrag + (size_t)(tap2 * p.KST + cc2 * 2) * wstep;
+                    A[set ^ 1][0] = w0[0];
+                    A[set ^ 1][1] = w0[wstep];
+                } else {
+                    A[set ^ 1][0] = A[set][0];
+                    A[set ^ 1][1] = A[set][1];
+                }
+                if (tap == TAPS - 1) {
+                    if (!(DBG & 2)) stage_store(half ? 0 : BUF);
+                    if (!(DBG & 4)) lds_barrier();
+                }
+                const char* nbase = smem + (half2 ? BUF : 0) + (tap2 / KS) * p.RP + (tap2 % KS) * ROWB;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        if (!(DBG & 8)) B[set ^ 1][ks][nb] = *reinterpret_cast<const bf16x8*>(nbase + hoff[nb] + ks * 32);
+                        else B[set ^ 1][ks][nb] = B[set][ks][nb];
+                        acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][ks], B[set][ks][nb], acc[0][nb], 0, 0, 0);
+                    }
+                // keep the successor's operand requests INSIDE this step: without the fence the
+                // machine scheduler sinks them next to their first use and the prefetch distance is lost
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- tile done: the next tile's first operands are already in flight
+        {
+            int n0, oy0, ox0;
+            tile_origin(pt, n0, oy0, ox0);
+            if (!(DBG & 32)) conv_epilogue_lds<NB>(p, acc, smem + 2 * BUF, n0, oy0, ox0, cot, wave, lane, tid);
+            else if (acc[0][0][0] == 12345.f) reinterpret_cast<float*>(p.out)[0] = acc[0][NB - 1][3];  // keep acc live
+        }
+        if (!more_tiles) break;
+        pt = pt_next;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
+    }
+}
+
+template <int NB, int PMAX, int KS, int DBG = 0>
+int launch_pipe(const ConvArgs& a, int grid, hipStream_t st) {
+    auto kern = conv_pipe_kernel<NB, PMAX, KS, DBG>;
+    static bool attr_set = false;  // benign race: idempotent
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), (size_t)2 * a.lds_buf + EPI_BYTES, st, a);
+    DXMI_CHECK_LAUNCH("dxmi_conv2d_fwd(pipe)");
+    return DXMI_OK;
+}
+
+int ilog2p(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+}  // namespace
+
+int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
+    if (a.in_mode != DXMI_IN_NHWC_BF16 || a.out_mode != DXMI_OUT_NHWC_BF16) return 1;
+    if (a.stride != 1 || a.Cout % 128 != 0 || (a.C0 + a.C1) % 64 != 0 || a.C0 % 32 != 0) return 1;  // even chunk count
+    const int CT = a.Cout / 128;
+    // pixel-tile size: the largest of 256/128/64 that still gives every CU a workgroup
+    const long px = (long)a.N * a.OH * a.OW;
+    int NB = 8;
+    while (NB > 2 && (px / (32 * NB)) * CT < 256) NB >>= 1;
+    // 128-pixel tiles (2 workgroups / CU: one's tile switch hides under the other's MFMAs) measured
+    // faster than 256-pixel tiles at 1 workgroup / CU: default cap 4.
+    static const int nb_cap = getenv("DXMI_CONV_NB") ? atoi(getenv("DXMI_CONV_NB")) : 4;  // tuning override
+    while (NB > nb_cap && NB > 2) NB >>= 1;
+    const int tile = 32 * NB;
+    const int TW = a.OW < 32 ? a.OW : 32;
+    int TH = tile / TW;
+    if (TH > a.OH) TH = a.OH;
+    const int SUBS = tile / (TW * TH);
+    if (TW * TH * SUBS != tile) return 1;
+    ConvArgs b = a;
+    b.TWl = ilog2p(TW); b.THl = ilog2p(TH); b.SUBS = SUBS;
+    b.HH = TH + a.ksize - 1; b.HWd = TW + a.ksize - 1;
+    b.tile_px = tile;
+    const int ngroups = (a.N + SUBS - 1) / SUBS;
+    b.PT = ngroups * (a.OH / TH) * (a.OW / TW);
+    b.CT = CT;
+    const int HP = SUBS * b.HH * b.HWd;
+    // LDS pitches: a 32-pixel MFMA block spans 32/TW halo rows; the ds_read_b128 lane groups stay
+    // conflict-free when consecutive rows are offset by 0 / 128 / 64 bytes (mod 256) for TW = 16 / 8 / 4
+    // (brute-forced over the b128 lane groups; TW = 32 is conflict-free at any pitch) and sub-images by
+    // a multiple of 256.
+    {
+        const int want = TW == 16 ? 0 : (TW == 8 ? 128 : (TW == 4 ? 64 : -1));
+        int rp = b.HWd * 80;
+        if (want >= 0) while (rp % 256 != want) rp += 16;
+        int sp = b.HH * rp;
+        if (SUBS > 1) while (sp % 256 != 0) sp += 16;
+        b.RP = rp; b.SP = sp;
+    }
+    b.lds_buf = SUBS * b.SP;
+    if (2 * b.lds_buf + EPI_BYTES > 160 * 1024) return 1;
+    const int npieces = HP * 4;
+    const int pmax = npieces <= 6 * 256 ? 6 : (npieces <= 9 * 256 ? 9 : 0);
+    if (!pmax) return 1;
+    if (kernel_id) {
+        *kernel_id = 10000 * a.ksize + NB * 100 + pmax;  // kxxyy = conv_pipe_kernel<xx, yy, k>
+        return DXMI_OK;
+    }
+    // persistent grid: as many workgroups as are co-resident (2 per CU for NB <= 4, else 1), a
+    // multiple of CT; each walks PT / nstreams pixel tiles.
+    static const int wg_per_cu = getenv("DXMI_CONV_WGS") ? atoi(getenv("DXMI_CONV_WGS")) : 0;
+    const int resident = 256 * (wg_per_cu > 0 ? wg_per_cu : (NB <= 4 ? 2 : 1));
+    int nstreams = resident / CT;
+    if (nstreams > b.PT) nstreams = b.PT;
+    if (nstreams < 1) nstreams = 1;
+    const int grid = nstreams * CT;
+    static const int stagger = getenv("DXMI_CONV_STAGGER") ? atoi(getenv("DXMI_CONV_STAGGER")) : 0;
+    b.stagger = (grid > 256 && b.PT / nstreams >= 2) ? stagger : 0;
+    static const int dbg = getenv("DXMI_CONV_DBG") ? atoi(getenv("DXMI_CONV_DBG")) : 0;
+    if (dbg && a.ksize == 3 && pmax == 6 && NB == 4) {
+        switch (dbg) {
+            case 1: return launch_pipe<4, 6, 3, 1>(b, grid, st);
+            case 8: return launch_pipe<4, 6, 3, 8>(b, grid, st);
+            case 15: return launch_pipe<4, 6, 3, 15>(b, grid, st);
+            case 16: return launch_pipe<4, 6, 3, 16>(b, grid, st);
+            case 32: return launch_pipe<4, 6, 3, 32>(b, grid, st);
+            case 48: return launch_pipe<4, 6, 3, 48>(b, grid, st);
+        }
+    }
+#define DXMI_PIPE(NB_, PM_) (a.ksize == 3 ? launch_pipe<NB_, PM_, 3>(b, grid, st) : launch_pipe<NB_, PM_, 1>(b, grid, st))
+    if (NB == 8) return pmax == 6 ? DXMI_PIPE(8, 6) : DXMI_PIPE(8, 9);
+    if (NB == 4) return pmax == 6 ? DXMI_PIPE(4, 6) : DXMI_PIPE(4, 9);
+    return pmax == 6 ? DXMI_PIPE(2, 6) : DXMI_PIPE(2, 9);
+#undef DXMI_PIPE
+}
