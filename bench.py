@@ -36,6 +36,13 @@ UNET_KW = dict(ch=128, out_ch=3, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_re
                in_channels=3, resolution=32)  # reference configs/cifar10/T10.yaml:1-10
 
 
+def kernel_name(kid):
+    """dxmi_conv2d_kernel_id -> the template instantiation name rocprofv3 prints."""
+    if kid >= 10000:
+        return f"conv_pipe_kernel<{(kid // 100) % 100}, {kid % 100}, {kid // 10000}, 0>"
+    return f"conv_igemm_kernel<{kid // 1000}, {(kid // 100) % 10}, 32, {kid % 100}>"
+
+
 def build_sampler(device, T):
     from models.DxMI.unet_small import Model
     from models.DxMI.var_sampler import VARSampler
@@ -146,13 +153,13 @@ def main():
             line["roofline"] = {
                 "bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
-                "kernel": f"conv_igemm_kernel<{kid // 1000},{(kid // 100) % 10},32,{kid % 100}>",
+                "kernel": kernel_name(kid),
                 "launches": s["launches"], "avg_launch_us": 1e3 * s["ms"] / s["launches"],
                 "algorithmic_gflop_per_launch": s["flops"] / s["launches"] / 1e9,
                 "algorithmic_gbps": s["bytes"] / (s["ms"] * 1e-3) / 1e9,
                 "share_of_step_time": s["ms"] * 1e-3 / elapsed,
             }
-            line["conv_kernels"] = {str(k): {"launches": v["launches"], "ms": round(v["ms"], 3),
+            line["conv_kernels"] = {kernel_name(k): {"launches": v["launches"], "ms": round(v["ms"], 3),
                                              "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12} for k, v in summ.items()}
     if world == 1 and not args.no_cpu_baseline:
         cb = 16

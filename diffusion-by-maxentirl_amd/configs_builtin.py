@@ -1,0 +1,40 @@
+"""Built-in copies of the model configurations the DxMI hot path is measured on, as Python data
+(the YAML files of the reference are accepted unchanged by dxmi_config.load; these exist so tests,
+bench.py and `--config builtin:cifar10_T10` work without the reference checkout).
+Values: reference configs/cifar10/T10.yaml:1-59 and configs/cifar10/cifar10.yaml."""
+import copy
+
+_UNET_CIFAR = {"_target_": "models.DxMI.unet_small.Model", "resolution": 32, "in_channels": 3, "out_ch": 3, "ch": 128,
+               "ch_mult": [1, 2, 2, 2], "num_res_blocks": 2, "attn_resolutions": [16], "dropout": 0.1}
+_VALUE_IGEBM = {"_target_": "models.value.TimeIndependentValue",
+                "net": {"_target_": "models.modules.IGEBMEncoderV2", "in_chan": 3, "out_chan": 1,
+                        "use_spectral_norm": False, "keepdim": False, "out_activation": "linear", "avg_pool_dim": 1,
+                        "learn_out_scale": True, "nh": 128}}
+
+CONFIGS = {
+    "cifar10_T10": {
+        "sampler_net": _UNET_CIFAR,
+        "sampler": {"_target_": "models.DxMI.var_sampler.VARSampler", "n_timesteps": 10, "sample_shape": [3, 32, 32],
+                    "trainable_beta": "fix_last"},
+        "energy": None,
+        "value": _VALUE_IGEBM,
+        "trainer": {"_target_": "models.DxMI.trainer.DxMI_Trainer", "tau1": 0.1, "tau2": 0.01, "gamma": 1,
+                    "use_sampler_beta": True, "time_cost": 0, "adavelreg": 0.99, "entropy_in_value": None,
+                    "velocity_in_value": None, "time_cost_sig": True},
+        "training": {"sampler_ckpt": "pretrained/cifar10_ddpm/model.ckpt.pth", "value_ckpt": None, "fid_epoch": 1,
+                     "n_epochs": 200, "batchsize": 128, "sampling_batchsize": 100, "n_fid_samples": 10000,
+                     "n_critic": 1, "n_generator": 1, "lr": 1e-7, "v_lr": 1e-5, "seed": 112233, "log_every": 50,
+                     "beta_lr": 1e-5},
+        "data": {"name": "cifar10", "data_dir": "datasets"},
+    },
+}
+# BASELINE configs[2] ("DDGAN backbone T=4"): models.ddgan is absent from the reference snapshot
+# (SURVEY 2 row 27), so the DDGAN *protocol* (T=4, value_resample) is run on the DDPM backbone.
+CONFIGS["cifar10_T4_ddpm_backbone"] = copy.deepcopy(CONFIGS["cifar10_T10"])
+CONFIGS["cifar10_T4_ddpm_backbone"]["sampler"]["n_timesteps"] = 4
+CONFIGS["cifar10_T4_ddpm_backbone"]["trainer"].update({"value_resample": True})
+
+
+def get(name):
+    from dxmi_config import Cfg
+    return Cfg(copy.deepcopy(CONFIGS[name]))

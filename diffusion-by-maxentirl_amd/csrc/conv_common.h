@@ -9,6 +9,7 @@ struct ConvArgs {
     const float* bias;
     const float* addvec;
     const bf16* residual;
+    const bf16* mask_src;    // activation-gradient mask source (same shape as out) or null
     void* out;
     int N, IH, IW, C0, C1, OH, OW, Cout;
     int ksize, stride, pad, ups, act, addvec_ld, in_mode, out_mode;
@@ -18,6 +19,7 @@ struct ConvArgs {
     int PT, CT, CB, KST;     // pixel tiles, cout tiles, 32-co blocks (padded), total 16-ci k-steps
     int tile_px;             // output pixels per workgroup tile (256, 128 or 64)
     int lds_buf;             // bytes of one LDS halo image (16-byte multiple)
+    float mask_slope;        // factor applied where mask_src <= 0 (0.2 leaky, 0 relu)
     int stagger;             // conv_pipe: start delay (units of s_sleep 127 ~ 8k cycles) of the second resident half
     int RP, SP;              // conv_pipe: LDS pitch of a halo row / of a sub-image, bytes (bank-conflict-free choice)
 };
@@ -85,6 +87,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[M
                             const bf16x4 rv = *reinterpret_cast<const bf16x4*>(p.residual + opix * p.Cout + co);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                        }
+                        if (p.mask_src) {
+                            const bf16x4 mv = *reinterpret_cast<const bf16x4*>(p.mask_src + opix * p.Cout + co);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= ((float)mv[e] > 0.f ? 1.f : p.mask_slope);
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = dxmi_act(v[e], p.act);

@@ -365,10 +365,12 @@ static int conv2d_impl(const dxmi_conv_desc* d, void* stream, int* kernel_id) {
     }
     DXMI_CHECK_ARG(d->out_mode != DXMI_OUT_NCHW_F32 || !d->residual, "dxmi_conv2d_fwd: residual unsupported with NCHW output");
     DXMI_CHECK_ARG(!d->residual || d->Cout % 4 == 0, "dxmi_conv2d_fwd: residual needs Cout%%4==0");
+    DXMI_CHECK_ARG(!d->mask_src || (d->Cout % 4 == 0 && d->out_mode == DXMI_OUT_NHWC_BF16), "dxmi_conv2d_fwd: mask_src needs NHWC bf16 output, Cout%%4==0");
 
     ConvArgs a;
     a.in0 = (const bf16*)d->in0; a.in1 = (const bf16*)d->in1; a.w = (const bf16*)d->wpacked;
     a.bias = d->bias; a.addvec = d->addvec; a.residual = (const bf16*)d->residual; a.out = d->out;
+    a.mask_src = (const bf16*)d->mask_src; a.mask_slope = d->mask_slope;
     a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.C0 = d->C0; a.C1 = d->C1; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
     a.ksize = d->ksize; a.stride = d->stride; a.pad = d->pad; a.ups = d->upsample ? 1 : 0; a.act = d->act;
     a.addvec_ld = d->addvec_ld; a.in_mode = d->in_mode; a.out_mode = d->out_mode; a.P = 0; a.pre_act = 0;
@@ -403,7 +405,7 @@ extern "C" int dxmi_linear_fwd(const float* x, const void* wpacked, const float*
     DXMI_CHECK_ARG(P > 0 && M > 0 && K > 0 && K % 32 == 0, "dxmi_linear_fwd: K (%d) must be a positive multiple of 32", K);
     ConvArgs a;
     a.in0 = (const bf16*)x; a.in1 = nullptr; a.w = (const bf16*)wpacked; a.bias = bias; a.addvec = nullptr;
-    a.residual = nullptr; a.out = out;
+    a.residual = nullptr; a.out = out; a.mask_src = nullptr; a.mask_slope = 0.f;
     a.N = 1; a.IH = 1; a.IW = P; a.C0 = K; a.C1 = 0; a.OH = 1; a.OW = P; a.Cout = M;
     a.ksize = 1; a.stride = 1; a.pad = 0; a.ups = 0; a.act = post_act; a.addvec_ld = 0;
     a.in_mode = DXMI_IN_ROWS_F32; a.out_mode = DXMI_OUT_ROWS_F32; a.P = P; a.pre_act = pre_act;

@@ -86,6 +86,11 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&ac
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
                 }
+                if (p.mask_src) {
+                    const bf16x8 mv = *reinterpret_cast<const bf16x8*>(p.mask_src + o);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= ((float)mv[e] > 0.f ? 1.f : p.mask_slope);
+                }
                 bf16x8 ov;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ov[e] = (bf16)dxmi_act(v[e], p.act);

@@ -1,0 +1,276 @@
+// Convolution weight gradient on MFMA for gfx950 (value-network / U-Net training path).
+//
+//   dW[tap][co][ci] = sum_p dY[p][co] * X[p + tap][ci]        p over all N*H*W output pixels
+// is a GEMM whose K dimension is the PIXEL index, while both operands live in NHWC (channel
+// contiguous).  The MFMA fragments need 8 consecutive k per lane, i.e. a transposed view of both
+// tiles: gfx950's ds_read_b64_tr_b16 delivers exactly that from row-major LDS images (a 16-lane
+// group reads a 4-pixel x 16-channel block and every lane receives one channel's 4 pixels; lane
+// semantics verified on hardware with tools/tr_probe.hip).  No transposed copies are ever made.
+//
+// Workgroup = 4 waves = a 64 co x 64 ci block of dW for ALL taps (accumulators: 9 x 32x32 fp32 per
+// wave), looping over a strided list of 128-pixel tiles: per tile the dY tile [128 px][64 co] and the
+// X halo tile [halo px][64 ci] are staged in LDS (pitch 192 B: the 4 rows x 64 B of a tr-read half
+// wave land in distinct banks), then per 16-pixel k-step ONE A fragment (2 tr reads) feeds 9 MFMAs
+// whose B fragments are the 9 shifted windows of the halo image.  Split-K over pixel tiles: every
+// workgroup writes its partial block with plain coalesced stores, a second kernel sums the partials
+// in a fixed order (bitwise reproducible), converts to OIHW and optionally accumulates into .grad.
+//
+// Replaces autograd's conv weight gradient for models/modules.py:71-101,142-145 and
+// models/DxMI/unet_small.py convs (reference: torch.nn.Conv2d backward).
+#include "conv_common.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define LDS_S16X4(p) ((__attribute__((address_space(3))) s16x4*)(p))
+
+struct WgradArgs {
+    const bf16* x0;      // forward input, NHWC [N,IH,IW,C0]
+    const bf16* x1;      // second concat source or null
+    const bf16* dy;      // output gradient, NHWC [N,OH,OW,Cout]
+    float* partial;      // [S][taps][Cout][Cin] fp32
+    int N, IH, IW, C0, C1, OH, OW, Cout;
+    int ksize, pad, ups;
+    int TWl, THl, SUBS, HH, HWd;  // 128-pixel tile geometry + halo
+    int PT, S;                    // pixel tiles, pixel splits
+    int CIB, COB;                 // 64-wide ci / co blocks
+};
+
+constexpr int WG_PITCH = 192;  // bytes per LDS pixel row (64 channels bf16 + 64 pad)
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* row_lo, const char* row_hi) {
+    // two transposing reads: k (pixel) 0..3 and 4..7 of this lane's channel
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(row_lo));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(row_hi));
+    bf16x8 r;
+    short* rs = reinterpret_cast<short*>(&r);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { rs[e] = a[e]; rs[4 + e] = b[e]; }
+    return r;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
+    constexpr int TAPS = KS * KS;
+    constexpr int TP = 128;  // pixels per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ydy = smem;                       // [TP][64 co]
+    char* xim = smem + TP * WG_PITCH;       // [halo px][64 ci]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;  // 32-co / 32-ci sub-block of the 64x64 block
+    // block -> (split, co block, ci block)
+    int b = blockIdx.x;
+    const int cib = b % p.CIB; b /= p.CIB;
+    const int cob = b % p.COB; b /= p.COB;
+    const int split = b;
+
+    const int TW = 1 << p.TWl, TH = 1 << p.THl;
+    const int txn = p.OW >> p.TWl, tyn = p.OH >> p.THl;
+    const int HHW = p.HH * p.HWd;
+    const int Cin = p.C0 + p.C1;
+    const int ci0 = cib * 64, co0 = cob * 64;
+    const bool first = ci0 < p.C0;
+    const bf16* xsrc = first ? p.x0 : p.x1;
+    const int Cs = first ? p.C0 : p.C1;
+    const int cis = first ? ci0 : ci0 - p.C0;
+
+    // tr-read lane roles: group g = lane>>4 -> channel half (g&1), k half (g>>1); lane 4q+p -> row q, cols 4p..
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int ch_off = (16 * (g & 1) + 4 * pp) * 2;  // byte offset of this lane's 4-channel chunk in a 32-ch sub-block
+    const int krow = 8 * (g >> 1) + q;               // + 4 for the second read
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int pt = split; pt < p.PT; pt += p.S) {
+        const int tx = pt % txn, ty = (pt / txn) % tyn;
+        const int n0 = (pt / (txn * tyn)) * p.SUBS;
+        const int oy0 = ty << p.THl, ox0 = tx << p.TWl;
+        __syncthreads();
+        // ---- stage dY tile: 128 px x 64 co = 8 pieces / px
+        for (int i = tid; i < TP * 8; i += 256) {
+            const int pix = i >> 3, pc = i & 7;
+            const int x = pix & (TW - 1), y = (pix >> p.TWl) & (TH - 1), n = n0 + (pix >> (p.TWl + p.THl));
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+            if (n < p.N) v = *reinterpret_cast<const bf16x8*>(p.dy + (((size_t)n * p.OH + oy0 + y) * p.OW + ox0 + x) * p.Cout + co0 + pc * 8);
+            *reinterpret_cast<bf16x8*>(ydy + pix * WG_PITCH + pc * 16) = v;
+        }
+        // ---- stage X halo tile: (SUBS*HH*HWd) px x 64 ci
+        for (int i = tid; i < p.SUBS * HHW * 8; i += 256) {
+            const int hp = i >> 3, pc = i & 7;
+            const int sub = hp / HHW, rem = hp - sub * HHW;
+            const int hy = rem / p.HWd, hx = rem - hy * p.HWd;
+            const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx, n = n0 + sub;
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+            if (n < p.N && iy >= 0 && ix >= 0 && iy < (p.IH << p.ups) && ix < (p.IW << p.ups))
+                v = *reinterpret_cast<const bf16x8*>(xsrc + (((size_t)n * p.IH + (iy >> p.ups)) * p.IW + (ix >> p.ups)) * Cs + cis + pc * 8);
+            *reinterpret_cast<bf16x8*>(xim + hp * WG_PITCH + pc * 16) = v;
+        }
+        __syncthreads();
+        // ---- 8 k-steps of 16 pixels
+#pragma unroll 2
+        for (int kb = 0; kb < TP / 16; ++kb) {
+            const int plo = kb * 16 + krow, phi = plo + 4;
+            const bf16x8 a = tr_frag(ydy + plo * WG_PITCH + wr * 64 + ch_off, ydy + phi * WG_PITCH + wr * 64 + ch_off);
+            // halo offsets of the two pixel rows this lane addresses
+            const int xl = plo & (TW - 1), yl = (plo >> p.TWl) & (TH - 1), sl = plo >> (p.TWl + p.THl);
+            const int xh = phi & (TW - 1), yh = (phi >> p.TWl) & (TH - 1), sh = phi >> (p.TWl + p.THl);
+            const char* bl = xim + ((sl * p.HH + yl) * p.HWd + xl) * WG_PITCH + wc * 64 + ch_off;
+            const char* bh = xim + ((sh * p.HH + yh) * p.HWd + xh) * WG_PITCH + wc * 64 + ch_off;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int toff = ((t / KS) * p.HWd + (t % KS)) * WG_PITCH;
+                const bf16x8 bfrag = tr_frag(bl + toff, bh + toff);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partial block: D[co][ci], lane: ci = lane&31, co = 8g' + 4h + {0..3}
+    const int h = lane >> 5;
+    float* pb = p.partial + (size_t)split * TAPS * p.Cout * Cin;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ci = ci0 + wc * 32 + (lane & 31);
+            pb[((size_t)t * p.Cout + co) * Cin + ci] = acc[t][r];
+        }
+}
+
+// sum the S partials in a fixed order -> OIHW fp32 gradient (optionally accumulated)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S, int taps, int Cout,
+                                    int Cin, int accumulate) {
+    const long total = (long)taps * Cout * Cin;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += partial[(size_t)k * total + idx];
+    const int ci = idx % Cin;
+    const long r = idx / Cin;
+    const int co = r % Cout;
+    const int t = (int)(r / Cout);
+    const long o = ((long)co * Cin + ci) * taps + t;
+    dw[o] = accumulate ? dw[o] + s : s;
+}
+
+// column sums of a [P][C] bf16 matrix -> fp32 [C] (bias gradient); fixed-order two-level reduction
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ x, float* __restrict__ part, long P,
+                                                            int C, int rows_per_block) {
+    // thread t handles 8-channel piece (t % (C/8)); rows strided by 256/(C/8)
+    const int c8n = C / 8;
+    const int pc = threadIdx.x % c8n, r0 = threadIdx.x / c8n, rstep = 256 / c8n;
+    const long base = (long)blockIdx.x * rows_per_block;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r0 < rstep)
+        for (long r = base + r0; r < base + rows_per_block && r < P; r += rstep) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * C + pc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+        }
+    __shared__ float red[256][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < c8n) {
+        float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = threadIdx.x; k < rstep * c8n; k += c8n)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] += red[k][e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[(size_t)blockIdx.x * C + threadIdx.x * 8 + e] = t[e];
+    }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < nblocks; ++k) s += part[(size_t)k * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+int ilog2w(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+}  // namespace
+
+extern "C" int64_t dxmi_conv2d_wgrad_workspace_bytes(int32_t N, int32_t OH, int32_t OW, int32_t Cin, int32_t Cout, int32_t ksize) {
+    const long PT = ((long)N * OH * OW + 127) / 128 + 16;
+    long S = 512 / ((long)(Cin / 64) * (Cout / 64));
+    if (S < 1) S = 1;
+    if (S > PT) S = PT;
+    return S * ksize * ksize * (int64_t)Cout * Cin * 4;
+}
+
+extern "C" int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int32_t C1, const void* dy, float* dw_oihw,
+                                 void* workspace, int32_t N, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t Cout,
+                                 int32_t ksize, int32_t pad, int32_t upsample, int32_t accumulate, void* stream) {
+    DXMI_CHECK_ARG(x0 && dy && dw_oihw && workspace, "dxmi_conv2d_wgrad: null pointer");
+    const int Cin = C0 + C1;
+    DXMI_CHECK_ARG(ksize == 1 || ksize == 3, "dxmi_conv2d_wgrad: ksize %d unsupported", ksize);
+    DXMI_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && C0 % 64 == 0, "dxmi_conv2d_wgrad: Cin (%d+%d) and Cout (%d) must be multiples of 64", C0, C1, Cout);
+    DXMI_CHECK_ARG((OW & (OW - 1)) == 0 && (OH & (OH - 1)) == 0 && OW >= 4 && OH >= 4, "dxmi_conv2d_wgrad: OH/OW must be powers of two >= 4");
+    DXMI_CHECK_ARG(C1 == 0 || x1, "dxmi_conv2d_wgrad: C1>0 but x1 NULL");
+    WgradArgs a;
+    a.x0 = (const bf16*)x0; a.x1 = (const bf16*)x1; a.dy = (const bf16*)dy; a.partial = (float*)workspace;
+    a.N = N; a.IH = IH; a.IW = IW; a.C0 = C0; a.C1 = C1; a.OH = OH; a.OW = OW; a.Cout = Cout;
+    a.ksize = ksize; a.pad = pad; a.ups = upsample ? 1 : 0;
+    const int TW = OW < 32 ? OW : 32;
+    int TH = 128 / TW; if (TH > OH) TH = OH;
+    a.TWl = ilog2w(TW); a.THl = ilog2w(TH); a.SUBS = 128 / (TW * TH);
+    a.HH = TH + ksize - 1; a.HWd = TW + ksize - 1;
+    const int ngroups = (N + a.SUBS - 1) / a.SUBS;
+    a.PT = ngroups * (OH / TH) * (OW / TW);
+    a.CIB = Cin / 64; a.COB = Cout / 64;
+    int S = 512 / (a.CIB * a.COB);
+    if (S < 1) S = 1;
+    if (S > a.PT) S = a.PT;
+    a.S = S;
+    const size_t lds = (size_t)(128 + a.SUBS * a.HH * a.HWd) * WG_PITCH;
+    DXMI_CHECK_ARG(lds <= 160 * 1024, "dxmi_conv2d_wgrad: LDS %zu too large", lds);
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(S * a.CIB * a.COB), block(256);
+    if (ksize == 3) {
+        static bool attr3 = false;
+        if (!attr3) { hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr3 = true; }
+        hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, block, lds, st, a);
+    } else {
+        static bool attr1 = false;
+        if (!attr1) { hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
+        hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, block, lds, st, a);
+    }
+    DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad");
+    const long total = (long)ksize * ksize * Cout * Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
+                       dw_oihw, S, ksize * ksize, Cout, Cin, accumulate);
+    DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad(reduce)");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_colsum_bf16(const void* x, float* out, void* workspace, int64_t P, int32_t C, int32_t accumulate,
+                                void* stream) {
+    DXMI_CHECK_ARG(x && out && workspace, "dxmi_colsum_bf16: null pointer");
+    DXMI_CHECK_ARG(C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0, "dxmi_colsum_bf16: C=%d unsupported", C);
+    const int rows_per_block = 512;
+    const int nblocks = (int)((P + rows_per_block - 1) / rows_per_block);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks), dim3(256), 0, st, (const bf16*)x, (float*)workspace, (long)P, C,
+                       rows_per_block);
+    DXMI_CHECK_LAUNCH("dxmi_colsum_bf16");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, out, nblocks, C,
+                       accumulate);
+    DXMI_CHECK_LAUNCH("dxmi_colsum_bf16(final)");
+    return DXMI_OK;
+}

@@ -145,6 +145,48 @@ __global__ __launch_bounds__(64) void value_head_kernel(const bf16* __restrict__
     }
 }
 
+// backward of pool_act: 8 channels per thread over the INPUT-resolution grid
+__global__ void pool_act_bwd_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ aout, bf16* __restrict__ din,
+                                    int N, int H, int W, int C, int pool, float slope) {
+    const int OH = pool ? H / 2 : H, OW = pool ? W / 2 : W;
+    const int C8 = C / 8;
+    const long total = (long)N * H * W * C8;
+    const float sc = pool ? 0.25f : 1.f;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c8 = idx % C8;
+        long r = idx / C8;
+        const int x = r % W; r /= W;
+        const int y = r % H;
+        const int n = (int)(r / H);
+        const size_t o = (((size_t)n * OH + (pool ? y / 2 : y)) * OW + (pool ? x / 2 : x)) * C + c8 * 8;
+        const bf16x8 g = *reinterpret_cast<const bf16x8*>(dout + o);
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(aout + o);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)g[e] * ((float)a[e] > 0.f ? sc : sc * slope));
+        *reinterpret_cast<bf16x8*>(din + (((size_t)n * H + y) * W + x) * C + c8 * 8) = v;
+    }
+}
+
+// backward of the value head w.r.t. the feature map (+ the relu/sum features for the parameter grads)
+__global__ __launch_bounds__(64) void value_head_bwd_kernel(const bf16* __restrict__ feat, const float* __restrict__ w,
+                                                           const float* __restrict__ dy, bf16* __restrict__ dfeat,
+                                                           float* __restrict__ s, int HW, int C) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const float g = dy[n];
+    for (int c = lane; c < C; c += 64) {
+        float acc = 0.f;
+        const float gw = g * w[c];
+        for (int px = 0; px < HW; ++px) {
+            const size_t o = ((size_t)n * HW + px) * C + c;
+            const float v = (float)feat[o];
+            acc += v > 0.f ? v : 0.f;
+            dfeat[o] = (bf16)(v > 0.f ? gw : 0.f);
+        }
+        s[(size_t)n * C + c] = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, bf16* __restrict__ out, int N, int C, int HW) {
     const long total = (long)N * C * HW;
@@ -215,6 +257,25 @@ extern "C" int dxmi_pool_act(const void* in, void* out, int32_t N, int32_t H, in
     hipLaunchKernelGGL(pool_act_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)in,
                        (bf16*)out, N, H, W, C, pool, act);
     DXMI_CHECK_LAUNCH("dxmi_pool_act");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_pool_act_bwd(const void* dout, const void* act_out, void* din, int32_t N, int32_t H, int32_t W,
+                                 int32_t C, int32_t pool, float slope, void* stream) {
+    DXMI_CHECK_ARG(dout && act_out && din && C % 8 == 0 && (!pool || (H % 2 == 0 && W % 2 == 0)), "dxmi_pool_act_bwd: bad arguments");
+    const long total = (long)N * H * W * (C / 8);
+    hipLaunchKernelGGL(pool_act_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout,
+                       (const bf16*)act_out, (bf16*)din, N, H, W, C, pool, slope);
+    DXMI_CHECK_LAUNCH("dxmi_pool_act_bwd");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_value_head_bwd(const void* feat, const float* w, const float* dy, void* dfeat, float* s, int32_t N,
+                                   int32_t HW, int32_t C, void* stream) {
+    DXMI_CHECK_ARG(feat && w && dy && dfeat && s, "dxmi_value_head_bwd: null pointer");
+    hipLaunchKernelGGL(value_head_bwd_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, (const bf16*)feat, w, dy, (bf16*)dfeat,
+                       s, HW, C);
+    DXMI_CHECK_LAUNCH("dxmi_value_head_bwd");
     return DXMI_OK;
 }
 

@@ -22,6 +22,7 @@ class ConvDesc(ctypes.Structure):
         ("OH", c_int), ("OW", c_int), ("Cout", c_int),
         ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int), ("act", c_int),
         ("addvec_ld", c_int), ("in_mode", c_int), ("out_mode", c_int), ("variant", c_int),
+        ("mask_src", c_void_p), ("mask_slope", c_float),
     ]
 
 
@@ -34,6 +35,11 @@ SIGNATURES = {
     "dxmi_conv2d_kernel_id": (c_int, [ctypes.POINTER(ConvDesc)]),
     "dxmi_packed_conv_weight_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "dxmi_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dxmi_conv2d_wgrad_workspace_bytes": (c_int64, [c_int] * 6),
+    "dxmi_conv2d_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "dxmi_colsum_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "dxmi_pool_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "dxmi_value_head_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dxmi_groupnorm_silu_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dxmi_attention_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),

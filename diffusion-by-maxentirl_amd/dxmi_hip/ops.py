@@ -63,7 +63,7 @@ def pack_conv_weight(w, transpose_flip=False, k27=False, out=None):
 
 
 def conv2d(x, pw, *, in1=None, bias=None, addvec=None, residual=None, stride=1, pad=None, pad_br=None, upsample=False,
-           act=ACT_NONE, out=None, out_nchw_f32=False, variant=0):
+           act=ACT_NONE, out=None, out_nchw_f32=False, variant=0, mask_src=None, mask_slope=0.0):
     """x: NHWC bf16 [N,IH,IW,C0] (or NCHW fp32 [N,3,H,W] when pw.k27)."""
     _need_cuda(x, in1, bias, addvec, residual, out)
     k = pw.ksize
@@ -109,6 +109,10 @@ def conv2d(x, pw, *, in1=None, bias=None, addvec=None, residual=None, stride=1, 
     d.in_mode = IN_NCHW_F32_K27 if pw.k27 else IN_NHWC_BF16
     d.out_mode = OUT_NCHW_F32 if out_nchw_f32 else OUT_NHWC_BF16
     d.variant = variant
+    if mask_src is not None:
+        assert mask_src.dtype == torch.bfloat16 and mask_src.is_contiguous() and tuple(mask_src.shape) == (N, OH, OW, Cout)
+    d.mask_src = mask_src.data_ptr() if mask_src is not None else None
+    d.mask_slope = float(mask_slope)
     if CONV_PROFILER is not None:
         CONV_PROFILER.launch(d)
     else:
@@ -151,6 +155,77 @@ class ConvProfiler:
 
 
 CONV_PROFILER = None
+
+
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only scratch buffer per device (split-K partials); safe because all launches are stream-ordered."""
+    key = str(device)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def conv2d_wgrad(x, dy, ksize, *, in1=None, pad=None, upsample=False, out=None, accumulate=False):
+    """Weight gradient of a stride-1 conv: x [N,IH,IW,C0] (| in1), dy [N,OH,OW,Cout] NHWC bf16 ->
+    fp32 OIHW [Cout, C0+C1, k, k] (written, or added when accumulate)."""
+    _need_cuda(x, in1, dy, out)
+    N, IH, IW, C0 = x.shape
+    C1 = in1.shape[3] if in1 is not None else 0
+    _, OH, OW, Cout = dy.shape
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16 and x.is_contiguous() and dy.is_contiguous()
+    if pad is None:
+        pad = ksize // 2
+    if out is None:
+        out = torch.empty((Cout, C0 + C1, ksize, ksize), dtype=torch.float32, device=x.device)
+        accumulate = False
+    assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (Cout, C0 + C1, ksize, ksize)
+    lib = load()
+    ws = _workspace(lib.dxmi_conv2d_wgrad_workspace_bytes(N, OH, OW, C0 + C1, Cout, ksize), x.device)
+    check(lib.dxmi_conv2d_wgrad(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(out), _ptr(ws), N, IH, IW, OH, OW, Cout, ksize,
+                                pad, int(upsample), int(accumulate), _stream()), "dxmi_conv2d_wgrad")
+    return out
+
+
+def colsum(x2d, out=None, accumulate=False):
+    """Column sums of a bf16 tensor viewed as [P, C] -> fp32 [C] (bias gradients)."""
+    _need_cuda(x2d, out)
+    C = x2d.shape[-1]
+    P = x2d.numel() // C
+    assert x2d.dtype == torch.bfloat16 and x2d.is_contiguous()
+    if out is None:
+        out = torch.empty(C, dtype=torch.float32, device=x2d.device)
+        accumulate = False
+    ws = _workspace(((P + 511) // 512) * C * 4, x2d.device)
+    check(load().dxmi_colsum_bf16(_ptr(x2d), _ptr(out), _ptr(ws), P, C, int(accumulate), _stream()), "dxmi_colsum_bf16")
+    return out
+
+
+def pool_act_bwd(dout, act_out, pool, slope, out=None):
+    _need_cuda(dout, act_out, out)
+    N, OH, OW, C = dout.shape
+    H, W = (OH * 2, OW * 2) if pool else (OH, OW)
+    assert dout.dtype == torch.bfloat16 and dout.is_contiguous() and act_out.shape == dout.shape and act_out.is_contiguous()
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=dout.device)
+    check(load().dxmi_pool_act_bwd(_ptr(dout), _ptr(act_out), _ptr(out), N, H, W, C, int(pool), float(slope), _stream()),
+          "dxmi_pool_act_bwd")
+    return out
+
+
+def value_head_bwd(feat, w, dy):
+    """feat [N,H,W,C] bf16, w [C] fp32, dy [N] fp32 -> (dfeat bf16 like feat, s [N,C] fp32)."""
+    _need_cuda(feat, w, dy)
+    N, H, W, C = feat.shape
+    dfeat = torch.empty_like(feat)
+    s = torch.empty((N, C), dtype=torch.float32, device=feat.device)
+    check(load().dxmi_value_head_bwd(_ptr(feat), _ptr(w), _ptr(dy), _ptr(dfeat), _ptr(s), N, H * W, C, _stream()),
+          "dxmi_value_head_bwd")
+    return dfeat, s
 
 
 def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, out=None):

@@ -1,0 +1,128 @@
+"""Generate samples from a trained DxMI sampler on MI355X (CLI-compatible with the reference's
+generate_cifar10.py:45-233 for the generation path).
+
+    torchrun --nproc_per_node=N generate_cifar10.py --log_dir results/cifar10/T10/run -n 50000 --batchsize 100
+
+Reads `config.yaml` + `sampler_{epoch}.pth` from --log_dir (as written by train_cifar10.py), shards the
+images over ranks with seed+rank (reference :103-110, :193-204), runs the HIP sampler and writes
+`{rank}_{i}.png` under <log_dir>/generated.  FID (pytorch_fid + Inception weights + the training PNGs)
+is outside the accelerated path: it runs only when pytorch_fid and the dataset folder are present,
+otherwise it is skipped with a message (`--skip_fid` forces that).  `--synthetic` builds the net from
+the built-in config with random weights (benchmark / smoke use, no checkpoint needed).
+"""
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+import cmd_utils as cmd  # noqa: F401  (kept for CLI parity: unknown --a.b overrides are parsed the same way)
+import dxmi_config
+from utils import mkdir_p, print0
+
+
+def rescale(X):
+    return (X - (-1)) / 2
+
+
+def save_png(img_chw, path):
+    """uint8 PNG of a [3,H,W] tensor in [0,1] (torchvision.utils.save_image rounding: x*255+0.5)."""
+    from PIL import Image
+    arr = img_chw.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
+    Image.fromarray(arr).save(path)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log_dir", type=str, required=True)
+    ap.add_argument("--batchsize", type=int, default=100)
+    ap.add_argument("-n", "--n_generate", type=int, default=50000)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--epoch", type=str, default="best")
+    ap.add_argument("-save", "--save_images", type=bool, default=True)
+    ap.add_argument("--guidance_scale", type=float, default=None)
+    ap.add_argument("--stat", type=str, default=None)
+    ap.add_argument("--skip_fid", action="store_true")
+    ap.add_argument("--synthetic", type=str, default=None, help="builtin config name, e.g. cifar10_T10 (random weights)")
+    args, unknown = ap.parse_known_args()
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(device)
+    seed = args.seed
+    torch.manual_seed(seed + local_rank)
+    np.random.seed(seed + local_rank)
+    torch.cuda.manual_seed_all(seed + local_rank)
+    random.seed(seed + local_rank)
+    assert args.n_generate % args.batchsize == 0, "n_generate must be a multiple of batchsize"
+    if args.guidance_scale is not None:
+        raise NotImplementedError("value-guided sampling (--guidance_scale) is a 'next' row (SURVEY 8f rank 3)")
+
+    if args.synthetic:
+        import configs_builtin
+        run_config = configs_builtin.get(args.synthetic)
+    else:
+        config_path = os.path.join(args.log_dir, "config.yaml")
+        if not os.path.exists(config_path):
+            raise ValueError(f"Config not found at {config_path}")
+        run_config = dxmi_config.load(config_path)
+    output_path = os.path.join(args.log_dir, "generated")
+    mkdir_p(output_path)
+
+    net = dxmi_config.instantiate(run_config.sampler_net)
+    sampler = dxmi_config.instantiate(run_config.sampler, net=net).to(device)
+    if not args.synthetic:
+        sampler_path = os.path.join(args.log_dir, f"sampler_{args.epoch}.pth")
+        if not os.path.exists(sampler_path) and os.path.exists(os.path.join(args.log_dir, "sampler.pth")):
+            sampler_path = os.path.join(args.log_dir, "sampler.pth")
+        if not os.path.exists(sampler_path):
+            raise ValueError(f"Sampler not found at {sampler_path}")
+        ckpt = torch.load(sampler_path, map_location=device)
+        sampler.net.load_state_dict(ckpt["state_dict"])
+        print0(f"Loaded sampler from {sampler_path} (epoch {ckpt.get('epoch')}, FID {ckpt.get('fid')})")
+    sampler.eval()
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl", init_method="env://")  # RCCL; only the final barrier uses it
+
+    n_batches = int(args.n_generate / args.batchsize / world)
+    i_img = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_batches):
+        with torch.no_grad():
+            d_sample = sampler.sample(args.batchsize, device=device)
+        # one device->host copy per batch, already quantisation-ready
+        sample = rescale(d_sample["sample"]).clamp(0, 1).cpu()
+        if args.save_images:
+            for s in sample:
+                save_png(s, os.path.join(output_path, f"{local_rank}_{i_img}.png"))
+                i_img += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        torch.distributed.barrier()
+    print0(f"Generated {args.n_generate} samples at {output_path} "
+           f"({n_batches * args.batchsize / dt:.1f} images/s/rank incl. PNG writing)")
+
+    data_path = os.path.join("datasets", f"{run_config.data.name}_train_png")
+    if args.skip_fid or local_rank != 0:
+        return
+    try:
+        from pytorch_fid.fid_score import calculate_fid_given_paths
+    except ImportError:
+        print0("pytorch_fid not installed: FID skipped (quality evaluation is outside the accelerated path)")
+        return
+    if not os.path.exists(data_path):
+        print0(f"Dataset not found at {data_path}: FID skipped")
+        return
+    fid = calculate_fid_given_paths([output_path, data_path], batch_size=args.batchsize, device=device, dims=2048)
+    print(f"FID score: {fid}")
+
+
+if __name__ == "__main__":
+    main()

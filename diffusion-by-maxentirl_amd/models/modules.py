@@ -77,6 +77,7 @@ class IGEBMEncoderV2(nn.Module):
         if learn_out_scale:
             self.out_scale = nn.Linear(1, 1, bias=True)
         self._packed, self._packed_key = None, None
+        self._packed_t, self._packed_t_key = None, None
 
     # ---- bf16 weight fragments, rebuilt when a parameter's version changes
     def packed(self):
@@ -90,6 +91,19 @@ class IGEBMEncoderV2(nn.Module):
                     pk[i, "skip"] = ops.pack_conv_weight(b.skip[0].weight)
             self._packed, self._packed_key = pk, key
         return self._packed
+
+    def packed_transposed(self):
+        """Transpose-flipped fragments: the data-gradient operators of the block convs."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed_t is None or key != self._packed_t_key:
+            pk = {}
+            for i, b in enumerate(self.blocks):
+                pk[i, "conv1"] = ops.pack_conv_weight(b.conv1.weight, transpose_flip=True)
+                pk[i, "conv2"] = ops.pack_conv_weight(b.conv2.weight, transpose_flip=True)
+                if b.skip is not None:
+                    pk[i, "skip"] = ops.pack_conv_weight(b.skip[0].weight, transpose_flip=True)
+            self._packed_t, self._packed_t_key = pk, key
+        return self._packed_t
 
     def forward(self, input, y=None):
         if not input.is_cuda:

@@ -1,0 +1,107 @@
+"""Autograd path of IGEBMEncoderV2 on the gfx950 kernels (training: models/DxMI/trainer.py:244-326
+back-propagates into the value parameters, :369-387 into the input `next_state`).
+
+One torch.autograd.Function wraps the whole network: forward runs the same fused HIP program as
+inference and keeps the (bf16 NHWC) activations; backward walks the blocks in reverse with
+  * data gradients  = the forward MFMA conv kernel on transpose-flipped weight fragments, with the
+    LeakyReLU derivative (mask of the saved activation) and the skip-path gradient fused into its
+    epilogue,
+  * weight gradients = the MFMA pixel-GEMM (dxmi_conv2d_wgrad), bias gradients = column sums,
+  * avg-pool / LeakyReLU / head backward = small fused elementwise kernels.
+Parameter gradients come back as fp32 tensors in the reference's parameter order, so optimizers,
+clip_grad_norm_ and DDP-style flat-gradient all-reduce see ordinary `.grad`s.
+"""
+import torch
+
+from dxmi_hip import ops
+
+SLOPE = 0.2
+
+
+class _ValueNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        pk = net.packed()
+        x = x.contiguous().float()
+        k27 = pk["conv1"].k27
+        x_nhwc = None if k27 else ops.nchw_f32_to_nhwc_bf16(x)
+        a0 = ops.conv2d(x if k27 else x_nhwc, pk["conv1"], bias=net.conv1.bias, act=ops.ACT_LEAKY02)
+        saved = []  # per block: (inp, h1, out, c2_or_None)
+        inp = a0
+        for i, b in enumerate(net.blocks):
+            h1 = ops.conv2d(inp, pk[i, "conv1"], bias=b.conv1.bias, act=ops.ACT_LEAKY02)
+            skip = ops.conv2d(inp, pk[i, "skip"]) if b.skip is not None else inp
+            if b.downsample:
+                c2 = ops.conv2d(h1, pk[i, "conv2"], bias=b.conv2.bias, residual=skip)
+                out = ops.pool_act(c2, True, ops.ACT_LEAKY02)
+            else:
+                out = ops.conv2d(h1, pk[i, "conv2"], bias=b.conv2.bias, residual=skip, act=ops.ACT_LEAKY02)
+            saved.append((inp, h1, out))
+            inp = out
+        ow, ob = (net.out_scale.weight, net.out_scale.bias) if net.learn_out_scale else (None, None)
+        res = ops.value_head(inp, net.linear.weight, net.linear.bias, ow, ob)
+        ctx.net, ctx.saved, ctx.a0, ctx.x, ctx.x_nhwc = net, saved, a0, x, x_nhwc
+        ctx.need_dx = x.requires_grad or ctx.needs_input_grad[1]
+        return res
+
+    @staticmethod
+    def backward(ctx, dres):
+        net, saved, a0 = ctx.net, ctx.saved, ctx.a0
+        pk_t = net.packed_transposed()
+        grads = {}
+        feat = saved[-1][2]
+        N = feat.shape[0]
+        dy = dres.reshape(N).float().contiguous()
+        # ---- head: y = s @ w + b ; out = y * ow + ob
+        w = net.linear.weight.reshape(-1)
+        if net.learn_out_scale:
+            ow = net.out_scale.weight.reshape(())
+            dy_pre = dy * ow
+        else:
+            dy_pre = dy
+        dfeat, s = ops.value_head_bwd(feat, w.contiguous(), dy_pre.contiguous())
+        grads[net.linear.weight] = (dy_pre[:, None] * s).sum(0, keepdim=True)
+        grads[net.linear.bias] = dy_pre.sum().reshape(1)
+        if net.learn_out_scale:
+            y_pre = s @ w + net.linear.bias
+            grads[net.out_scale.weight] = (dy * y_pre).sum().reshape(1, 1)
+            grads[net.out_scale.bias] = dy.sum().reshape(1)
+        # dfeat is the gradient w.r.t. the last block's OUTPUT (post LeakyReLU)
+        g_out = dfeat
+        for i in reversed(range(len(net.blocks))):
+            b = net.blocks[i]
+            inp, h1, out = saved[i]
+            # gradient w.r.t. conv2 output + skip (before pool / LeakyReLU)
+            d_c2 = ops.pool_act_bwd(g_out, out, b.downsample, SLOPE)
+            grads[b.conv2.weight] = ops.conv2d_wgrad(h1, d_c2, 3)
+            grads[b.conv2.bias] = ops.colsum(d_c2)
+            d_h1 = ops.conv2d(d_c2, pk_t[i, "conv2"], mask_src=h1, mask_slope=SLOPE)  # * LeakyReLU'(h1)
+            grads[b.conv1.weight] = ops.conv2d_wgrad(inp, d_h1, 3)
+            grads[b.conv1.bias] = ops.colsum(d_h1)
+            if b.skip is not None:
+                grads[b.skip[0].weight] = ops.conv2d_wgrad(inp, d_c2, 1)
+                d_skip = ops.conv2d(d_c2, pk_t[i, "skip"])
+            else:
+                d_skip = d_c2
+            # gradient w.r.t. the block input = previous block's output (post LeakyReLU)
+            g_out = ops.conv2d(d_h1, pk_t[i, "conv1"], residual=d_skip)
+        # ---- stem conv: a0 = LeakyReLU(conv1(x))
+        d_a0 = ops.pool_act_bwd(g_out, a0, False, SLOPE)
+        x_nhwc = ctx.x_nhwc if ctx.x_nhwc is not None else ops.nchw_f32_to_nhwc_bf16(ctx.x)
+        grads[net.conv1.bias] = ops.colsum(d_a0)
+        # 3-channel image conv: K = 27 weight gradient and the input gradient are tiny GEMMs; torch ops on
+        # the bf16 tensors (0.2 % of the network's FLOPs)
+        d_a0_nchw = d_a0.permute(0, 3, 1, 2).float()
+        x32 = x_nhwc.permute(0, 3, 1, 2).float()
+        grads[net.conv1.weight] = torch.nn.grad.conv2d_weight(x32, net.conv1.weight.shape, d_a0_nchw, padding=1)
+        dx = None
+        if ctx.need_dx:
+            dx = torch.nn.grad.conv2d_input(x32.shape, net.conv1.weight.to(torch.bfloat16).float(), d_a0_nchw, padding=1)
+        out = [None, dx]
+        for prm in net.parameters():
+            out.append(grads.get(prm))
+        return tuple(out)
+
+
+def forward_with_grad(net, x):
+    return _ValueNetFn.apply(net, x, *list(net.parameters()))

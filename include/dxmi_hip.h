@@ -77,6 +77,9 @@ typedef struct dxmi_conv_desc {
     int32_t in_mode;         /* DXMI_IN_*  */
     int32_t out_mode;        /* DXMI_OUT_* */
     int32_t variant;         /* 0 = default tiling; >0 selects an alternative (tuning / tests) */
+    const void*  mask_src;   /* backward use: NHWC bf16 tensor shaped like out; result *= (mask_src > 0 ? 1 : mask_slope)
+                                after bias/residual, i.e. the LeakyReLU/ReLU derivative of a saved activation; or NULL */
+    float        mask_slope;
 } dxmi_conv_desc;
 
 int dxmi_conv2d_fwd(const dxmi_conv_desc* d, void* stream);
@@ -90,6 +93,37 @@ int dxmi_conv2d_kernel_id(const dxmi_conv_desc* d);
 int64_t dxmi_packed_conv_weight_bytes(int32_t Cout, int32_t Cin, int32_t ksize, int32_t k27);
 int dxmi_pack_conv_weight(const float* w_oihw, void* dst, int32_t Cout, int32_t Cin,
                           int32_t ksize, int32_t transpose_flip, int32_t k27, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backward of the convolutions (training path: models/DxMI/trainer.py:261,322,387 call
+ * .backward() through the value network and the U-Net).
+ *  - data gradient: dxmi_conv2d_fwd with weights packed by dxmi_pack_conv_weight(transpose_flip=1)
+ *    (stride-1 convs; mask_src/mask_slope fuse the activation derivative, residual fuses the
+ *    skip-path gradient).
+ *  - weight gradient: dxmi_conv2d_wgrad: dW[co][ci][ky][kx] = sum_p dY[p][co] X[p+tap][ci] as an MFMA
+ *    GEMM over the pixel index (ds_read_b64_tr_b16 transposed fragments, split-K over pixel tiles,
+ *    fixed-order reduction).  x0|x1: forward input (virtual concat), dy: output gradient, both NHWC
+ *    bf16; dw_oihw fp32 [Cout,Cin,k,k]; accumulate != 0 adds into dw_oihw.
+ *  - bias gradient: dxmi_colsum_bf16 over dy viewed as [P, C].
+ * ---------------------------------------------------------------------------------------- */
+int64_t dxmi_conv2d_wgrad_workspace_bytes(int32_t N, int32_t OH, int32_t OW, int32_t Cin, int32_t Cout,
+                                          int32_t ksize);
+int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int32_t C1, const void* dy,
+                      float* dw_oihw, void* workspace, int32_t N, int32_t IH, int32_t IW, int32_t OH,
+                      int32_t OW, int32_t Cout, int32_t ksize, int32_t pad, int32_t upsample,
+                      int32_t accumulate, void* stream);
+/* workspace: ceil(P/512) * C floats */
+int dxmi_colsum_bf16(const void* x, float* out, void* workspace, int64_t P, int32_t C,
+                     int32_t accumulate, void* stream);
+/* Backward of dxmi_pool_act: din = (pool ? 0.25 * upsample2(g) : g), g = dout * (act_out > 0 ? 1 : slope);
+ * dout/act_out: [N,OH,OW,C], din: [N,H,W,C] (H = 2*OH when pool). */
+int dxmi_pool_act_bwd(const void* dout, const void* act_out, void* din, int32_t N, int32_t H, int32_t W,
+                      int32_t C, int32_t pool, float slope, void* stream);
+/* Backward of the value head w.r.t. its feature map: dfeat[n,p,c] = dy[n] * w[c] * (feat > 0); also
+ * returns s[n,c] = sum_p relu(feat[n,p,c]) (fp32) from which the caller forms the tiny parameter
+ * gradients. */
+int dxmi_value_head_bwd(const void* feat, const float* w, const float* dy, void* dfeat, float* s,
+                        int32_t N, int32_t HW, int32_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU) over NHWC bf16, optionally over a virtual concat of two
