@@ -83,8 +83,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs p) {
         const int iy = oy0 * S - p.pad + hy;
         const int ix = ox0 * S - p.pad + hx;
         const int n = n0 + sub;
-        const bool ok = (iy >= 0) && (ix >= 0) && (iy < (p.IH << p.ups)) && (ix < (p.IW << p.ups)) && (n < p.N);
-        return ok ? ((n * p.IH + (iy >> p.ups)) * p.IW + (ix >> p.ups)) : -1;
+        const int sh = p.ups ? 1 : 0;  // ups 1: nearest x2 ; ups 2: zero-stuffed x2 (stride-2 data gradient)
+        const bool ok = (iy >= 0) && (ix >= 0) && (iy < (p.IH << sh)) && (ix < (p.IW << sh)) && (n < p.N) &&
+                        (p.ups != 2 || (((iy | ix) & 1) == 0));
+        return ok ? ((n * p.IH + (iy >> sh)) * p.IW + (ix >> sh)) : -1;
     };
     int srcpix[PMAX > 0 ? PMAX : 1];
     if (PMAX > 0 && p.in_mode == DXMI_IN_NHWC_BF16) {
@@ -359,6 +361,7 @@ static int conv2d_impl(const dxmi_conv_desc* d, void* stream, int* kernel_id) {
     } else {
         DXMI_CHECK_ARG(Cin % 32 == 0 && d->C0 % 32 == 0, "dxmi_conv2d_fwd: Cin (%d+%d) must be a multiple of 32", d->C0, d->C1);
         DXMI_CHECK_ARG(d->C1 == 0 || d->in1, "dxmi_conv2d_fwd: C1>0 but in1 is NULL");
+        DXMI_CHECK_ARG(d->upsample >= 0 && d->upsample <= 2, "dxmi_conv2d_fwd: upsample must be 0, 1 (nearest) or 2 (zero-stuffed)");
         const int VIH = d->IH << (d->upsample ? 1 : 0), VIW = d->IW << (d->upsample ? 1 : 0);
         DXMI_CHECK_ARG((d->OH - 1) * d->stride - d->pad < VIH && (d->OW - 1) * d->stride - d->pad < VIW && d->pad >= 0 && d->pad < d->ksize,
                        "dxmi_conv2d_fwd: output %dx%d inconsistent with input %dx%d", d->OH, d->OW, VIH, VIW);
@@ -372,7 +375,7 @@ static int conv2d_impl(const dxmi_conv_desc* d, void* stream, int* kernel_id) {
     a.bias = d->bias; a.addvec = d->addvec; a.residual = (const bf16*)d->residual; a.out = d->out;
     a.mask_src = (const bf16*)d->mask_src; a.mask_slope = d->mask_slope;
     a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.C0 = d->C0; a.C1 = d->C1; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
-    a.ksize = d->ksize; a.stride = d->stride; a.pad = d->pad; a.ups = d->upsample ? 1 : 0; a.act = d->act;
+    a.ksize = d->ksize; a.stride = d->stride; a.pad = d->pad; a.ups = d->upsample; a.act = d->act;
     a.addvec_ld = d->addvec_ld; a.in_mode = d->in_mode; a.out_mode = d->out_mode; a.P = 0; a.pre_act = 0;
     const int TW = d->OW < 32 ? d->OW : 32;
     int TH = 256 / TW; if (TH > d->OH) TH = d->OH;

@@ -170,8 +170,10 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
             const int n = n0 + (gq >> 20);
             const int iy = oy0 - p.pad + ((gq >> 10) & 1023);
             const int ix = ox0 - p.pad + (gq & 1023);
-            const bool ok = gq >= 0 && iy >= 0 && ix >= 0 && iy < (p.IH << p.ups) && ix < (p.IW << p.ups) && n < p.N;
-            sp[q] = ok ? (n * p.IH + (iy >> p.ups)) * p.IW + (ix >> p.ups) : -1;
+            const int sh = p.ups ? 1 : 0;  // ups 1: nearest x2 ; ups 2: zero-stuffed x2 (stride-2 data gradient)
+            const bool ok = gq >= 0 && iy >= 0 && ix >= 0 && iy < (p.IH << sh) && ix < (p.IW << sh) && n < p.N &&
+                            (p.ups != 2 || (((iy | ix) & 1) == 0));
+            sp[q] = ok ? (n * p.IH + (iy >> sh)) * p.IW + (ix >> sh) : -1;
         }
     };
 

@@ -30,7 +30,7 @@ struct WgradArgs {
     const bf16* dy;      // output gradient, NHWC [N,OH,OW,Cout]
     float* partial;      // [S][taps][Cout][Cin] fp32
     int N, IH, IW, C0, C1, OH, OW, Cout;
-    int ksize, pad, ups;
+    int ksize, pad, ups, stride;
     int TWl, THl, SUBS, HH, HWd;  // 128-pixel tile geometry + halo
     int PT, S;                    // pixel tiles, pixel splits
     int CIB, COB;                 // 64-wide ci / co blocks
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             const int hp = i >> 3, pc = i & 7;
             const int sub = hp / HHW, rem = hp - sub * HHW;
             const int hy = rem / p.HWd, hx = rem - hy * p.HWd;
-            const int iy = oy0 - p.pad + hy, ix = ox0 - p.pad + hx, n = n0 + sub;
+            const int iy = oy0 * p.stride - p.pad + hy, ix = ox0 * p.stride - p.pad + hx, n = n0 + sub;
             bf16x8 v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             // halo offsets of the two pixel rows this lane addresses
             const int xl = plo & (TW - 1), yl = (plo >> p.TWl) & (TH - 1), sl = plo >> (p.TWl + p.THl);
             const int xh = phi & (TW - 1), yh = (phi >> p.TWl) & (TH - 1), sh = phi >> (p.TWl + p.THl);
-            const char* bl = xim + ((sl * p.HH + yl) * p.HWd + xl) * WG_PITCH + wc * 64 + ch_off;
-            const char* bh = xim + ((sh * p.HH + yh) * p.HWd + xh) * WG_PITCH + wc * 64 + ch_off;
+            const char* bl = xim + ((sl * p.HH + yl * p.stride) * p.HWd + xl * p.stride) * WG_PITCH + wc * 64 + ch_off;
+            const char* bh = xim + ((sh * p.HH + yh * p.stride) * p.HWd + xh * p.stride) * WG_PITCH + wc * 64 + ch_off;
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
                 const int toff = ((t / KS) * p.HWd + (t % KS)) * WG_PITCH;
@@ -168,15 +168,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restr
                                                             int C, int rows_per_block) {
     // thread t handles 8-channel piece (t % (C/8)); rows strided by 256/(C/8)
     const int c8n = C / 8;
-    const int pc = threadIdx.x % c8n, r0 = threadIdx.x / c8n, rstep = 256 / c8n;
+    const int pc = threadIdx.x % c8n, r0 = threadIdx.x / c8n, rstep = blockDim.x / c8n;  // blockDim.x = rstep * c8n
     const long base = (long)blockIdx.x * rows_per_block;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (r0 < rstep)
-        for (long r = base + r0; r < base + rows_per_block && r < P; r += rstep) {
+    for (long r = base + r0; r < base + rows_per_block && r < P; r += rstep) {
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * C + pc * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
-        }
+    }
     __shared__ float red[256][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
@@ -216,7 +215,8 @@ extern "C" int64_t dxmi_conv2d_wgrad_workspace_bytes(int32_t N, int32_t OH, int3
 
 extern "C" int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int32_t C1, const void* dy, float* dw_oihw,
                                  void* workspace, int32_t N, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t Cout,
-                                 int32_t ksize, int32_t pad, int32_t upsample, int32_t accumulate, void* stream) {
+                                 int32_t ksize, int32_t stride, int32_t pad, int32_t upsample, int32_t accumulate, void* stream) {
+    DXMI_CHECK_ARG(stride == 1 || stride == 2, "dxmi_conv2d_wgrad: stride %d unsupported", stride);
     DXMI_CHECK_ARG(x0 && dy && dw_oihw && workspace, "dxmi_conv2d_wgrad: null pointer");
     const int Cin = C0 + C1;
     DXMI_CHECK_ARG(ksize == 1 || ksize == 3, "dxmi_conv2d_wgrad: ksize %d unsupported", ksize);
@@ -226,11 +226,11 @@ extern "C" int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int
     WgradArgs a;
     a.x0 = (const bf16*)x0; a.x1 = (const bf16*)x1; a.dy = (const bf16*)dy; a.partial = (float*)workspace;
     a.N = N; a.IH = IH; a.IW = IW; a.C0 = C0; a.C1 = C1; a.OH = OH; a.OW = OW; a.Cout = Cout;
-    a.ksize = ksize; a.pad = pad; a.ups = upsample ? 1 : 0;
+    a.ksize = ksize; a.pad = pad; a.ups = upsample ? 1 : 0; a.stride = stride;
     const int TW = OW < 32 ? OW : 32;
     int TH = 128 / TW; if (TH > OH) TH = OH;
     a.TWl = ilog2w(TW); a.THl = ilog2w(TH); a.SUBS = 128 / (TW * TH);
-    a.HH = TH + ksize - 1; a.HWd = TW + ksize - 1;
+    a.HH = (TH - 1) * stride + ksize; a.HWd = (TW - 1) * stride + ksize;
     const int ngroups = (N + a.SUBS - 1) / a.SUBS;
     a.PT = ngroups * (OH / TH) * (OW / TW);
     a.CIB = Cin / 64; a.COB = Cout / 64;
@@ -262,15 +262,29 @@ extern "C" int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int
 extern "C" int dxmi_colsum_bf16(const void* x, float* out, void* workspace, int64_t P, int32_t C, int32_t accumulate,
                                 void* stream) {
     DXMI_CHECK_ARG(x && out && workspace, "dxmi_colsum_bf16: null pointer");
-    DXMI_CHECK_ARG(C % 8 == 0 && C / 8 <= 256 && 256 % (C / 8) == 0, "dxmi_colsum_bf16: C=%d unsupported", C);
+    DXMI_CHECK_ARG(C % 8 == 0 && C / 8 <= 256, "dxmi_colsum_bf16: C=%d unsupported", C);
+    const int cthreads = (256 / (C / 8)) * (C / 8);
     const int rows_per_block = 512;
     const int nblocks = (int)((P + rows_per_block - 1) / rows_per_block);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks), dim3(256), 0, st, (const bf16*)x, (float*)workspace, (long)P, C,
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks), dim3(cthreads), 0, st, (const bf16*)x, (float*)workspace, (long)P, C,
                        rows_per_block);
     DXMI_CHECK_LAUNCH("dxmi_colsum_bf16");
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, out, nblocks, C,
                        accumulate);
     DXMI_CHECK_LAUNCH("dxmi_colsum_bf16(final)");
+    return DXMI_OK;
+}
+
+// out[b][c] = sum over the b-th block of `rows_per_block` rows of x[P][C] (per-image sums: the gradient of
+// the per-(n, channel) temb term, unet_small.py:123).
+extern "C" int dxmi_colsum_blocks_bf16(const void* x, float* out, int64_t P, int32_t C, int32_t rows_per_block, void* stream) {
+    DXMI_CHECK_ARG(x && out && rows_per_block > 0, "dxmi_colsum_blocks_bf16: bad arguments");
+    DXMI_CHECK_ARG(C % 8 == 0 && C / 8 <= 256, "dxmi_colsum_blocks_bf16: C=%d unsupported", C);
+    const int cthreads = (256 / (C / 8)) * (C / 8);
+    const int nblocks = (int)((P + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks), dim3(cthreads), 0, (hipStream_t)stream, (const bf16*)x, out, (long)P, C,
+                       rows_per_block);
+    DXMI_CHECK_LAUNCH("dxmi_colsum_blocks_bf16");
     return DXMI_OK;
 }

@@ -160,6 +160,201 @@ __global__ __launch_bounds__(512) void gn_silu_kernel(GnArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward of GroupNorm(+SiLU): given x (virtual concat), the upstream gradient dy w.r.t. the
+// kernel's output, gamma/beta -> dx (split back into the two concat sources, optional additive
+// inputs fused: skip-connection / residual gradients) and per-image partial d(gamma), d(beta).
+// Same one-pass structure as the forward: x and dy slices stay resident as raw bf16, statistics are
+// recomputed (two-pass) instead of being stored by the forward.
+//   xh = (x-mean)*rstd ; y = xh*g + b ; z = silu(y) | y
+//   dyy = dy * silu'(y) ; dg += dyy*xh ; db += dyy ; dxh = dyy*g
+//   dx = rstd * (dxh - mean_grp(dxh) - xh * mean_grp(dxh*xh))
+struct GnBwdArgs {
+    const bf16* in0;
+    const bf16* in1;
+    const bf16* dy;      // [N,HW,C0+C1]
+    const bf16* add0;    // optional, added to dx0
+    const bf16* add1;    // optional, added to dx1
+    const float* gamma;
+    const float* beta;
+    bf16* dx0;
+    bf16* dx1;
+    float* dgamma_part;  // [N][C]
+    float* dbeta_part;   // [N][C]
+    int C0, C1, HW, groups, slices, ppp, cpg, gps;
+    float eps;
+    int silu;
+    int fast;
+};
+
+template <int VEC, int PIECES>
+__global__ __launch_bounds__(512) void gn_silu_bwd_kernel(GnBwdArgs p) {
+    typedef typename PieceT<VEC>::type piece_t;
+    constexpr int W = VEC / 2;
+    __shared__ float red[512 / 64][32];
+    __shared__ float stat[32];
+    extern __shared__ __attribute__((aligned(16))) char dyn[];  // [nthr][2*VEC] floats for the channel sums
+    float* chan = reinterpret_cast<float*>(dyn);
+
+    const int C = p.C0 + p.C1;
+    const int n = blockIdx.x / p.slices;
+    const int s = blockIdx.x % p.slices;
+    const int Csl = C / p.slices;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthr >> 6;
+    const int pc = tid % p.ppp;
+    const int prow = tid / p.ppp;
+    const int rows_per_iter = nthr / p.ppp;
+    const int c = s * Csl + pc * VEC;
+    const int gl = (pc * VEC) / p.cpg;
+    const bool from0 = c < p.C0;
+    const bf16* src = from0 ? p.in0 : p.in1;
+    const int Cs = from0 ? p.C0 : p.C1;
+    const int cs = from0 ? c : c - p.C0;
+
+    uint32_t xv[PIECES][W], gv[PIECES][W];
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        const int px = prow + q * rows_per_iter;
+#pragma unroll
+        for (int e = 0; e < W; ++e) { xv[q][e] = 0u; gv[q][e] = 0u; }
+        if (px < p.HW) {
+            const piece_t t = *reinterpret_cast<const piece_t*>(src + ((size_t)n * p.HW + px) * Cs + cs);
+            const piece_t u = *reinterpret_cast<const piece_t*>(p.dy + ((size_t)n * p.HW + px) * C + c);
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                xv[q][e] = reinterpret_cast<const uint32_t*>(&t)[e];
+                gv[q][e] = reinterpret_cast<const uint32_t*>(&u)[e];
+            }
+        }
+    }
+    const int ppt = p.cpg / VEC;
+    auto group_reduce = [&](float val) -> float {
+        if (p.fast) {
+            float t = val;
+            for (int o = 32; o >= p.ppp; o >>= 1) t += __shfl_xor(t, o, 64);
+            for (int o = ppt >> 1; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+            if (lane < p.ppp && (lane % ppt) == 0) red[wave][gl] = t;
+        } else {
+            for (int g = 0; g < p.gps; ++g) {
+                float t = wave_sum(gl == g ? val : 0.f);
+                if (lane == 0) red[wave][g] = t;
+            }
+        }
+        __syncthreads();
+        if (tid < p.gps) {
+            float t = 0.f;
+            for (int w = 0; w < nwaves; ++w) t += red[w][tid];
+            stat[tid] = t;
+        }
+        __syncthreads();
+        const float r = stat[gl];
+        __syncthreads();
+        return r;
+    };
+    const float inv_cnt = 1.f / (float)(p.HW * p.cpg);
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q)
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            asm volatile("" : "+v"(xv[q][e]));
+            sum += GN_LO(xv[q][e]) + GN_HI(xv[q][e]);
+        }
+    const float mean = group_reduce(sum) * inv_cnt;
+    float ssq = 0.f;
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        const int px = prow + q * rows_per_iter;
+        if (px < p.HW) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                asm volatile("" : "+v"(xv[q][e]));
+                const float d0 = GN_LO(xv[q][e]) - mean, d1 = GN_HI(xv[q][e]) - mean;
+                ssq += d0 * d0 + d1 * d1;
+            }
+        }
+    }
+    const float rstd = rsqrtf(group_reduce(ssq) * inv_cnt + p.eps);
+
+    float ga[VEC], be[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { ga[e] = p.gamma[c + e]; be[e] = p.beta[c + e]; }
+
+    // pass A: channel sums (dgamma, dbeta) and the two group sums; dyy is recomputed in pass B
+    auto dyy_of = [&](float xh, float g, float gam, float bet) -> float {
+        if (!p.silu) return g;
+        const float y = xh * gam + bet;
+        const float sg = 1.f / (1.f + __expf(-y));
+        return g * (sg * (1.f + y * (1.f - sg)));
+    };
+    float dgs[VEC], dbs[VEC], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { dgs[e] = 0.f; dbs[e] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        const int px = prow + q * rows_per_iter;
+        if (px < p.HW) {
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                asm volatile("" : "+v"(xv[q][e]));
+                asm volatile("" : "+v"(gv[q][e]));
+                const float xh0 = (GN_LO(xv[q][e]) - mean) * rstd, xh1 = (GN_HI(xv[q][e]) - mean) * rstd;
+                const float a0 = dyy_of(xh0, GN_LO(gv[q][e]), ga[2 * e], be[2 * e]);
+                const float a1 = dyy_of(xh1, GN_HI(gv[q][e]), ga[2 * e + 1], be[2 * e + 1]);
+                dgs[2 * e] += a0 * xh0; dgs[2 * e + 1] += a1 * xh1;
+                dbs[2 * e] += a0; dbs[2 * e + 1] += a1;
+                const float h0 = a0 * ga[2 * e], h1 = a1 * ga[2 * e + 1];
+                s1 += h0 + h1;
+                s2 += h0 * xh0 + h1 * xh1;
+            }
+        }
+    }
+    const float m1 = group_reduce(s1) * inv_cnt;
+    const float m2 = group_reduce(s2) * inv_cnt;
+
+    // channel sums across the threads that share this channel piece (fixed order)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { chan[tid * 2 * VEC + e] = dgs[e]; chan[tid * 2 * VEC + VEC + e] = dbs[e]; }
+    __syncthreads();
+    if (tid < p.ppp) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float tg = 0.f, tb = 0.f;
+            for (int k = tid; k < nthr; k += p.ppp) { tg += chan[k * 2 * VEC + e]; tb += chan[k * 2 * VEC + VEC + e]; }
+            p.dgamma_part[(size_t)n * C + c + e] = tg;
+            p.dbeta_part[(size_t)n * C + c + e] = tb;
+        }
+    }
+
+    // pass B: dx
+    bf16* dst = from0 ? p.dx0 : p.dx1;
+    const bf16* add = from0 ? p.add0 : p.add1;
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+        const int px = prow + q * rows_per_iter;
+        if (px < p.HW) {
+            const size_t o = ((size_t)n * p.HW + px) * Cs + cs;
+            piece_t av;
+            if (add) av = *reinterpret_cast<const piece_t*>(add + o);
+            piece_t ov;
+#pragma unroll
+            for (int e = 0; e < W; ++e) {
+                asm volatile("" : "+v"(xv[q][e]));
+                asm volatile("" : "+v"(gv[q][e]));
+                const float xh0 = (GN_LO(xv[q][e]) - mean) * rstd, xh1 = (GN_HI(xv[q][e]) - mean) * rstd;
+                const float h0 = dyy_of(xh0, GN_LO(gv[q][e]), ga[2 * e], be[2 * e]) * ga[2 * e];
+                const float h1 = dyy_of(xh1, GN_HI(gv[q][e]), ga[2 * e + 1], be[2 * e + 1]) * ga[2 * e + 1];
+                float r0 = rstd * (h0 - m1 - xh0 * m2), r1 = rstd * (h1 - m1 - xh1 * m2);
+                if (add) { r0 += (float)av[2 * e]; r1 += (float)av[2 * e + 1]; }
+                ov[2 * e] = (bf16)r0;
+                ov[2 * e + 1] = (bf16)r1;
+            }
+            *reinterpret_cast<piece_t*>(dst + o) = ov;
+        }
+    }
+}
+
 int gcd(int a, int b) { return b ? gcd(b, a % b) : a; }
 
 template <int VEC>
@@ -178,6 +373,70 @@ int launch_gn(const GnArgs& a, int N, int pieces, int threads, hipStream_t st) {
 }
 
 }  // namespace
+
+template <int VEC>
+int launch_gn_bwd(const GnBwdArgs& a, int N, int pieces, int threads, hipStream_t st) {
+    dim3 grid(N * a.slices), block(threads);
+    const size_t dyn = (size_t)threads * 2 * VEC * sizeof(float);
+#define GNB_CASE(P)                                                                     \
+    if (pieces <= P) {                                                                  \
+        hipLaunchKernelGGL((gn_silu_bwd_kernel<VEC, P>), grid, block, dyn, st, a);      \
+        DXMI_CHECK_LAUNCH("dxmi_groupnorm_silu_bwd");                                   \
+        return DXMI_OK;                                                                 \
+    }
+    GNB_CASE(1) GNB_CASE(2) GNB_CASE(4) GNB_CASE(8) GNB_CASE(12) GNB_CASE(16)
+#undef GNB_CASE
+    dxmi_set_error("dxmi_groupnorm_silu_bwd: %d pieces per thread unsupported", pieces);
+    return DXMI_EINVAL;
+}
+
+// shared slicing rule: whole groups per slice, <= max_pieces pieces per thread at <= 512 threads
+static int gn_plan(int C, int C0, int HW, int groups, int max8, int max4, int* VEC_, int* slices_, int* threads_,
+                   int* pieces_, int* ppp_) {
+    const int cpg = C / groups;
+    const int VEC = (cpg % 8 == 0 && C0 % 8 == 0) ? 8 : 4;
+    const int max_pieces = VEC == 8 ? max8 : max4;
+    int slices = 1, threads = 0, pieces = 0, ppp = 0;
+    for (;; slices *= 2) {
+        if (groups % slices != 0) return -1;
+        const int Csl = C / slices;
+        ppp = Csl / VEC;
+        const int unit = ppp / gcd(ppp, 64) * 64;
+        if (unit > 512) return -2;
+        long total = (long)HW * ppp;
+        threads = (512 / unit) * unit;
+        if (total < threads) threads = (int)((total + unit - 1) / unit) * unit;
+        pieces = (int)((total + threads - 1) / threads);
+        if (pieces <= max_pieces || slices == groups) break;
+    }
+    *VEC_ = VEC; *slices_ = slices; *threads_ = threads; *pieces_ = pieces; *ppp_ = ppp;
+    return 0;
+}
+
+extern "C" int dxmi_groupnorm_silu_bwd(const void* in0, int32_t C0, const void* in1, int32_t C1, const void* dy,
+                                       const void* add0, const void* add1, const float* gamma, const float* beta, void* dx0,
+                                       void* dx1, float* dgamma_part, float* dbeta_part, int32_t N, int32_t HW,
+                                       int32_t groups, float eps, int32_t apply_silu, void* stream) {
+    DXMI_CHECK_ARG(in0 && dy && gamma && beta && dx0 && dgamma_part && dbeta_part, "dxmi_groupnorm_silu_bwd: null pointer");
+    DXMI_CHECK_ARG(C1 == 0 || (in1 && dx1), "dxmi_groupnorm_silu_bwd: C1>0 needs in1 and dx1");
+    const int C = C0 + C1;
+    DXMI_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0, "dxmi_groupnorm_silu_bwd: C=%d groups=%d", C, groups);
+    const int cpg = C / groups;
+    DXMI_CHECK_ARG(cpg % 4 == 0 && C0 % 4 == 0, "dxmi_groupnorm_silu_bwd: channels per group (%d) must be a multiple of 4", cpg);
+    int VEC, slices, threads, pieces, ppp;
+    DXMI_CHECK_ARG(gn_plan(C, C0, HW, groups, 8, 16, &VEC, &slices, &threads, &pieces, &ppp) == 0 && pieces <= 16,
+                   "dxmi_groupnorm_silu_bwd: cannot slice HW=%d C=%d", HW, C);
+    GnBwdArgs a;
+    a.in0 = (const bf16*)in0; a.in1 = (const bf16*)in1; a.dy = (const bf16*)dy; a.add0 = (const bf16*)add0;
+    a.add1 = (const bf16*)add1; a.gamma = gamma; a.beta = beta; a.dx0 = (bf16*)dx0; a.dx1 = (bf16*)dx1;
+    a.dgamma_part = dgamma_part; a.dbeta_part = dbeta_part;
+    a.C0 = C0; a.C1 = C1; a.HW = HW; a.groups = groups; a.slices = slices; a.ppp = ppp; a.cpg = cpg;
+    a.gps = groups / slices; a.eps = eps; a.silu = apply_silu;
+    const int ppt = cpg / VEC;
+    a.fast = (ppp <= 64) && ((ppp & (ppp - 1)) == 0) && ((ppt & (ppt - 1)) == 0);
+    hipStream_t st = (hipStream_t)stream;
+    return VEC == 8 ? launch_gn_bwd<8>(a, N, pieces, threads, st) : launch_gn_bwd<4>(a, N, pieces, threads, st);
+}
 
 extern "C" int dxmi_groupnorm_silu_fwd(const void* in0, int32_t C0, const void* in1, int32_t C1, const float* gamma,
                                        const float* beta, void* out, int32_t N, int32_t HW, int32_t groups, float eps,

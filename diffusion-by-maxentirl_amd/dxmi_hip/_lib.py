@@ -36,8 +36,12 @@ SIGNATURES = {
     "dxmi_packed_conv_weight_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "dxmi_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_conv2d_wgrad_workspace_bytes": (c_int64, [c_int] * 6),
-    "dxmi_conv2d_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "dxmi_conv2d_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
+    "dxmi_groupnorm_silu_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 9 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "dxmi_bgemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "dxmi_softmax_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "dxmi_colsum_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "dxmi_colsum_blocks_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "dxmi_pool_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dxmi_value_head_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dxmi_groupnorm_silu_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

@@ -170,7 +170,7 @@ def _workspace(nbytes, device):
     return buf
 
 
-def conv2d_wgrad(x, dy, ksize, *, in1=None, pad=None, upsample=False, out=None, accumulate=False):
+def conv2d_wgrad(x, dy, ksize, *, in1=None, pad=None, stride=1, upsample=False, out=None, accumulate=False):
     """Weight gradient of a stride-1 conv: x [N,IH,IW,C0] (| in1), dy [N,OH,OW,Cout] NHWC bf16 ->
     fp32 OIHW [Cout, C0+C1, k, k] (written, or added when accumulate)."""
     _need_cuda(x, in1, dy, out)
@@ -187,7 +187,7 @@ def conv2d_wgrad(x, dy, ksize, *, in1=None, pad=None, upsample=False, out=None, 
     lib = load()
     ws = _workspace(lib.dxmi_conv2d_wgrad_workspace_bytes(N, OH, OW, C0 + C1, Cout, ksize), x.device)
     check(lib.dxmi_conv2d_wgrad(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(out), _ptr(ws), N, IH, IW, OH, OW, Cout, ksize,
-                                pad, int(upsample), int(accumulate), _stream()), "dxmi_conv2d_wgrad")
+                                stride, pad, int(upsample), int(accumulate), _stream()), "dxmi_conv2d_wgrad")
     return out
 
 
@@ -202,6 +202,16 @@ def colsum(x2d, out=None, accumulate=False):
         accumulate = False
     ws = _workspace(((P + 511) // 512) * C * 4, x2d.device)
     check(load().dxmi_colsum_bf16(_ptr(x2d), _ptr(out), _ptr(ws), P, C, int(accumulate), _stream()), "dxmi_colsum_bf16")
+    return out
+
+
+def colsum_per_image(x):
+    """x [N,H,W,C] bf16 -> [N,C] fp32 sums over H*W."""
+    _need_cuda(x)
+    N, H, W, C = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    check(load().dxmi_colsum_blocks_bf16(_ptr(x), _ptr(out), N * H * W, C, H * W, _stream()), "dxmi_colsum_blocks_bf16")
     return out
 
 
@@ -226,6 +236,56 @@ def value_head_bwd(feat, w, dy):
     check(load().dxmi_value_head_bwd(_ptr(feat), _ptr(w), _ptr(dy), _ptr(dfeat), _ptr(s), N, H * W, C, _stream()),
           "dxmi_value_head_bwd")
     return dfeat, s
+
+
+def groupnorm_silu_bwd(x, dy, gamma, beta, *, in1=None, add0=None, add1=None, groups=32, eps=1e-6, silu=True):
+    """-> (dx0, dx1 or None, dgamma [C], dbeta [C])."""
+    _need_cuda(x, in1, dy, add0, add1, gamma, beta)
+    N, H, W, C0 = x.shape
+    C1 = in1.shape[3] if in1 is not None else 0
+    C = C0 + C1
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and tuple(dy.shape) == (N, H, W, C)
+    dx0 = torch.empty_like(x)
+    dx1 = torch.empty_like(in1) if in1 is not None else None
+    part = torch.empty((2, N, C), dtype=torch.float32, device=x.device)
+    check(load().dxmi_groupnorm_silu_bwd(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(add0), _ptr(add1), _ptr(gamma), _ptr(beta),
+                                         _ptr(dx0), _ptr(dx1), _ptr(part[0]), _ptr(part[1]), N, H * W, groups, float(eps),
+                                         int(silu), _stream()), "dxmi_groupnorm_silu_bwd")
+    red = part.sum(1)  # [2, C]: tiny fixed-order reduction over images
+    return dx0, dx1, red[0], red[1]
+
+
+def bgemm(A, B, C, M, N, K, a_strides, a_ld, a_kc, b_strides, b_ld, b_kc, c_strides, c_ld, alpha, outer, inner):
+    """Raw batched bf16 GEMM (see include/dxmi_hip.h); tensors are only used for their base pointers."""
+    check(load().dxmi_bgemm_bf16(_ptr(A), _ptr(B), _ptr(C), M, N, K, a_strides[0], a_strides[1], a_ld, int(a_kc), b_strides[0],
+                                 b_strides[1], b_ld, int(b_kc), c_strides[0], c_strides[1], c_ld, int(C.dtype == torch.float32),
+                                 float(alpha), outer, inner, _stream()), "dxmi_bgemm_bf16")
+    return C
+
+
+def attention_bwd(qkv, do, heads, scale):
+    """qkv [N,T,3C] ([q|k|v], heads = contiguous channel blocks), do [N,T,C] -> dqkv [N,T,3C] (bf16)."""
+    _need_cuda(qkv, do)
+    N, T, C3 = qkv.shape
+    C = C3 // 3
+    D = C // heads
+    dev = qkv.device
+    assert qkv.dtype == torch.bfloat16 and do.dtype == torch.bfloat16 and qkv.is_contiguous() and do.is_contiguous()
+    S = torch.empty((N, heads, T, T), dtype=torch.float32, device=dev)
+    dP = torch.empty_like(S)
+    P = torch.empty((N, heads, T, T), dtype=torch.bfloat16, device=dev)
+    dS = torch.empty_like(P)
+    dqkv = torch.empty_like(qkv)
+    q, k, v = qkv[:, :, 0:C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]
+    dq, dk, dv = dqkv[:, :, 0:C], dqkv[:, :, C:2 * C], dqkv[:, :, 2 * C:]
+    qs, os_, ss = (T * C3, D), (T * C, D), (heads * T * T, T * T)
+    bgemm(q, k, S, T, T, D, qs, C3, True, qs, C3, True, ss, T, scale, N, heads)          # S = scale Q K^T
+    bgemm(do, v, dP, T, T, D, os_, C, True, qs, C3, True, ss, T, 1.0, N, heads)           # dP = dO V^T
+    check(load().dxmi_softmax_bwd(_ptr(S), _ptr(dP), _ptr(P), _ptr(dS), N * heads * T, T, _stream()), "dxmi_softmax_bwd")
+    bgemm(P, do, dv, T, D, T, ss, T, False, os_, C, False, qs, C3, 1.0, N, heads)         # dV = P^T dO
+    bgemm(dS, k, dq, T, D, T, ss, T, True, qs, C3, False, qs, C3, scale, N, heads)        # dQ = scale dS K
+    bgemm(dS, q, dk, T, D, T, ss, T, False, qs, C3, False, qs, C3, scale, N, heads)       # dK = scale dS^T Q
+    return dqkv
 
 
 def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, out=None):

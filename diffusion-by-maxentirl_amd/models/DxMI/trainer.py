@@ -1,0 +1,225 @@
+"""DxMI trainer (`models.DxMI.trainer.DxMI_Trainer`, `append_buffer`, `reset_buffer`) for the HIP path.
+
+Behaviour follows the reference algorithm (models/DxMI/trainer.py:23-70, 73-408) — contrastive energy
+step, T backward-ordered TD value steps on the replayed transitions, policy step through V with the
+velocity / entropy regularisers, adaptive velocity regulariser — including its order-dependent details
+(SURVEY 7): `betas_for_q` EMA before the value update, `target = V(x')` (the velocity-augmented target
+only survives on the energy branch), `randperm` drawn from torch's CPU generator, the
+len(img)==len(x0) slicing, clip-then-step.  What changes is how the work runs on the GPU:
+  * transitions are appended with ONE concatenation per field per call instead of T (the reference
+    re-copies the growing buffer T times per field: O(T^2) traffic), and the never-read `final` field
+    holds a view-expanded tensor;
+  * the TD loop gathers each step's rows once (index of an index) instead of materialising the
+    permuted T*B buffer five times per step;
+  * value targets are evaluated under no_grad (the reference builds and discards an autograd graph);
+  * the logged scalars are collected on the device and synchronised ONCE per call instead of ~2T+10
+    `.item()` round trips.
+Networks run through their HIP autograd functions (models/value_train.py, unet_small_train.py).
+"""
+import torch
+import torch.nn.functional as F
+
+from ..diffusion import extract, make_beta_schedule
+
+
+def reset_buffer(device):
+    """Empty transition buffer (reference :58-70)."""
+    d = {k: torch.FloatTensor().to(device) for k in ("state", "next_state", "final", "logp", "control", "entropy", "mean", "sigma")}
+    d["timestep"] = torch.LongTensor().to(device)
+    d["y"] = torch.LongTensor().to(device)
+    return d
+
+
+def append_buffer(state_buffer, d_sample):
+    """Flatten a sampled trajectory into (state, next_state, timestep, ...) rows, time-major blocks of
+    n_sample (reference :23-55).  Same resulting tensors; one cat per field."""
+    x_seq = d_sample["l_sample"]
+    n_sample, n_seq = len(x_seq[0]), len(x_seq) - 1
+    device = x_seq[0].device
+
+    def put(key, pieces):
+        state_buffer[key] = torch.cat([state_buffer[key]] + [p.detach() for p in pieces])
+
+    put("state", x_seq[:-1])
+    put("next_state", x_seq[1:])
+    state_buffer["timestep"] = torch.cat([state_buffer["timestep"],
+                                          torch.arange(n_seq, device=device).repeat_interleave(n_sample)])
+    put("final", [x_seq[-1]] * n_seq)
+    for key in ("logp", "control", "entropy", "mean", "sigma"):
+        if key in d_sample:
+            put(key, d_sample[key][:n_seq])
+    if "y" in d_sample:
+        put("y", [d_sample["y"]] * n_seq)
+    return state_buffer
+
+
+class DxMI_Trainer:
+    def __init__(self, batchsize, tau1=0., tau2=0., gamma=None, q_beta_schedule="constant", q_beta_start=1., q_beta_end=1.,
+                 adavelreg=None, n_timesteps=10, value_update_order="backward", entropy_in_value=None,
+                 velocity_in_value=None, use_sampler_beta=False, time_cost=None, time_cost_sig=None,
+                 repeat_value_update=1, value_resample=False, value_grad_clip=False, skip_sampler_tau=0):
+        """Same keyword surface as the reference (:74-133)."""
+        self.batchsize, self.n_timesteps = batchsize, n_timesteps
+        self.gamma, self.tau1, self.tau2 = gamma, tau1, tau2
+        self.value_update_order = value_update_order
+        self.entropy_in_value, self.velocity_in_value = entropy_in_value, velocity_in_value
+        self.q_beta_schedule, self.q_beta_start, self.q_beta_end = q_beta_schedule, q_beta_start, q_beta_end
+        self.adavelreg = adavelreg
+        self.use_sampler_beta = use_sampler_beta
+        self.time_cost, self.time_cost_sig = time_cost, time_cost_sig
+        self.repeat_value_update = repeat_value_update
+        self.value_resample = value_resample
+        self.value_grad_clip = value_grad_clip
+        self.skip_sampler_tau = skip_sampler_tau
+
+    def set_models(self, f, v, sampler, optimizer, optimizer_fstar, optimizer_v):
+        """reference :136-161."""
+        self.f, self.v, self.sampler = f, v, sampler
+        self.optimizer, self.optimizer_fstar, self.optimizer_v = optimizer, optimizer_fstar, optimizer_v
+        if self.f is not None:
+            raise NotImplementedError("separate energy network f: used only by the 2-D toy configs, not on the HIP path")
+        if self.use_sampler_beta:
+            if hasattr(self.sampler, "user_defined_eta"):
+                self.betas_for_q = torch.tensor(self.sampler.user_defined_eta, dtype=torch.float32)
+            elif hasattr(self.sampler, "log_betas"):
+                self.betas_for_q = torch.exp(self.sampler.log_betas).detach()
+            elif hasattr(self.sampler.net, "log_betas"):
+                self.betas_for_q = torch.exp(self.sampler.net.log_betas).detach()
+        else:
+            self.betas_for_q = make_beta_schedule(schedule=self.q_beta_schedule, n_timesteps=self.n_timesteps,
+                                                  start=self.q_beta_start, end=self.q_beta_end)
+
+    # ------------------------------------------------------------------ pieces of the objective
+    def get_running_cost(self, state, next_state, pred_mean, pred_std, t):
+        """||x' - x||^2 / (2 beta_{T-1-t}) averaged over CHW (reference :163-169); integer gather exact."""
+        beta_next = extract(self.betas_for_q, self.n_timesteps - t - 1, state).to(state.device)
+        return (((next_state - state) ** 2) / (2 * beta_next)).view(len(state), -1).mean(dim=1)
+
+    def update_adaptive_vel_reg(self, d_sample):
+        """EMA of the per-step mean squared displacement, reversed to q-time (reference :218-228)."""
+        device = d_sample["sample"].device
+        samples = torch.stack(d_sample["l_sample"])
+        diff = ((samples[1:] - samples[:-1]) ** 2).view(samples.shape[0] - 1, -1).mean(dim=1).flip(0).to(device)
+        self.betas_for_q = (self.betas_for_q.to(device) * self.adavelreg + (1 - self.adavelreg) * diff).detach()
+
+    def _time_cost_terms(self, timestep):
+        extra = 0.
+        if self.time_cost_sig is not None:
+            center = self.n_timesteps // 2
+            extra = self.time_cost_sig * torch.sigmoid(-timestep + center) - self.time_cost_sig * torch.sigmoid(-timestep - 1 + center)
+        return extra
+
+    # ------------------------------------------------------------------ value / energy update
+    def update_f_v(self, img, d_sample, state_dict):
+        """reference :230-346."""
+        x_seq = d_sample["l_sample"]
+        if self.adavelreg is not None:
+            self.update_adaptive_vel_reg(d_sample)
+        self.optimizer_v.zero_grad()
+        x0 = x_seq[-1]
+        n_steps, batchsize, device = self.n_timesteps, self.batchsize, img.device
+        self.v.train()
+        # energy step: the last value step is the energy
+        Tt = n_steps * torch.ones(len(img) + len(x0), dtype=torch.long, device=device)
+        output = self.v(torch.cat((img.detach(), x0.detach()), 0), Tt)
+        pos_e, neg_e = output[:x0.shape[0]], output[x0.shape[0]:]
+        d_loss = pos_e.mean() - neg_e.mean()
+        if self.gamma is not None:
+            reg = pos_e.pow(2).mean() + neg_e.pow(2).mean()
+            d_loss = d_loss + self.gamma * reg
+        else:
+            reg = torch.zeros((), device=device)
+        d_loss.backward()
+        self.optimizer_v.step()
+        self.optimizer_v.zero_grad()
+        logs = {"ebm/d_loss_": d_loss.detach(), "ebm/pos_e_": pos_e.detach().mean(), "ebm/neg_e_": neg_e.detach().mean(),
+                "ebm/reg_": reg.detach()}
+
+        # TD value estimation over the last T*B buffered transitions
+        permutation = torch.randperm(batchsize * n_steps)                     # CPU generator, as the reference
+        indices = (permutation + (state_dict["state"].shape[0] - batchsize * n_steps)).to(device)
+        ts_perm = state_dict["timestep"][indices]
+        running_cost = v_loss = None
+        for i in range(n_steps):
+            update_t = n_steps - i - 1
+            rows = indices[torch.nonzero(ts_perm == update_t).flatten()]     # == [indices][train_indices], gathered once
+            state = state_dict["state"][rows]
+            timestep = state_dict["timestep"][rows]
+            if self.value_resample:
+                with torch.no_grad():
+                    d_step = self.sampler.sample_step(state, timestep)
+                next_state, pred_mean, pred_std = d_step["sample"], d_step["mean"], d_step["sigma"]
+            else:
+                next_state = state_dict["next_state"][rows]
+                pred_mean = state_dict["mean"][rows]
+                pred_std = state_dict["sigma"][rows]
+            running_cost = self.get_running_cost(state, next_state, pred_mean, pred_std, timestep)
+            entropy = torch.log(pred_std.squeeze())
+            self.v.eval()
+            with torch.no_grad():
+                target = self.v(next_state, timestep + 1).squeeze()
+            target = target + self._time_cost_terms(timestep)
+            if self.time_cost is not None:
+                target = target + self.time_cost
+            if self.velocity_in_value is not None:
+                target = target + running_cost * self.tau2 * (timestep < n_steps - self.velocity_in_value).float()
+            if self.entropy_in_value or self.entropy_in_value == 0:
+                assert isinstance(self.entropy_in_value, int), "self.entropy_in_value should be interger"
+                target = target - entropy * self.tau1 * (timestep < n_steps - self.entropy_in_value).float()
+            self.v.train()
+            v_xt = self.v(state, timestep).squeeze()
+            v_loss = F.mse_loss(v_xt, target.detach())
+            v_loss.backward()
+            if self.value_grad_clip:
+                torch.nn.utils.clip_grad_norm_(self.v.parameters(), 0.1)
+            self.optimizer_v.step()
+            self.optimizer_v.zero_grad()
+            logs[f"running_cost/step_{update_t}_"] = running_cost.detach().mean()
+            logs[f"value/step_{update_t}_"] = v_xt.detach().mean()
+        logs["ebm/v_loss_"] = v_loss.detach()
+        logs["ebm/running_cost_"] = running_cost.detach().mean()
+        if self.adavelreg is not None:
+            for t, beta in enumerate(self.betas_for_q):
+                logs[f"adavelreg/beta{t}_"] = beta
+        return self._to_floats(logs)
+
+    # ------------------------------------------------------------------ policy update
+    def update_sampler(self, state_dict, n_generator, d_sample=None):
+        """reference :348-408."""
+        self.v.eval()
+        self.sampler.train()
+        permutation = torch.randperm(state_dict["state"].shape[0])
+        batchsize = self.batchsize
+        n_data = min(len(permutation), batchsize * n_generator)
+        device = state_dict["state"].device
+        for m in range(0, n_data, batchsize):
+            self.optimizer.zero_grad()
+            indices = permutation[m:m + batchsize].to(device)
+            state = state_dict["state"][indices]
+            t = state_dict["timestep"][indices]
+            d_step = self.sampler.sample_step(state, t)
+            next_state, pred_mean, pred_std = d_step["sample"], d_step["mean"], d_step["sigma"]
+            running_cost = self.get_running_cost(state, next_state, pred_mean, pred_std, t)
+            causal_entropy = torch.log(pred_std.squeeze())
+            sampler_value_loss = self.v(next_state, t + 1).squeeze()
+            non_terminal = (t < self.n_timesteps - self.skip_sampler_tau).float()
+            sampler_loss = (sampler_value_loss + (running_cost * self.tau2 - causal_entropy * self.tau1) * non_terminal).mean()
+            sampler_loss.backward()
+            torch.nn.utils.clip_grad_norm_(self.sampler.parameters(), 0.1)
+            self.optimizer.step()
+        logs = {"sampler/sampler_loss_": sampler_loss.detach(), "sampler/sampler_value_loss_": sampler_value_loss.detach().mean(),
+                "sampler/running_cost_": running_cost.detach().mean(), "sampler/causal_entropy_": causal_entropy.detach().mean()}
+        if self.sampler.trainable_beta:
+            net = self.sampler.net.module if hasattr(self.sampler.net, "module") else self.sampler.net
+            sigma = torch.exp(net.log_betas.detach())
+            for t in range(len(sigma)):
+                logs[f"sigma/sigma_{t}_"] = sigma[t]
+        return self._to_floats(logs)
+
+    @staticmethod
+    def _to_floats(logs):
+        """One device->host synchronisation for the whole dictionary."""
+        keys = list(logs.keys())
+        dev = next(v.device for v in logs.values() if torch.is_tensor(v))
+        vals = torch.stack([torch.as_tensor(logs[k], dtype=torch.float32, device=dev).reshape(()) for k in keys]).tolist()
+        return dict(zip(keys, vals))

@@ -71,7 +71,8 @@ typedef struct dxmi_conv_desc {
     int32_t ksize;           /* 1 or 3 */
     int32_t stride;          /* 1 or 2 */
     int32_t pad;             /* top/left zero padding (bottom/right padding is implied by OH/OW) */
-    int32_t upsample;        /* 1: input is nearest-upsampled x2 before the conv */
+    int32_t upsample;        /* 1: input is nearest-upsampled x2 before the conv; 2: zero-stuffed x2 (the
+                                data gradient of a stride-2 conv is a stride-1 conv over the stuffed dY) */
     int32_t act;             /* DXMI_ACT_* applied last */
     int32_t addvec_ld;
     int32_t in_mode;         /* DXMI_IN_*  */
@@ -110,11 +111,36 @@ int64_t dxmi_conv2d_wgrad_workspace_bytes(int32_t N, int32_t OH, int32_t OW, int
                                           int32_t ksize);
 int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int32_t C1, const void* dy,
                       float* dw_oihw, void* workspace, int32_t N, int32_t IH, int32_t IW, int32_t OH,
-                      int32_t OW, int32_t Cout, int32_t ksize, int32_t pad, int32_t upsample,
+                      int32_t OW, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t upsample,
                       int32_t accumulate, void* stream);
 /* workspace: ceil(P/512) * C floats */
 int dxmi_colsum_bf16(const void* x, float* out, void* workspace, int64_t P, int32_t C,
                      int32_t accumulate, void* stream);
+/* out[b][c] = sum of rows [b*rows_per_block, (b+1)*rows_per_block) of x[P][C] (per-image channel sums). */
+int dxmi_colsum_blocks_bf16(const void* x, float* out, int64_t P, int32_t C, int32_t rows_per_block,
+                            void* stream);
+
+/* Backward of GroupNorm(+SiLU) (training path).  x = [in0 | in1] and dy (gradient w.r.t. the forward
+ * kernel's output, one dense [N,HW,C0+C1] tensor) -> dx0 [N,HW,C0], dx1 [N,HW,C1] (+ add0/add1 fused:
+ * skip-connection / residual gradients), and per-image partial sums dgamma_part/dbeta_part [N,C] fp32
+ * (sum over dim 0 gives the parameter gradients).  Statistics are recomputed, nothing is saved by the
+ * forward.  Replaces autograd through unet_small.py:119-126,169,329-330. */
+int dxmi_groupnorm_silu_bwd(const void* in0, int32_t C0, const void* in1, int32_t C1, const void* dy,
+                            const void* add0, const void* add1, const float* gamma, const float* beta,
+                            void* dx0, void* dx1, float* dgamma_part, float* dbeta_part, int32_t N,
+                            int32_t HW, int32_t groups, float eps, int32_t apply_silu, void* stream);
+
+/* Batched bf16 GEMM on MFMA for attention backward: C[b] = alpha * A[b] (MxK) * B[b] (KxN), batch
+ * b = (outer, inner) with element strides *_b0 / *_b1.  *_kcontig != 0: element (row,k) of that operand
+ * is at row*ld + k; == 0: at k*ld + row (read through transposing LDS loads).  C row-major [M,N] with
+ * c_ld, fp32 or bf16.  dxmi_softmax_bwd: per row of length T, P = softmax(S), dS = P o (dP - <dP,P>). */
+int dxmi_bgemm_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N, int32_t K, int64_t a_b0,
+                    int64_t a_b1, int32_t a_ld, int32_t a_kcontig, int64_t b_b0, int64_t b_b1, int32_t b_ld,
+                    int32_t b_kcontig, int64_t c_b0, int64_t c_b1, int32_t c_ld, int32_t c_f32, float alpha,
+                    int32_t outer, int32_t inner, void* stream);
+int dxmi_softmax_bwd(const float* S, const float* dP, void* P, void* dS, int64_t rows, int32_t T,
+                     void* stream);
+
 /* Backward of dxmi_pool_act: din = (pool ? 0.25 * upsample2(g) : g), g = dout * (act_out > 0 ? 1 : slope);
  * dout/act_out: [N,OH,OW,C], din: [N,H,W,C] (H = 2*OH when pool). */
 int dxmi_pool_act_bwd(const void* dout, const void* act_out, void* din, int32_t N, int32_t H, int32_t W,

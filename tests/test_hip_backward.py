@@ -141,3 +141,119 @@ def test_value_net_backward_vs_reference(golden_dir):
         print(f"  {k}: HIP vs reference {r:.2e}   (oracle bf16-model vs reference {fl:.2e})")
         assert got.shape == g[k].shape and r < 1.5 * fl + 5e-3, (k, r, fl)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in v.parameters())
+
+
+GN_BWD_CASES = [(3, 128, 0, 32, True), (2, 256, 0, 16, True), (2, 256, 0, 16, False), (2, 256, 128, 32, True),
+                (3, 256, 256, 8, True), (5, 256, 0, 4, True)]
+
+
+@pytest.mark.parametrize("N,C0,C1,H,silu", GN_BWD_CASES)
+def test_groupnorm_silu_bwd(ops, N, C0, C1, H, silu):
+    C = C0 + C1
+    g = torch.Generator().manual_seed(C + H + N)
+    x = bf(torch.randn(N, C, H, H, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C, generator=g)).requires_grad_(True)
+    dy = bf(torch.randn(N, C, H, H, generator=g))
+    add = bf(torch.randn(N, C, H, H, generator=g))
+    y = F.group_norm(x, 32, gamma, beta, 1e-6)
+    if silu:
+        y = F.silu(y)
+    y.backward(dy)
+    xd = x.detach()
+    dx0, dx1, dg, db = ops.groupnorm_silu_bwd(nhwc(xd[:, :C0]), nhwc(dy), gamma.detach().to(DEV), beta.detach().to(DEV),
+                                              in1=nhwc(xd[:, C0:]) if C1 else None, add0=nhwc(add[:, :C0]),
+                                              add1=nhwc(add[:, C0:]) if C1 else None, silu=silu)
+    got = torch.cat([nchw(dx0)] + ([nchw(dx1)] if C1 else []), 1)
+    assert rel_l2(got, x.grad + add) < 4e-3
+    assert rel_l2(dg.cpu(), gamma.grad) < 1e-4 and rel_l2(db.cpu(), beta.grad) < 1e-4
+
+
+@pytest.mark.parametrize("N,T,C,heads", [(2, 256, 256, 1), (3, 16, 256, 1), (2, 64, 128, 2)])
+def test_attention_bwd(ops, N, T, C, heads):
+    g = torch.Generator().manual_seed(T + C)
+    qkv = bf(torch.randn(N, T, 3 * C, generator=g)).requires_grad_(True)
+    do = bf(torch.randn(N, T, C, generator=g))
+    D = C // heads
+    scale = 1.0 / math.sqrt(D)
+    q, k, v = qkv.split(C, dim=2)
+    q = q.view(N, T, heads, D).transpose(1, 2)
+    k = k.view(N, T, heads, D).transpose(1, 2)
+    v = v.view(N, T, heads, D).transpose(1, 2)
+    o = (torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1) @ v).transpose(1, 2).reshape(N, T, C)
+    o.backward(do)
+    got = ops.attention_bwd(qkv.detach().to(torch.bfloat16).to(DEV), do.to(torch.bfloat16).to(DEV), heads, scale)
+    assert rel_l2(got.float().cpu(), qkv.grad) < 1e-2, rel_l2(got.float().cpu(), qkv.grad)
+
+
+def test_stride2_conv_backward(ops):
+    """DDPM Downsample (pad (0,1,0,1), k3 s2): data gradient = stride-1 conv over the zero-stuffed dY
+    with flipped weights; weight gradient = the strided pixel GEMM."""
+    g = torch.Generator().manual_seed(31)
+    N, C, H = 3, 128, 16
+    x = bf(torch.randn(N, C, H, H, generator=g)).requires_grad_(True)
+    w = bf(torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)).requires_grad_(True)
+    dy = bf(torch.randn(N, C, H // 2, H // 2, generator=g))
+    F.conv2d(F.pad(x, (0, 1, 0, 1)), w, stride=2).backward(dy)
+    pw_t = ops.pack_conv_weight(w.detach().to(DEV), transpose_flip=True)
+    dx = ops.conv2d(nhwc(dy), pw_t, pad=2, pad_br=0, upsample=2)
+    assert dx.shape == (N, H, H, C) and rel_l2(nchw(dx), x.grad) < 4e-3
+    dw = ops.conv2d_wgrad(nhwc(x.detach()), nhwc(dy), 3, stride=2, pad=0)
+    assert rel_l2(dw.cpu(), w.grad) < 1e-4
+
+
+def test_upsample_conv_backward(ops):
+    g = torch.Generator().manual_seed(32)
+    N, C, H = 2, 256, 8
+    x = bf(torch.randn(N, C, H, H, generator=g)).requires_grad_(True)
+    w = bf(torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)).requires_grad_(True)
+    dy = bf(torch.randn(N, C, 2 * H, 2 * H, generator=g))
+    F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, padding=1).backward(dy)
+    dw = ops.conv2d_wgrad(nhwc(x.detach()), nhwc(dy), 3, upsample=True)
+    assert rel_l2(dw.cpu(), w.grad) < 1e-4
+    pw_t = ops.pack_conv_weight(w.detach().to(DEV), transpose_flip=True)
+    dx_hi = ops.conv2d(nhwc(dy), pw_t)                       # gradient w.r.t. the upsampled image
+    dx = ops.pool_act(dx_hi, True, ops.ACT_NONE)             # 2x2 mean; x4 = sum over the replicated pixels
+    assert rel_l2(nchw(dx) * 4, x.grad) < 6e-3
+
+
+def test_unet_backward_vs_oracle(golden_dir):
+    """Full U-Net backward (eval mode = dropout off) against torch autograd through the pinned oracle
+    (fp32) and its bf16 storage model (the noise floor of a bf16 backward)."""
+    from models.DxMI.unet_small import Model
+    from oracle import Precision
+    from oracle import unet_small as ounet
+    from oracle.weights import formula_tensor
+    net = Model(ch=128, out_ch=3, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=[16], dropout=0.1,
+                in_channels=3, resolution=32)
+    sd = {k: formula_tensor(k, v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 32, 32, generator=g)
+    t = torch.tensor([308.867645, 28.2926369])
+    w_out = torch.randn(2, 3, 32, 32, generator=g)
+    y = net(x.to(DEV), t.to(DEV))
+    assert y.requires_grad
+    (y * w_out.to(DEV)).sum().backward()
+    cfg = ounet.UNetSmallConfig()
+    names = ["conv_in.weight", "down.0.block.0.conv1.weight", "down.0.block.0.norm1.weight", "down.0.block.0.temb_proj.weight",
+             "down.1.attn.0.q.weight", "down.1.attn.0.proj_out.bias", "down.1.downsample.conv.weight", "mid.block_1.conv2.weight",
+             "up.1.block.2.nin_shortcut.weight", "up.1.upsample.conv.weight", "up.0.block.2.conv1.weight", "norm_out.bias",
+             "conv_out.weight", "temb.dense.0.weight", "temb.dense.1.bias"]
+    ref = {}
+    for mode in ("fp32", "bf16"):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        yo = ounet.forward(leaves, cfg, x, t, Precision(mode))
+        (yo * w_out).sum().backward()
+        ref[mode] = {k: leaves[k].grad for k in names}
+    P = dict(net.named_parameters())
+    worst = 0.0
+    for k in names:
+        r = rel_l2(P[k].grad.cpu(), ref["fp32"][k])
+        fl = rel_l2(ref["bf16"][k], ref["fp32"][k])
+        print(f"  {k}: HIP vs oracle fp32 {r:.2e}   (oracle bf16-model vs fp32 {fl:.2e})")
+        assert P[k].grad.shape == ref["fp32"][k].shape
+        assert r < 2.0 * fl + 1e-2, (k, r, fl)
+        worst = max(worst, r)
+    assert all(p.grad is not None for n, p in net.named_parameters() if n != "log_betas")
