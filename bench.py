@@ -75,6 +75,38 @@ def cpu_baseline(T, batch, reps):
     return batch / best
 
 
+def build_trainer(sampler, device, B, T):
+    """DxMI trainer on the HIP path with the reference's CIFAR-10 hyper-parameters
+    (configs/cifar10/T10.yaml:33-59; optimizer split train_cifar10.py:283-296)."""
+    from models.DxMI.trainer import DxMI_Trainer
+    from models.modules import IGEBMEncoderV2
+    from models.value import TimeIndependentValue
+    from dxmi_hip.dist import broadcast_parameters
+    v = TimeIndependentValue(IGEBMEncoderV2(in_chan=3, out_chan=1, use_spectral_norm=False, keepdim=False,
+                                            out_activation="linear", avg_pool_dim=1, learn_out_scale=True, nh=128)).to(device)
+    net = sampler.net
+    broadcast_parameters(net)
+    broadcast_parameters(v)
+    not_beta = [p for n, p in net.named_parameters() if "log_betas" not in n]
+    opt = torch.optim.Adam([{"params": net.log_betas, "lr": 1e-5}, {"params": not_beta, "lr": 1e-7}])
+    opt_v = torch.optim.Adam(v.parameters(), lr=1e-5)
+    tr = DxMI_Trainer(batchsize=B, tau1=0.1, tau2=0.01, gamma=1, use_sampler_beta=True, time_cost=0, adavelreg=0.99,
+                      entropy_in_value=None, velocity_in_value=None, time_cost_sig=True, n_timesteps=T)
+    tr.set_models(f=None, v=v, sampler=sampler, optimizer=opt, optimizer_fstar=None, optimizer_v=opt_v)
+    return tr
+
+
+def train_step(tr, sampler, images, device):
+    """One iteration of train_cifar10.py:162-193 (n_critic = n_generator = 1)."""
+    from models.DxMI.trainer import append_buffer, reset_buffer
+    sampler.eval()
+    d_sample = sampler.sample(len(images), device=device)
+    buf = append_buffer(reset_buffer(device), d_sample)
+    d_energy = tr.update_f_v(images, d_sample, buf)
+    d_sampler = tr.update_sampler(buf, 1)
+    return d_energy, d_sampler
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,6 +116,7 @@ def main():
     ap.add_argument("--T", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-conv-events", action="store_true", help="skip the per-launch HIP events (roofline leg)")
+    ap.add_argument("--train-steps", type=int, default=3, help="timed DxMI train steps (0 = skip the train leg)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,6 +166,26 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = tt.item()
 
+    # ---- second leg: DxMI train step (sample + value/energy update + policy update), same batch/GPU
+    train_sps = None
+    if args.train_steps > 0:
+        tr = build_trainer(sampler, device, B, T)
+        gimg = torch.Generator(device=device).manual_seed(112233 + rank)
+        imgs = torch.rand(B, 3, 32, 32, device=device, generator=gimg) * 2 - 1
+        train_step(tr, sampler, imgs, device)          # warm-up (weight packing, workspaces)
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(args.train_steps):
+            logs = train_step(tr, sampler, imgs, device)
+        sync_all()
+        t_train = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([t_train], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            t_train = tt.item()
+        assert all(v == v for v in logs[0].values())   # no NaN
+        train_sps = args.train_steps / t_train
+
     if rank != 0:
         return
     images = B * args.steps * world
@@ -143,7 +196,10 @@ def main():
         "config": {"workload": f"CIFAR-10 DDPM U-Net (35.7M params) VARSampler T={T} generation, "
                                f"{B} images/GPU/step, 3x32x32 (BASELINE configs[1])",
                    "images_per_gpu_per_step": B, "T": T, "parallelism": f"dp{world} (independent trajectories, no collective)"},
-        "train_steps_per_sec": None,
+        "train_steps_per_sec": train_sps,
+        "train_config": {"per_gpu_batch": B, "global_batch": B * world, "timed_steps": args.train_steps,
+                         "step": "sample T + update_f_v (1 energy + T TD steps) + update_sampler, Adam, dropout 0.1",
+                         "grad_sync": "flat fp32 all-reduce over RCCL" if world > 1 else "none (1 GPU)"},
     }
     if prof is not None:
         summ = prof.summary()

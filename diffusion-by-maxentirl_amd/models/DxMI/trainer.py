@@ -78,6 +78,11 @@ class DxMI_Trainer:
         self.optimizer, self.optimizer_fstar, self.optimizer_v = optimizer, optimizer_fstar, optimizer_v
         if self.f is not None:
             raise NotImplementedError("separate energy network f: used only by the 2-D toy configs, not on the HIP path")
+        # data-parallel gradient exchange (replaces the reference's DDP wrappers, train_cifar10.py:298-309):
+        # no-ops on a single process
+        from dxmi_hip.dist import FlatGradSync
+        self.sync_v = FlatGradSync(v) if v is not None else (lambda: None)
+        self.sync_sampler = FlatGradSync(sampler) if sampler is not None else (lambda: None)
         if self.use_sampler_beta:
             if hasattr(self.sampler, "user_defined_eta"):
                 self.betas_for_q = torch.tensor(self.sampler.user_defined_eta, dtype=torch.float32)
@@ -130,10 +135,10 @@ class DxMI_Trainer:
         else:
             reg = torch.zeros((), device=device)
         d_loss.backward()
+        self.sync_v()
         self.optimizer_v.step()
         self.optimizer_v.zero_grad()
-        logs = {"ebm/d_loss_": d_loss.detach(), "ebm/pos_e_": pos_e.detach().mean(), "ebm/neg_e_": neg_e.detach().mean(),
-                "ebm/reg_": reg.detach()}
+        d_running_cost, d_value = {}, {}
 
         # TD value estimation over the last T*B buffered transitions
         permutation = torch.randperm(batchsize * n_steps)                     # CPU generator, as the reference
@@ -170,14 +175,17 @@ class DxMI_Trainer:
             v_xt = self.v(state, timestep).squeeze()
             v_loss = F.mse_loss(v_xt, target.detach())
             v_loss.backward()
+            self.sync_v()
             if self.value_grad_clip:
                 torch.nn.utils.clip_grad_norm_(self.v.parameters(), 0.1)
             self.optimizer_v.step()
             self.optimizer_v.zero_grad()
-            logs[f"running_cost/step_{update_t}_"] = running_cost.detach().mean()
-            logs[f"value/step_{update_t}_"] = v_xt.detach().mean()
-        logs["ebm/v_loss_"] = v_loss.detach()
-        logs["ebm/running_cost_"] = running_cost.detach().mean()
+            d_running_cost[f"running_cost/step_{update_t}_"] = running_cost.detach().mean()
+            d_value[f"value/step_{update_t}_"] = v_xt.detach().mean()
+        logs = {"ebm/d_loss_": d_loss.detach(), "ebm/v_loss_": v_loss.detach(), "ebm/pos_e_": pos_e.detach().mean(),
+                "ebm/neg_e_": neg_e.detach().mean(), "ebm/running_cost_": running_cost.detach().mean(), "ebm/reg_": reg.detach()}
+        logs.update(d_running_cost)
+        logs.update(d_value)
         if self.adavelreg is not None:
             for t, beta in enumerate(self.betas_for_q):
                 logs[f"adavelreg/beta{t}_"] = beta
@@ -205,6 +213,7 @@ class DxMI_Trainer:
             non_terminal = (t < self.n_timesteps - self.skip_sampler_tau).float()
             sampler_loss = (sampler_value_loss + (running_cost * self.tau2 - causal_entropy * self.tau1) * non_terminal).mean()
             sampler_loss.backward()
+            self.sync_sampler()   # the value net's side-effect gradients of this backward are discarded, not reduced
             torch.nn.utils.clip_grad_norm_(self.sampler.parameters(), 0.1)
             self.optimizer.step()
         logs = {"sampler/sampler_loss_": sampler_loss.detach(), "sampler/sampler_value_loss_": sampler_value_loss.detach().mean(),

@@ -153,8 +153,49 @@ def gen_value():
         save("value_forward_64", x=x64, out=v(x64, None))
 
 
+def gen_trainer_step():
+    """One full DxMI_Trainer step (sample -> append_buffer -> update_f_v -> update_sampler), B=4, T=10,
+    dropout 0 (parity fixtures run without dropout: SURVEY 7 RNG parity), CPU generator seeded so the
+    INT path (randperm, gathers) is reproducible."""
+    import models.DxMI.trainer as ref_tr
+    B, T = 4, 10
+    torch.manual_seed(0)
+    kw = dict(UNET_KW)
+    kw["dropout"] = 0.0
+    net = ref_unet.Model(**kw)
+    sampler = ref_vs.VARSampler(net, T, [3, 32, 32], trainable_beta="fix_last")
+    net.load_state_dict(formula_state_dict(net.state_dict()))
+    v = build_value()
+    params_not_beta = [p for n, p in net.named_parameters() if "log_betas" not in n]
+    opt = torch.optim.Adam([{"params": net.log_betas, "lr": 1e-5}, {"params": params_not_beta, "lr": 1e-7}])
+    opt_v = torch.optim.Adam(v.parameters(), lr=1e-5)
+    trainer = ref_tr.DxMI_Trainer(batchsize=B, tau1=0.1, tau2=0.01, gamma=1, use_sampler_beta=True, time_cost=0,
+                                  adavelreg=0.99, entropy_in_value=None, velocity_in_value=None, time_cost_sig=True,
+                                  n_timesteps=T)
+    trainer.set_models(f=None, v=v, sampler=sampler, optimizer=opt, optimizer_fstar=None, optimizer_v=opt_v)
+    g = torch.Generator().manual_seed(555)
+    img = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    seed = 2468
+    torch.manual_seed(seed)
+    sampler.eval()
+    d_sample = sampler.sample(B, device="cpu")
+    buf = ref_tr.append_buffer(ref_tr.reset_buffer("cpu"), d_sample)
+    d_energy = trainer.update_f_v(img, d_sample, buf)
+    d_sampler = trainer.update_sampler(buf, 1)
+    vsd = v.state_dict()
+    nsd = net.state_dict()
+    save("trainer_step", seed=seed, B=B, T=T, img=img,
+         energy_keys=np.array(list(d_energy.keys())), energy_vals=np.array(list(d_energy.values()), dtype=np.float64),
+         sampler_keys=np.array(list(d_sampler.keys())), sampler_vals=np.array(list(d_sampler.values()), dtype=np.float64),
+         betas_for_q=trainer.betas_for_q, buffer_timestep=buf["timestep"], buffer_state_sum=buf["state"].double().sum(),
+         buffer_shapes=np.array([list(buf[k].shape) + [0] * (4 - buf[k].dim()) for k in ("state", "next_state", "mean", "sigma", "logp", "control")]),
+         value_conv1_w_delta=(vsd["net.conv1.weight"] - formula_state_dict({"net.conv1.weight": vsd["net.conv1.weight"]})["net.conv1.weight"]),
+         value_linear_w=vsd["net.linear.weight"], log_betas_after=nsd["log_betas"],
+         net_conv_out_w_delta=(nsd["conv_out.weight"] - formula_state_dict({"conv_out.weight": nsd["conv_out.weight"]})["conv_out.weight"]))
+
+
 GENS = {"schedule": gen_schedule, "unet": gen_unet_forward, "var_sampling": gen_var_sampling,
-        "sample_step": gen_sample_step, "value": gen_value}
+        "sample_step": gen_sample_step, "value": gen_value, "trainer": gen_trainer_step}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

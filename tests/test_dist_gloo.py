@@ -1,0 +1,58 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the flat gradient all-reduce and the
+parameter broadcast that replace the reference's DDP wrappers."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "diffusion-by-maxentirl_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dxmi_hip.dist import FlatGradSync, broadcast_parameters
+    torch.manual_seed(100 + rank)                      # different init per rank
+    m = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 1))
+    m.register_buffer("buf", torch.full((3,), float(rank)))
+    broadcast_parameters(m, src=0)
+    w0 = m[0].weight.detach().clone()
+    x = torch.full((4, 8), float(rank + 1))
+    m(x).sum().backward()
+    local = [p.grad.clone() for p in m.parameters()]
+    FlatGradSync(m)()
+    q.put((rank, w0, m.buf.clone(), local, [p.grad.clone() for p in m.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_and_broadcast_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, w_a, buf_a, loc_a, syn_a), (_, w_b, buf_b, loc_b, syn_b) = res
+    assert torch.equal(w_a, w_b) and torch.equal(buf_a, buf_b) and float(buf_b[0]) == 0.0   # broadcast from rank 0
+    for la, lb, sa, sb in zip(loc_a, loc_b, syn_a, syn_b):
+        assert torch.allclose(sa, (la + lb) / 2, atol=1e-6) and torch.equal(sa, sb)          # mean over ranks, identical
+
+
+def test_single_process_is_noop():
+    sys.path.insert(0, os.path.join(ROOT, "diffusion-by-maxentirl_amd"))
+    from dxmi_hip.dist import FlatGradSync, is_distributed
+    assert not is_distributed()
+    m = torch.nn.Linear(3, 2)
+    m(torch.ones(1, 3)).sum().backward()
+    g = m.weight.grad.clone()
+    FlatGradSync(m)()
+    assert torch.equal(m.weight.grad, g)
