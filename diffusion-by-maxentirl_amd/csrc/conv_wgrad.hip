@@ -264,7 +264,8 @@ extern "C" int dxmi_colsum_bf16(const void* x, float* out, void* workspace, int6
     DXMI_CHECK_ARG(x && out && workspace, "dxmi_colsum_bf16: null pointer");
     DXMI_CHECK_ARG(C % 8 == 0 && C / 8 <= 256, "dxmi_colsum_bf16: C=%d unsupported", C);
     const int cthreads = (256 / (C / 8)) * (C / 8);
-    const int rows_per_block = 512;
+    int rows_per_block = 512;
+    while ((P + rows_per_block - 1) / rows_per_block > 256) rows_per_block *= 2;  // <= 256 partial rows
     const int nblocks = (int)((P + rows_per_block - 1) / rows_per_block);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks), dim3(cthreads), 0, st, (const bf16*)x, (float*)workspace, (long)P, C,

@@ -187,6 +187,32 @@ __global__ __launch_bounds__(64) void value_head_bwd_kernel(const bf16* __restri
     }
 }
 
+// im2col of a 3-channel NCHW fp32 image for the 3x3/s1/p1 stem convs: out[n,y,x,k] (64 wide, bf16),
+// k = ci*9 + ky*3 + kx for k < 27, zero otherwise.  Feeds the 1x1 weight-gradient GEMM of the stem.
+__global__ void im2col27_kernel(const float* __restrict__ x, bf16* __restrict__ out, int N, int H, int W) {
+    const long total = (long)N * H * W * 8;  // 8 pieces of 8 channels per pixel
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int pc = idx & 7;
+        long r = idx >> 3;
+        const int xx = r % W; r /= W;
+        const int yy = r % H;
+        const int n = (int)(r / H);
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = pc * 8 + e;
+            float f = 0.f;
+            if (k < 27) {
+                const int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
+                const int iy = yy + ky - 1, ix = xx + kx - 1;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) f = x[(((long)n * 3 + ci) * H + iy) * W + ix];
+            }
+            v[e] = (bf16)f;
+        }
+        *reinterpret_cast<bf16x8*>(out + idx * 8) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, bf16* __restrict__ out, int N, int C, int HW) {
     const long total = (long)N * C * HW;
@@ -285,6 +311,14 @@ extern "C" int dxmi_value_head(const void* in, const float* w, const float* b, c
     hipLaunchKernelGGL(value_head_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, (const bf16*)in, w, b, out_w,
                        out_b, out, HW, C);
     DXMI_CHECK_LAUNCH("dxmi_value_head");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_im2col27(const float* x, void* out, int32_t N, int32_t H, int32_t W, void* stream) {
+    DXMI_CHECK_ARG(x && out, "dxmi_im2col27: null pointer");
+    hipLaunchKernelGGL(im2col27_kernel, dim3(grid_for((long)N * H * W * 8, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)out,
+                       N, H, W);
+    DXMI_CHECK_LAUNCH("dxmi_im2col27");
     return DXMI_OK;
 }
 

@@ -200,7 +200,7 @@ def colsum(x2d, out=None, accumulate=False):
     if out is None:
         out = torch.empty(C, dtype=torch.float32, device=x2d.device)
         accumulate = False
-    ws = _workspace(((P + 511) // 512) * C * 4, x2d.device)
+    ws = _workspace(max(256, (P + 511) // 512) * C * 4, x2d.device)
     check(load().dxmi_colsum_bf16(_ptr(x2d), _ptr(out), _ptr(ws), P, C, int(accumulate), _stream()), "dxmi_colsum_bf16")
     return out
 
@@ -384,6 +384,18 @@ def value_head(x, w, b, out_w=None, out_b=None, out=None):
     check(load().dxmi_value_head(_ptr(x), _ptr(w), _ptr(b), _ptr(out_w), _ptr(out_b), _ptr(out), N, H * W, C,
                                  _stream()), "dxmi_value_head")
     return out
+
+
+def stem_conv_wgrad(x_nchw, dy):
+    """Weight gradient of a 3-channel 3x3/s1/p1 image conv: x [N,3,H,W] fp32, dy [N,H,W,Cout] bf16 ->
+    fp32 [Cout,3,3,3] (im2col to K=27(+37 zero) then the 1x1 MFMA pixel-GEMM)."""
+    _need_cuda(x_nchw, dy)
+    N, C, H, W = x_nchw.shape
+    assert C == 3 and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    cols = torch.empty((N, H, W, 64), dtype=torch.bfloat16, device=x_nchw.device)
+    check(load().dxmi_im2col27(_ptr(x_nchw), _ptr(cols), N, H, W, _stream()), "dxmi_im2col27")
+    dw = conv2d_wgrad(cols, dy, 1)                      # [Cout, 64, 1, 1]
+    return dw[:, :27, 0, 0].reshape(dy.shape[3], 3, 3, 3).contiguous()
 
 
 def nchw_f32_to_nhwc_bf16(x, out=None):

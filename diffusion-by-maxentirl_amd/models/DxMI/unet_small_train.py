@@ -238,12 +238,10 @@ class _UNetFn(torch.autograd.Function):
         if 0 in gskip:
             g = g + gskip.pop(0)
         grads[net.conv_in.bias] = ops.colsum(g)
-        g_nchw = g.permute(0, 3, 1, 2).float()
-        x_bf = ctx.x.to(torch.bfloat16).float()
-        grads[net.conv_in.weight] = torch.nn.grad.conv2d_weight(x_bf, net.conv_in.weight.shape, g_nchw, padding=1)
+        grads[net.conv_in.weight] = ops.stem_conv_wgrad(ctx.x, g)
         dx = None
         if ctx.needs_input_grad[1]:
-            dx = torch.nn.grad.conv2d_input(x_bf.shape, net.conv_in.weight.to(torch.bfloat16).float(), g_nchw, padding=1)
+            dx = ops.conv2d(g, ops.pack_conv_weight(net.conv_in.weight, transpose_flip=True), out_nchw_f32=True)
 
         # ---- temb MLP + all temb_proj layers: tiny dense graph, re-evaluated in fp32 with torch autograd
         blocks = list(net._resblocks())

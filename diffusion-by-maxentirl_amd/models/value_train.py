@@ -87,16 +87,13 @@ class _ValueNetFn(torch.autograd.Function):
             g_out = ops.conv2d(d_h1, pk_t[i, "conv1"], residual=d_skip)
         # ---- stem conv: a0 = LeakyReLU(conv1(x))
         d_a0 = ops.pool_act_bwd(g_out, a0, False, SLOPE)
-        x_nhwc = ctx.x_nhwc if ctx.x_nhwc is not None else ops.nchw_f32_to_nhwc_bf16(ctx.x)
         grads[net.conv1.bias] = ops.colsum(d_a0)
-        # 3-channel image conv: K = 27 weight gradient and the input gradient are tiny GEMMs; torch ops on
-        # the bf16 tensors (0.2 % of the network's FLOPs)
-        d_a0_nchw = d_a0.permute(0, 3, 1, 2).float()
-        x32 = x_nhwc.permute(0, 3, 1, 2).float()
-        grads[net.conv1.weight] = torch.nn.grad.conv2d_weight(x32, net.conv1.weight.shape, d_a0_nchw, padding=1)
+        assert net.in_chan == 3, "stem backward is written for 3-channel images"
+        grads[net.conv1.weight] = ops.stem_conv_wgrad(ctx.x, d_a0)
         dx = None
         if ctx.need_dx:
-            dx = torch.nn.grad.conv2d_input(x32.shape, net.conv1.weight.to(torch.bfloat16).float(), d_a0_nchw, padding=1)
+            # data gradient of the stem: 128 -> 3 channel conv on flipped weights, fp32 NCHW out
+            dx = ops.conv2d(d_a0, ops.pack_conv_weight(net.conv1.weight, transpose_flip=True), out_nchw_f32=True)
         out = [None, dx]
         for prm in net.parameters():
             out.append(grads.get(prm))

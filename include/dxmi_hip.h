@@ -222,6 +222,11 @@ int dxmi_pool_act(const void* in, void* out, int32_t N, int32_t H, int32_t W, in
 int dxmi_value_head(const void* in, const float* w, const float* b, const float* out_w,
                     const float* out_b, float* out, int32_t N, int32_t HW, int32_t C, void* stream);
 
+/* im2col of a 3-channel NCHW fp32 image (3x3, stride 1, pad 1): out [N,H,W,64] bf16, channel
+ * k = ci*9+ky*3+kx for k < 27, zero above — the activation operand of the stem convs' weight gradient
+ * (dxmi_conv2d_wgrad with ksize 1). */
+int dxmi_im2col27(const float* x, void* out, int32_t N, int32_t H, int32_t W, void* stream);
+
 /* Layout converters at the network edge. */
 int dxmi_nchw_f32_to_nhwc_bf16(const float* in, void* out, int32_t N, int32_t C, int32_t HW,
                                void* stream);

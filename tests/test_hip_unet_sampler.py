@@ -225,3 +225,27 @@ def test_full_batch_properties(sampler10):
 def test_graft_smoke():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_cli_train_then_generate(tmp_path):
+    """Drop-in CLI surface end to end on one GPU: train_cifar10.py (3 synthetic iterations, writes
+    config.yaml + sampler_last.pth with reference key names) then generate_cifar10.py from that log dir."""
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffusion-by-maxentirl_amd")
+    env = dict(os.environ, LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, "train_cifar10.py", "--config", "builtin:cifar10_T10", "--dataset", "builtin",
+                        "--run", "t", "--synthetic_data", "--max_iters", "3", "--training.batchsize", "8",
+                        "--training.n_epochs", "1", "--training.log_every", "1"], cwd=pkg, env=dict(env, PWD=pkg),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    logdir = os.path.join(pkg, "results", "cifar10", "cifar10_T10", "t")
+    ck = torch.load(os.path.join(logdir, "sampler_last.pth"), map_location="cpu")
+    assert len(ck["state_dict"]) == 330 and "log_betas" in ck["state_dict"] and ck["iter"] == 3
+    r2 = subprocess.run([sys.executable, "generate_cifar10.py", "--log_dir", logdir, "-n", "8", "--batchsize", "8",
+                         "--epoch", "last", "--skip_fid"], cwd=pkg, env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
+    pngs = [f for f in os.listdir(os.path.join(logdir, "generated")) if f.endswith(".png")]
+    assert len(pngs) == 8
+    import shutil
+    shutil.rmtree(os.path.join(pkg, "results"), ignore_errors=True)
