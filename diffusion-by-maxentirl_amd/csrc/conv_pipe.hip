@@ -52,12 +52,13 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&ac
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[0][nb][4 * g + e];
-                if (p.bias) {
+                const bool co_ok = cot * 128 + co_l + 8 * g < p.Cout;
+                if (p.bias && co_ok) {
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + cot * 128 + co_l + 8 * g);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += bv[e];
                 }
-                if (p.addvec && n < p.N) {
+                if (p.addvec && n < p.N && co_ok) {
                     const f32x4 t = *reinterpret_cast<const f32x4*>(p.addvec + (size_t)n * p.addvec_ld + cot * 128 + co_l + 8 * g);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += t[e];
@@ -74,7 +75,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&ac
             const int x = pix & (TW - 1);
             const int y = (pix >> p.TWl) & (TH - 1);
             const int n = n0 + (pix >> (p.TWl + p.THl));
-            if (n < p.N) {
+            if (n < p.N && cot * 128 + pc * 8 < p.Cout) {
                 const size_t o = (((size_t)n * p.OH + oy0 + y) * p.OW + ox0 + x) * p.Cout + cot * 128 + pc * 8;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(eb + lp * EPI_PITCH + pc * 32);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(eb + lp * EPI_PITCH + pc * 32 + 16);
@@ -207,7 +208,9 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
         for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
 
     const int cb0 = cot * 4 + wave;  // this wave's 32-co block
-    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(p.w) + (size_t)cb0 * 64 + lane;
+    // Cout % 128 == 64: the last cout tile is half empty; its idle waves read a valid block and store nothing
+    const int cbw = cb0 < p.CB ? cb0 : p.CB - 1;
+    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(p.w) + (size_t)cbw * 64 + lane;
     const int wstep = p.CB * 64;  // fragments between consecutive k-steps
 
     // register sets, ping-pong by the parity of the unrolled step index
@@ -323,8 +326,8 @@ int ilog2p(int v) {
 
 int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     if (a.in_mode != DXMI_IN_NHWC_BF16 || a.out_mode != DXMI_OUT_NHWC_BF16) return 1;
-    if (a.stride != 1 || a.Cout % 128 != 0 || (a.C0 + a.C1) % 64 != 0 || a.C0 % 32 != 0) return 1;  // even chunk count
-    const int CT = a.Cout / 128;
+    if (a.stride != 1 || a.Cout % 64 != 0 || (a.C0 + a.C1) % 64 != 0 || a.C0 % 32 != 0) return 1;  // even chunk count
+    const int CT = (a.Cout + 127) / 128;
     // pixel-tile size: the largest of 256/128/64 that still gives every CU a workgroup
     const long px = (long)a.N * a.OH * a.OW;
     int NB = 8;

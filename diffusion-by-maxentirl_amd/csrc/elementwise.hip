@@ -187,6 +187,70 @@ __global__ __launch_bounds__(64) void value_head_bwd_kernel(const bf16* __restri
     }
 }
 
+// nearest-neighbour x2 upsample, NHWC bf16, 8 channels per thread (ResBlock up: x_upd, models/cm/unet.py:197-198)
+__global__ void upsample2x_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int N, int H, int W, int C) {
+    const int C8 = C / 8, OH = 2 * H, OW = 2 * W;
+    const long total = (long)N * OH * OW * C8;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c8 = idx % C8;
+        long r = idx / C8;
+        const int ox = r % OW; r /= OW;
+        const int oy = r % OH;
+        const int n = (int)(r / OH);
+        *reinterpret_cast<bf16x8*>(out + idx * 8) =
+            *reinterpret_cast<const bf16x8*>(in + (((size_t)n * H + (oy >> 1)) * W + (ox >> 1)) * C + c8 * 8);
+    }
+}
+
+// EDM preconditioning input: x_in = x / sqrt(sigma^2 + sd^2), rescaled_t = 250*ln(sigma + 1e-44)
+// (KarrasDenoiser.get_scalings / denoise, models/cm/karras_diffusion.py:64-68, :348-349)
+__global__ void edm_precond_kernel(const float* __restrict__ x, const float* __restrict__ sigma, float* __restrict__ x_in,
+                                   float* __restrict__ t_out, int CHW, float sd) {
+    const int b = blockIdx.x;
+    const float s = sigma[b];
+    const float c_in = 1.f / powf(s * s + sd * sd, 0.5f);
+    if (threadIdx.x == 0) t_out[b] = 1000.f * 0.25f * logf(s + 1e-44f);
+    const size_t base = (size_t)b * CHW;
+    for (int i = threadIdx.x * 4; i < CHW; i += 256 * 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + base + i);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = c_in * v[e];
+        *reinterpret_cast<f32x4*>(x_in + base + i) = o;
+    }
+}
+
+// Fused Euler-ancestral EDM transition (models/DxMI/openai_diffusion.py:71-94 with
+// karras_diffusion.py:64-68,350): denoised = c_out*F + c_skip*x ; d = (x - denoised)/sigma ;
+// mu = x + d*(sigma_down - sigma) ; x' = mu + z*sigma_up.
+__global__ void edm_step_kernel(const float* __restrict__ x, const float* __restrict__ fout, const float* __restrict__ z,
+                                const float* __restrict__ sigma, const float* __restrict__ sigma_down,
+                                const float* __restrict__ sigma_up, float* __restrict__ sample, float* __restrict__ mean,
+                                int CHW, float sd) {
+    const int b = blockIdx.x;
+    const float s = sigma[b], sdn = sigma_down[b], sup = sigma_up[b];
+    const float den = s * s + sd * sd;
+    const float c_skip = sd * sd / den;
+    const float c_out = s * sd / powf(den, 0.5f);
+    const float dt = sdn - s;
+    const size_t base = (size_t)b * CHW;
+    for (int i = threadIdx.x * 4; i < CHW; i += 256 * 4) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + i);
+        const f32x4 fv = *reinterpret_cast<const f32x4*>(fout + base + i);
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + base + i);
+        f32x4 mu, sm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float den_ = c_out * fv[e] + c_skip * xv[e];
+            const float d = (xv[e] - den_) / s;
+            mu[e] = xv[e] + d * dt;
+            sm[e] = mu[e] + zv[e] * sup;
+        }
+        *reinterpret_cast<f32x4*>(mean + base + i) = mu;
+        *reinterpret_cast<f32x4*>(sample + base + i) = sm;
+    }
+}
+
 // im2col of a 3-channel NCHW fp32 image for the 3x3/s1/p1 stem convs: out[n,y,x,k] (64 wide, bf16),
 // k = ci*9 + ky*3 + kx for k < 27, zero otherwise.  Feeds the 1x1 weight-gradient GEMM of the stem.
 __global__ void im2col27_kernel(const float* __restrict__ x, bf16* __restrict__ out, int N, int H, int W) {
@@ -311,6 +375,33 @@ extern "C" int dxmi_value_head(const void* in, const float* w, const float* b, c
     hipLaunchKernelGGL(value_head_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, (const bf16*)in, w, b, out_w,
                        out_b, out, HW, C);
     DXMI_CHECK_LAUNCH("dxmi_value_head");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_upsample2x(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    DXMI_CHECK_ARG(in && out && C % 8 == 0, "dxmi_upsample2x: bad arguments");
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for((long)N * 4 * H * W * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)in, (bf16*)out, N, H, W, C);
+    DXMI_CHECK_LAUNCH("dxmi_upsample2x");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_edm_precond(const float* x, const float* sigma, float* x_in, float* t_out, int32_t N, int32_t CHW,
+                                float sigma_data, void* stream) {
+    DXMI_CHECK_ARG(x && sigma && x_in && t_out && CHW % 4 == 0, "dxmi_edm_precond: bad arguments");
+    hipLaunchKernelGGL(edm_precond_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, sigma, x_in, t_out, CHW, sigma_data);
+    DXMI_CHECK_LAUNCH("dxmi_edm_precond");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_edm_step_fwd(const float* x, const float* model_out, const float* z, const float* sigma,
+                                 const float* sigma_down, const float* sigma_up, float* sample, float* mean, int32_t N,
+                                 int32_t CHW, float sigma_data, void* stream) {
+    DXMI_CHECK_ARG(x && model_out && z && sigma && sigma_down && sigma_up && sample && mean && CHW % 4 == 0,
+                   "dxmi_edm_step_fwd: bad arguments");
+    hipLaunchKernelGGL(edm_step_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, model_out, z, sigma, sigma_down, sigma_up,
+                       sample, mean, CHW, sigma_data);
+    DXMI_CHECK_LAUNCH("dxmi_edm_step_fwd");
     return DXMI_OK;
 }
 

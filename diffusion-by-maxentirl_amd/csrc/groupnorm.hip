@@ -161,6 +161,107 @@ __global__ __launch_bounds__(512) void gn_silu_kernel(GnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Generic two-kernel GroupNorm(+SiLU) for shapes the register-resident kernel cannot hold (EDM U-Net:
+// 6/18/30/42 channels per group, 64x64 and larger maps): (1) per-(image, row-chunk) partial sums of every
+// group from fully coalesced 16-byte row pieces; (2) apply: each workgroup re-reduces its image's partials
+// in a fixed order, then normalises its rows (second read mostly served by L2 / Infinity Cache).
+// Optional per-image scale/shift (ADM "scale-shift norm", models/cm/unet.py:252-256):
+//   y = (xh*gamma + beta) * (1 + scale[n,c]) + shift[n,c]   then SiLU.
+struct GnGenArgs {
+    const bf16* in0;
+    const bf16* in1;
+    const float* gamma;
+    const float* beta;
+    const float* ss;     // [N][ss_ld]: scale at [c], shift at [C + c], or null
+    bf16* out;
+    float* part;         // [N][chunks][groups][2]
+    int C0, C1, HW, groups, cpg, chunks, rows_per_chunk, ss_ld;
+    float eps;
+    int silu;
+};
+
+__global__ __launch_bounds__(256) void gn_gen_stats_kernel(GnGenArgs p) {
+    __shared__ float sm[2][32];
+    const int C = p.C0 + p.C1, c8n = C / 8;
+    const int n = blockIdx.x / p.chunks, chunk = blockIdx.x % p.chunks;
+    const int tid = threadIdx.x;
+    if (tid < 64) sm[tid >> 5][tid & 31] = 0.f;
+    __syncthreads();
+    const int row0 = chunk * p.rows_per_chunk;
+    const int row1 = min(row0 + p.rows_per_chunk, p.HW);
+    const long npieces = (long)(row1 - row0) * c8n;
+    float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};  // a piece of 8 channels touches at most 2 groups when cpg >= 8... general: flush per element
+    for (long i = tid; i < npieces; i += 256) {
+        const int r = row0 + (int)(i / c8n), pc = (int)(i % c8n);
+        const int c = pc * 8;
+        const bool from0 = c < p.C0;
+        const bf16* src = from0 ? p.in0 + ((size_t)n * p.HW + r) * p.C0 + c : p.in1 + ((size_t)n * p.HW + r) * p.C1 + (c - p.C0);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+        int gcur = c / p.cpg;
+        float ls = 0.f, lq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / p.cpg;
+            if (g != gcur) {
+                atomicAdd(&sm[0][gcur], ls);
+                atomicAdd(&sm[1][gcur], lq);
+                ls = 0.f; lq = 0.f; gcur = g;
+            }
+            const float f = (float)v[e];
+            ls += f; lq += f * f;
+        }
+        atomicAdd(&sm[0][gcur], ls);
+        atomicAdd(&sm[1][gcur], lq);
+    }
+    (void)s; (void)q;
+    __syncthreads();
+    if (tid < 2 * p.groups) {
+        const int g = tid % p.groups, w = tid / p.groups;
+        p.part[(((size_t)n * p.chunks + chunk) * p.groups + g) * 2 + w] = sm[w][g];
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_gen_apply_kernel(GnGenArgs p) {
+    __shared__ float mean_s[32], rstd_s[32];
+    const int C = p.C0 + p.C1, c8n = C / 8;
+    const int n = blockIdx.x / p.chunks, chunk = blockIdx.x % p.chunks;
+    const int tid = threadIdx.x;
+    if (tid < p.groups) {
+        float s = 0.f, q = 0.f;
+        for (int k = 0; k < p.chunks; ++k) {
+            s += p.part[(((size_t)n * p.chunks + k) * p.groups + tid) * 2 + 0];
+            q += p.part[(((size_t)n * p.chunks + k) * p.groups + tid) * 2 + 1];
+        }
+        const float cnt = (float)p.HW * p.cpg;
+        const float m = s / cnt;
+        const float var = fmaxf(q / cnt - m * m, 0.f);
+        mean_s[tid] = m;
+        rstd_s[tid] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    const int row0 = chunk * p.rows_per_chunk;
+    const int row1 = min(row0 + p.rows_per_chunk, p.HW);
+    const long npieces = (long)(row1 - row0) * c8n;
+    for (long i = tid; i < npieces; i += 256) {
+        const int r = row0 + (int)(i / c8n), pc = (int)(i % c8n);
+        const int c = pc * 8;
+        const bool from0 = c < p.C0;
+        const bf16* src = from0 ? p.in0 + ((size_t)n * p.HW + r) * p.C0 + c : p.in1 + ((size_t)n * p.HW + r) * p.C1 + (c - p.C0);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / p.cpg;
+            float y = ((float)v[e] - mean_s[g]) * rstd_s[g] * p.gamma[c + e] + p.beta[c + e];
+            if (p.ss) y = y * (1.f + p.ss[(size_t)n * p.ss_ld + c + e]) + p.ss[(size_t)n * p.ss_ld + C + c + e];
+            if (p.silu) y = y / (1.f + __expf(-y));
+            o[e] = (bf16)y;
+        }
+        *reinterpret_cast<bf16x8*>(p.out + ((size_t)n * p.HW + r) * C + c) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward of GroupNorm(+SiLU): given x (virtual concat), the upstream gradient dy w.r.t. the
 // kernel's output, gamma/beta -> dx (split back into the two concat sources, optional additive
 // inputs fused: skip-connection / residual gradients) and per-image partial d(gamma), d(beta).
@@ -436,6 +537,58 @@ extern "C" int dxmi_groupnorm_silu_bwd(const void* in0, int32_t C0, const void* 
     a.fast = (ppp <= 64) && ((ppp & (ppp - 1)) == 0) && ((ppt & (ppt - 1)) == 0);
     hipStream_t st = (hipStream_t)stream;
     return VEC == 8 ? launch_gn_bwd<8>(a, N, pieces, threads, st) : launch_gn_bwd<4>(a, N, pieces, threads, st);
+}
+
+extern "C" int64_t dxmi_groupnorm_generic_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
+    const int chunks = HW >= 1024 ? 16 : (HW >= 256 ? 4 : 1);
+    (void)C;
+    return (int64_t)N * chunks * 32 * 2 * 4;
+}
+
+// Generic GroupNorm(+scale-shift)(+SiLU): any even... any C0, C1 multiples of 8, any channels per group.
+extern "C" int dxmi_groupnorm_generic_fwd(const void* in0, int32_t C0, const void* in1, int32_t C1, const float* gamma,
+                                          const float* beta, const float* scale_shift, int32_t ss_ld, void* out,
+                                          void* workspace, int32_t N, int32_t HW, int32_t groups, float eps,
+                                          int32_t apply_silu, void* stream) {
+    DXMI_CHECK_ARG(in0 && out && gamma && beta && workspace, "dxmi_groupnorm_generic_fwd: null pointer");
+    const int C = C0 + C1;
+    DXMI_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0 && C0 % 8 == 0 && C1 % 8 == 0 && (C1 == 0 || in1),
+                   "dxmi_groupnorm_generic_fwd: C0=%d C1=%d groups=%d", C0, C1, groups);
+    GnGenArgs a;
+    a.in0 = (const bf16*)in0; a.in1 = (const bf16*)in1; a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.ss_ld = ss_ld;
+    a.out = (bf16*)out; a.part = (float*)workspace; a.C0 = C0; a.C1 = C1; a.HW = HW; a.groups = groups; a.cpg = C / groups;
+    a.chunks = HW >= 1024 ? 16 : (HW >= 256 ? 4 : 1);
+    a.rows_per_chunk = (HW + a.chunks - 1) / a.chunks;
+    a.eps = eps; a.silu = apply_silu;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_gen_stats_kernel, dim3(N * a.chunks), dim3(256), 0, st, a);
+    DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_fwd(stats)");
+    hipLaunchKernelGGL(gn_gen_apply_kernel, dim3(N * a.chunks), dim3(256), 0, st, a);
+    DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_fwd(apply)");
+    return DXMI_OK;
+}
+
+// 1 when the one-pass register-resident kernel (dxmi_groupnorm_silu_fwd) can serve the shape, else 0
+// (callers then use dxmi_groupnorm_generic_fwd).  Same slicing walk as the launcher below.
+extern "C" int dxmi_groupnorm_silu_supported(int32_t C0, int32_t C1, int32_t HW, int32_t groups) {
+    const int C = C0 + C1;
+    if (groups <= 0 || groups > 32 || C % groups != 0) return 0;
+    const int cpg = C / groups;
+    if (cpg % 4 != 0 || C0 % 4 != 0) return 0;
+    const int VEC = (cpg % 8 == 0 && C0 % 8 == 0) ? 8 : 4;
+    const int max_pieces = VEC == 8 ? 16 : 32;
+    for (int slices = 1;; slices *= 2) {
+        if (groups % slices != 0) return 0;
+        const int ppp = C / slices / VEC;
+        const int unit = ppp / gcd(ppp, 64) * 64;
+        if (unit > 512) return 0;
+        const long total = (long)HW * ppp;
+        int threads = (512 / unit) * unit;
+        if (total < threads) threads = (int)((total + unit - 1) / unit) * unit;
+        const int pieces = (int)((total + threads - 1) / threads);
+        if (pieces <= max_pieces) return 1;
+        if (slices == groups) return pieces <= 32;
+    }
 }
 
 extern "C" int dxmi_groupnorm_silu_fwd(const void* in0, int32_t C0, const void* in1, int32_t C1, const float* gamma,

@@ -288,10 +288,14 @@ def attention_bwd(qkv, do, heads, scale):
     return dqkv
 
 
-def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, out=None):
-    _need_cuda(x, in1, gamma, beta, out)
+def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, out=None, scale_shift=None):
+    """GroupNorm(+SiLU).  The register-resident one-pass kernel serves channels-per-group % 4 == 0 slices that fit;
+    everything else (EDM shapes, scale-shift norm) goes to the generic two-kernel path."""
+    _need_cuda(x, in1, gamma, beta, out, scale_shift)
     N, H, W, C0 = x.shape
     C1 = in1.shape[3] if in1 is not None else 0
+    if scale_shift is not None or not load().dxmi_groupnorm_silu_supported(C0, C1, H * W, groups):
+        return groupnorm_generic(x, gamma, beta, in1=in1, groups=groups, eps=eps, silu=silu, out=out, scale_shift=scale_shift)
     assert x.dtype == torch.bfloat16 and x.is_contiguous()
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C0 + C1
     if out is None:
@@ -299,6 +303,54 @@ def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, 
     check(load().dxmi_groupnorm_silu_fwd(_ptr(x), C0, _ptr(in1), C1, _ptr(gamma), _ptr(beta), _ptr(out), N, H * W,
                                          groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_silu_fwd")
     return out
+
+
+def groupnorm_generic(x, gamma, beta, *, in1=None, groups=32, eps=1e-5, silu=True, out=None, scale_shift=None):
+    _need_cuda(x, in1, gamma, beta, out, scale_shift)
+    N, H, W, C0 = x.shape
+    C1 = in1.shape[3] if in1 is not None else 0
+    C = C0 + C1
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device)
+    ss_ld = 0
+    if scale_shift is not None:
+        assert scale_shift.dtype == torch.float32 and scale_shift.stride(-1) == 1 and scale_shift.shape[1] == 2 * C
+        ss_ld = scale_shift.stride(0)
+    lib = load()
+    ws = _workspace(lib.dxmi_groupnorm_generic_workspace_bytes(N, H * W, C), x.device)
+    check(lib.dxmi_groupnorm_generic_fwd(_ptr(x), C0, _ptr(in1), C1, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld, _ptr(out),
+                                         _ptr(ws), N, H * W, groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_generic_fwd")
+    return out
+
+
+def upsample2x(x, out=None):
+    _need_cuda(x, out)
+    N, H, W, C = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    if out is None:
+        out = torch.empty((N, 2 * H, 2 * W, C), dtype=torch.bfloat16, device=x.device)
+    check(load().dxmi_upsample2x(_ptr(x), _ptr(out), N, H, W, C, _stream()), "dxmi_upsample2x")
+    return out
+
+
+def edm_precond(x, sigma, sigma_data=0.5):
+    _need_cuda(x, sigma)
+    N = x.shape[0]
+    x_in = torch.empty_like(x)
+    t = torch.empty(N, dtype=torch.float32, device=x.device)
+    check(load().dxmi_edm_precond(_ptr(x), _ptr(sigma), _ptr(x_in), _ptr(t), N, x.numel() // N, float(sigma_data), _stream()),
+          "dxmi_edm_precond")
+    return x_in, t
+
+
+def edm_step(x, model_out, z, sigma, sigma_down, sigma_up, sigma_data=0.5):
+    _need_cuda(x, model_out, z, sigma, sigma_down, sigma_up)
+    N = x.shape[0]
+    sample, mean = torch.empty_like(x), torch.empty_like(x)
+    check(load().dxmi_edm_step_fwd(_ptr(x), _ptr(model_out), _ptr(z), _ptr(sigma), _ptr(sigma_down), _ptr(sigma_up), _ptr(sample),
+                                   _ptr(mean), N, x.numel() // N, float(sigma_data), _stream()), "dxmi_edm_step_fwd")
+    return sample, mean
 
 
 def attention(qkv, heads, scale, out=None):

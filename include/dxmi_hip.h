@@ -222,6 +222,30 @@ int dxmi_pool_act(const void* in, void* out, int32_t N, int32_t H, int32_t W, in
 int dxmi_value_head(const void* in, const float* w, const float* b, const float* out_w,
                     const float* out_b, float* out, int32_t N, int32_t HW, int32_t C, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * EDM / ADM U-Net path (models/cm/unet.py, models/cm/karras_diffusion.py, models/DxMI/openai_diffusion.py).
+ * dxmi_groupnorm_generic_fwd: GroupNorm32 (+ scale-shift norm, + SiLU) for any channels-per-group and
+ *   map size (two kernels: coalesced partial statistics, then apply); scale_shift: fp32 [N, ss_ld] with
+ *   scale at [c] and shift at [C + c] (unet.py:252-256) or NULL.  workspace from
+ *   dxmi_groupnorm_generic_workspace_bytes.
+ * dxmi_upsample2x: nearest x2 (ResBlock up, x branch; unet.py:197-198).
+ * dxmi_edm_precond: x_in = c_in(sigma)*x, t = 250 ln(sigma + 1e-44)   (karras_diffusion.py:64-68,348-349).
+ * dxmi_edm_step_fwd: fused Euler-ancestral transition (openai_diffusion.py:71-94): denoised =
+ *   c_out F + c_skip x; d = (x - denoised)/sigma; mean = x + d (sigma_down - sigma); sample = mean + z sigma_up.
+ * ---------------------------------------------------------------------------------------- */
+int dxmi_groupnorm_silu_supported(int32_t C0, int32_t C1, int32_t HW, int32_t groups); /* 1: one-pass kernel serves it */
+int64_t dxmi_groupnorm_generic_workspace_bytes(int32_t N, int32_t HW, int32_t C);
+int dxmi_groupnorm_generic_fwd(const void* in0, int32_t C0, const void* in1, int32_t C1, const float* gamma,
+                               const float* beta, const float* scale_shift, int32_t ss_ld, void* out,
+                               void* workspace, int32_t N, int32_t HW, int32_t groups, float eps,
+                               int32_t apply_silu, void* stream);
+int dxmi_upsample2x(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int dxmi_edm_precond(const float* x, const float* sigma, float* x_in, float* t_out, int32_t N, int32_t CHW,
+                     float sigma_data, void* stream);
+int dxmi_edm_step_fwd(const float* x, const float* model_out, const float* z, const float* sigma,
+                      const float* sigma_down, const float* sigma_up, float* sample, float* mean, int32_t N,
+                      int32_t CHW, float sigma_data, void* stream);
+
 /* im2col of a 3-channel NCHW fp32 image (3x3, stride 1, pad 1): out [N,H,W,64] bf16, channel
  * k = ci*9+ky*3+kx for k < 27, zero above — the activation operand of the stem convs' weight gradient
  * (dxmi_conv2d_wgrad with ksize 1). */

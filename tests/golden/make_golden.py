@@ -194,8 +194,77 @@ def gen_trainer_step():
          net_conv_out_w_delta=(nsd["conv_out.weight"] - formula_state_dict({"conv_out.weight": nsd["conv_out.weight"]})["conv_out.weight"]))
 
 
+EDM_TINY = dict(image_size=16, class_cond=True, learn_sigma=False, num_channels=64, num_res_blocks=1, channel_mult="1,2",
+                num_heads=4, num_head_channels=64, num_heads_upsample=-1, attention_resolutions="8", dropout=0.0,
+                use_checkpoint=False, use_scale_shift_norm=True, resblock_updown=True, use_fp16=False,
+                use_new_attention_order=False, weight_schedule="uniform", sigma_min=0.002, sigma_max=80.0)
+
+
+def build_edm(**over):
+    """Shrunken ADM U-Net (imagenet64 topology: class-cond, scale-shift norm, resblock up/down, 64-wide
+    heads) in fp32.  QKVAttentionLegacy returns fp16 (unet.py:421,441), which the fp32 proj_out conv
+    rejects on the CPU: a forward hook casts its OUTPUT back to fp32 — its fp16 arithmetic is kept."""
+    import models.cm.script_util as ref_su
+    import models.cm.unet as ref_cm_unet
+    kw = dict(EDM_TINY)
+    kw.update(over)
+    net, diffusion = ref_su.create_model_and_diffusion(**kw)
+    net.load_state_dict(formula_state_dict(net.state_dict()))
+    for m in net.modules():
+        if isinstance(m, ref_cm_unet.QKVAttentionLegacy):
+            m.register_forward_hook(lambda mod, inp, out: out.float())
+    net.eval()
+    return net, diffusion
+
+
+def gen_edm():
+    import models.cm.karras_diffusion as ref_kd
+    import models.DxMI.openai_diffusion as ref_oa
+    import contextlib, io
+    # schedule tables for the two shipped imagenet64 / lsun sampler settings
+    tabs = {}
+    for name, kw in (("T10", dict(n_timesteps=10)), ("T4", dict(n_timesteps=4, stochastic_last=True, rho=4.0))):
+        net, diffusion = build_edm()
+        with contextlib.redirect_stdout(io.StringIO()):
+            s = ref_oa.OpenAIDiffusion(net, diffusion, sample_shape=(3, 16, 16), class_cond=True, num_classes=1000,
+                                       trainable_beta="fix_last", **kw)
+        tabs[f"sigmas_{name}"], tabs[f"sigma_up_{name}"], tabs[f"sigma_down_{name}"] = s.sigmas, s.sigma_up, s.sigma_down
+        tabs[f"log_betas_{name}"] = net.log_betas.detach()
+    save("edm_schedule", **tabs)
+
+    for tag, over in (("", {}), ("_plain", dict(class_cond=False, use_scale_shift_norm=False, resblock_updown=False))):
+        net, diffusion = build_edm(**over)
+        cc = over.get("class_cond", True)
+        g = torch.Generator().manual_seed(31)
+        x = torch.randn(2, 3, 16, 16, generator=g)
+        t = torch.tensor([1095.5, -1553.6])   # 250 ln(sigma) at sigma = 80 and 0.002
+        y = torch.tensor([3, 977])
+        with torch.no_grad():
+            out = net(x, t, y=y) if cc else net(x, t)
+            sig = torch.tensor([80.0, 0.3])
+            mo, den = diffusion.denoise(net, x * 5, sig, **({"y": y} if cc else {}))
+        save(f"edm_unet_forward{tag}", x=x, t=t, y=y, out=out, sigma=sig, model_output=mo, denoised=den,
+             n_params=sum(p.numel() for p in net.parameters()),
+             state_keys=np.array(list(net.state_dict().keys())),
+             state_shapes=np.array([list(v.shape) + [0] * (4 - v.dim()) for v in net.state_dict().values()]))
+        with contextlib.redirect_stdout(io.StringIO()):
+            s = ref_oa.OpenAIDiffusion(net, diffusion, n_timesteps=4, sample_shape=(3, 16, 16), class_cond=cc,
+                                       num_classes=1000 if cc else 0, trainable_beta="fix_last", stochastic_last=True, rho=4.0)
+        seed = 909
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            d = s.sample(2, device="cpu", i_class=7 if cc else None)
+        save(f"edm_sampling_T4{tag}", seed=seed, sample=d["sample"], l_sample=torch.stack(d["l_sample"]),
+             mean=torch.stack(d["mean"]), sigma=torch.stack(d["sigma"]))
+        idx = torch.tensor([0, 3])
+        torch.manual_seed(seed + 1)
+        with torch.no_grad():
+            ds = s.sample_step(x * 3, idx, **({"y": y} if cc else {}))
+        save(f"edm_sample_step_T4{tag}", seed=seed + 1, x=x * 3, idx=idx, y=y, **ds)
+
+
 GENS = {"schedule": gen_schedule, "unet": gen_unet_forward, "var_sampling": gen_var_sampling,
-        "sample_step": gen_sample_step, "value": gen_value, "trainer": gen_trainer_step}
+        "sample_step": gen_sample_step, "value": gen_value, "trainer": gen_trainer_step, "edm": gen_edm}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
