@@ -35,6 +35,33 @@ CONFIGS["cifar10_T4_ddpm_backbone"]["sampler"]["n_timesteps"] = 4
 CONFIGS["cifar10_T4_ddpm_backbone"]["trainer"].update({"value_resample": True})
 
 
+# EDM backbones (reference configs/imagenet64/T10.yaml, T4.yaml; configs/lsun/T4.yaml): `diffusion:` feeds
+# models.cm.script_util.create_model_and_diffusion, `sampler:` feeds models.DxMI.openai_diffusion.OpenAIDiffusion.
+_EDM_COMMON = {"sigma_min": 0.002, "sigma_max": 80.0, "num_res_blocks": 3, "num_heads": 4, "num_heads_upsample": -1,
+               "num_head_channels": 64, "attention_resolutions": "32,16,8", "channel_mult": "", "dropout": 0.0,
+               "use_checkpoint": False, "use_scale_shift_norm": True, "resblock_updown": True, "use_fp16": True,
+               "use_new_attention_order": False, "learn_sigma": False, "weight_schedule": "uniform", "distillation": False}
+CONFIGS["imagenet64_T10"] = {
+    "diffusion": dict(_EDM_COMMON, image_size=64, num_channels=192, class_cond=True),
+    "sampler": {"sample_shape": [3, 64, 64], "n_timesteps": 10, "class_cond": True, "num_classes": 1000,
+                "trainable_beta": "fix_last", "sigma_min": 0.002, "sigma_max": 80.0},
+    "value": _VALUE_IGEBM,
+    "training": {"pretrained_path": "pretrained/imagenet64_edm/edm_imagenet64_ema.pt", "batchsize": 128,
+                 "sampling_batchsize": 100, "seed": 42, "lr": 1e-8, "v_lr": 1e-5, "beta_lr": 1e-6},
+    "data": {"name": "imagenet64"},
+}
+CONFIGS["imagenet64_T4"] = copy.deepcopy(CONFIGS["imagenet64_T10"])
+CONFIGS["imagenet64_T4"]["sampler"].update({"n_timesteps": 4, "stochastic_last": True, "rho": 4.0})
+CONFIGS["lsun_bedroom_T4"] = {
+    "diffusion": dict(_EDM_COMMON, image_size=256, num_channels=256, class_cond=False),
+    "sampler": {"sample_shape": [3, 256, 256], "n_timesteps": 4, "class_cond": False, "num_classes": 1000,
+                "trainable_beta": "fix_last", "sigma_min": 0.002, "sigma_max": 80.0, "stochastic_last": True, "rho": 4.0},
+    "training": {"pretrained_path": "pretrained/lsun_bedroom_edm/edm_bedroom256_ema.pt", "batchsize": 16,
+                 "sampling_batchsize": 16, "seed": 42},
+    "data": {"name": "lsun_bedroom"},
+}
+
+
 def get(name):
     from dxmi_config import Cfg
     return Cfg(copy.deepcopy(CONFIGS[name]))

@@ -1,0 +1,109 @@
+"""Generate samples from an EDM-backbone DxMI sampler (ImageNet-64, LSUN-256) on MI355X; CLI-compatible with
+the reference's generate_large.py:85-190 for the generation path.
+
+    torchrun --nproc_per_node=N generate_large.py --log_dir results/imagenet64/T10/run --n_sample 50000 --batchsize 100
+
+Reads `config.yaml` + `sampler.pth` from --log_dir, builds models.cm U-Net + OpenAIDiffusion, seeds every rank
+with seed+rank (reference :103-114) and generates n_sample / batchsize / world batches per rank; --batchsize is
+PER RANK, as in the reference.  Ranks never exchange data while sampling (the reference wraps the net in DDP
+only to broadcast weights; here every rank loads the same checkpoint), so the only collective is the final
+gather of uint8 images for the FID npz.  FID itself (pytorch_fid + Inception weights + dataset statistics) is
+outside the accelerated path and runs only when those are present; --skip_fid writes PNGs as images are produced.
+`--synthetic NAME` builds the net of a built-in config with random weights (benchmark / smoke use).
+"""
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+import dxmi_config
+from generate_cifar10 import save_png
+from models.cm.script_util import create_model_and_diffusion
+from models.DxMI.openai_diffusion import OpenAIDiffusion
+from utils import mkdir_p, print0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log_dir", type=str, required=True, help="path to logdir")
+    ap.add_argument("--n_sample", type=int, required=True)
+    ap.add_argument("--batchsize", type=int, default=100)
+    ap.add_argument("--guidance_scale", type=float, default=None)
+    ap.add_argument("--skip_fid", action="store_true")
+    ap.add_argument("--synthetic", type=str, default=None, help="builtin config name, e.g. imagenet64_T10 (random weights)")
+    args, unknown = ap.parse_known_args()
+    if args.guidance_scale is not None:
+        raise NotImplementedError("value-guided sampling (--guidance_scale) is a 'next' row (SURVEY 8f)")
+
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(device)
+    if args.synthetic:
+        import configs_builtin
+        cfg = configs_builtin.get(args.synthetic)
+    else:
+        cfg = dxmi_config.load(os.path.join(args.log_dir, "config.yaml"))
+    seed = cfg.training.seed
+    torch.manual_seed(seed + local_rank)
+    np.random.seed(seed + local_rank)
+    torch.cuda.manual_seed_all(seed + local_rank)
+    random.seed(seed + local_rank)
+
+    unet, diffusion = create_model_and_diffusion(**cfg.diffusion)
+    sampler = OpenAIDiffusion(unet, diffusion, **cfg.sampler)
+    output_path = os.path.join(args.log_dir, "generated")
+    mkdir_p(output_path)
+    if not args.synthetic:
+        ckpt_path = os.path.join(args.log_dir, "sampler.pth")
+        ckpt = torch.load(ckpt_path, map_location="cpu")
+        print0(f"checkpoint loaded from {ckpt_path} (FID {ckpt.get('fid')}, iter {ckpt.get('i_iter')})")
+        sampler.net.load_state_dict(ckpt["state_dict"])
+    sampler.net.to(device)
+    if cfg.diffusion.use_fp16:
+        unet.convert_to_fp16()
+    sampler.eval()
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl", init_method="env://")  # RCCL
+
+    n_batches = int(args.n_sample / args.batchsize / world)
+    l_sample, i_img = [], 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_batches):
+        d_sample = sampler.sample(args.batchsize, device=device, i_class=None, enable_grad=False)
+        sample = d_sample["sample"]
+        if args.skip_fid:
+            sample = ((sample + 1) / 2).clamp(0, 1).cpu()
+            for s in sample:
+                save_png(s, os.path.join(output_path, f"{local_rank}_{i_img}.png"))
+                i_img += 1
+        else:
+            l_sample.append(((sample + 1) * 127.5).clamp(0, 255).to(torch.uint8))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print0(f"generated {n_batches * args.batchsize} images/rank x {world} ranks, "
+           f"{n_batches * args.batchsize / max(dt, 1e-9):.1f} images/s/rank")
+    if args.skip_fid:
+        return
+    samples = torch.cat(l_sample)
+    if world > 1:
+        gathered = [torch.zeros_like(samples) for _ in range(world)]
+        torch.distributed.all_gather(gathered, samples)
+        samples = torch.cat(gathered)
+    if local_rank == 0:
+        np.savez(os.path.join(args.log_dir, f"samples_{len(samples)}.npz"), samples.permute(0, 2, 3, 1).cpu().numpy())
+        try:
+            import pytorch_fid  # noqa: F401
+            print0("pytorch_fid found: run its fid_score on the saved npz (quality evaluation is outside the accelerated path)")
+        except ImportError:
+            print0("pytorch_fid not installed: FID skipped; samples saved as npz")
+
+
+if __name__ == "__main__":
+    main()
