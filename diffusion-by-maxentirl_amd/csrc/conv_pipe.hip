@@ -102,7 +102,9 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&ac
     }
 }
 
-template <int NB, int PMAX, int KS, int DBG = 0>  // DBG: timing-only ablations (wrong results)
+// AQ: how many steps ahead the weight fragments are requested (queue of AQ+1 fragment pairs).  Small-map layers are
+// bound by the L2 latency of those requests (4 MFMAs per step at NB=2), so they run a deeper queue.
+template <int NB, int PMAX, int KS, int DBG = 0, int AQ = 1>  // DBG: timing-only ablations (wrong results)
 __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvArgs p) {
     constexpr int CK = 32, ROWB = CK * 2 + 16, PPP = CK / 8, TAPS = KS * KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -214,22 +216,31 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
     const int wstep = p.CB * 64;  // fragments between consecutive k-steps
 
     // register sets, ping-pong by the parity of the unrolled step index
-    bf16x8 A[2][2], B[2][2][NB];
+    bf16x8 Aq[AQ + 1][2], B[2][2][NB];
     int srcA[PMAX];  // staging sources of the tile being loaded
 
     // ---- prologue: chunk 0 of the first tile into LDS image 0, operands of its first step into set 0
     tile_srcpix(pt, srcA);
     stage_load(0, srcA);
     stage_store(0);
-    A[0][0] = wfrag[0];
-    A[0][1] = wfrag[wstep];
+    const int clast = nchunks - 1;
+    // weight fragments of step f of the (chunk, tap) stream that starts at chunk c (wraps into the next tile)
+    auto load_a = [&](int c, int f, bf16x8 (&dst)[2]) {
+        int cc = c + f / TAPS;
+        cc = cc > clast ? cc - nchunks : cc;
+        cc = cc > clast ? cc - nchunks : cc;
+        const bf16x8* w0 = wfrag + (size_t)((f % TAPS) * p.KST + cc * 2) * wstep;
+        dst[0] = w0[0];
+        dst[1] = w0[wstep];
+    };
+#pragma unroll
+    for (int f = 0; f < AQ; ++f) load_a(0, f, Aq[f]);
     lds_barrier();
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) B[0][ks][nb] = *reinterpret_cast<const bf16x8*>(smem + hoff[nb] + ks * 32);
 
-    const int clast = nchunks - 1;
     for (;;) {
         const int pt_next = pt + nstreams;
         const bool more_tiles = pt_next < p.PT;
@@ -261,14 +272,8 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
                         stage_load(last_pair ? 0 : c + 2, srcA);
                     }
                 }
-                if (!(DBG & 1)) {
-                    const bf16x8* w0 = wfrag + (size_t)(tap2 * p.KST + cc2 * 2) * wstep;
-                    A[set ^ 1][0] = w0[0];
-                    A[set ^ 1][1] = w0[wstep];
-                } else {
-                    A[set ^ 1][0] = A[set][0];
-                    A[set ^ 1][1] = A[set][1];
-                }
+                if (!(DBG & 1)) load_a(c, u + AQ, Aq[AQ]);
+                else { Aq[AQ][0] = Aq[0][0]; Aq[AQ][1] = Aq[0][1]; }
                 if (tap == TAPS - 1) {
                     if (!(DBG & 2)) stage_store(half ? 0 : BUF);
                     if (!(DBG & 4)) lds_barrier();
@@ -280,8 +285,10 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
                     for (int nb = 0; nb < NB; ++nb) {
                         if (!(DBG & 8)) B[set ^ 1][ks][nb] = *reinterpret_cast<const bf16x8*>(nbase + hoff[nb] + ks * 32);
                         else B[set ^ 1][ks][nb] = B[set][ks][nb];
-                        acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[set][ks], B[set][ks][nb], acc[0][nb], 0, 0, 0);
+                        acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[0][ks], B[set][ks][nb], acc[0][nb], 0, 0, 0);
                     }
+#pragma unroll
+                for (int f = 0; f < AQ; ++f) { Aq[f][0] = Aq[f + 1][0]; Aq[f][1] = Aq[f + 1][1]; }
                 // keep the successor's operand requests INSIDE this step: without the fence the
                 // machine scheduler sinks them next to their first use and the prefetch distance is lost
                 __builtin_amdgcn_sched_barrier(0);
@@ -303,9 +310,9 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
     }
 }
 
-template <int NB, int PMAX, int KS, int DBG = 0>
+template <int NB, int PMAX, int KS, int DBG = 0, int AQ = 1>
 int launch_pipe(const ConvArgs& a, int grid, hipStream_t st) {
-    auto kern = conv_pipe_kernel<NB, PMAX, KS, DBG>;
+    auto kern = conv_pipe_kernel<NB, PMAX, KS, DBG, AQ>;
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -331,7 +338,7 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     // pixel-tile size: the largest of 256/128/64 that still gives every CU a workgroup
     const long px = (long)a.N * a.OH * a.OW;
     int NB = 8;
-    while (NB > 2 && (px / (32 * NB)) * CT < 256) NB >>= 1;
+    while (NB > 2 && (px / (32 * NB)) * CT < 512) NB >>= 1;   // two workgroups per CU
     // 128-pixel tiles (2 workgroups / CU: one's tile switch hides under the other's MFMAs) measured
     // faster than 256-pixel tiles at 1 workgroup / CU: default cap 4.
     static const int nb_cap = getenv("DXMI_CONV_NB") ? atoi(getenv("DXMI_CONV_NB")) : 4;  // tuning override
@@ -392,7 +399,11 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
             case 48: return launch_pipe<4, 6, 3, 48>(b, grid, st);
         }
     }
-#define DXMI_PIPE(NB_, PM_) (a.ksize == 3 ? launch_pipe<NB_, PM_, 3>(b, grid, st) : launch_pipe<NB_, PM_, 1>(b, grid, st))
+    static const int aq_env = getenv("DXMI_CONV_AQ") ? atoi(getenv("DXMI_CONV_AQ")) : -1;   // tuning override
+    // queue depth by shape: 3x3 at NB=2 (4x4 / 8x8 maps, latency bound) 8 ahead, 3x3 at NB=4 4 ahead (register
+    // budget of two workgroups per CU), 1x1 (short K loops, measured no gain) 1 ahead
+#define DXMI_PIPE(NB_, PM_) (a.ksize == 3 ? (aq_env == 1 ? launch_pipe<NB_, PM_, 3>(b, grid, st) : launch_pipe<NB_, PM_, 3, 0, (NB_ == 2 ? 8 : (NB_ == 4 ? 4 : 1))>(b, grid, st)) \
+                                          : launch_pipe<NB_, PM_, 1>(b, grid, st))
     if (NB == 8) return pmax == 6 ? DXMI_PIPE(8, 6) : DXMI_PIPE(8, 9);
     if (NB == 4) return pmax == 6 ? DXMI_PIPE(4, 6) : DXMI_PIPE(4, 9);
     return pmax == 6 ? DXMI_PIPE(2, 6) : DXMI_PIPE(2, 9);
