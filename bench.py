@@ -39,8 +39,22 @@ UNET_KW = dict(ch=128, out_ch=3, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_re
 def kernel_name(kid):
     """dxmi_conv2d_kernel_id -> the template instantiation name rocprofv3 prints."""
     if kid >= 10000:
-        return f"conv_pipe_kernel<{(kid // 100) % 100}, {kid % 100}, {kid // 10000}, 0>"
+        nb, ks = (kid // 100) % 100, kid // 10000
+        aq = (8 if nb == 2 else (4 if nb == 4 else 1)) if ks == 3 else 1   # queue depth chosen in conv_pipe.hip
+        return f"conv_pipe_kernel<{nb}, {kid % 100}, {ks}, 0, {aq}>"
     return f"conv_igemm_kernel<{kid // 1000}, {(kid // 100) % 10}, 32, {kid % 100}>"
+
+
+def pmc_traffic(kname):
+    """HBM-side bytes per launch of `kname` from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py);
+    PMC counters cannot be read from inside the process, so this is the profile of the same command."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"].get(kname)
+        return (k["hbm_bytes_per_launch"] if k else None), "profiles/r01_pmc_traffic.json"
+    except OSError:
+        return None, "profiles/r01_pmc_traffic.json (missing)"
 
 
 def build_sampler(device, T):
@@ -206,9 +220,12 @@ def main():
         if summ:
             kid, s = max(summ.items(), key=lambda kv: kv[1]["ms"])
             tflops = s["flops"] / (s["ms"] * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic(kernel_name(kid))
             line["roofline"] = {
                 "bound": "mfma", "achieved": tflops, "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                "frac": tflops / MFMA_BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_unit": "HBM-side bytes per launch = (2*FETCH_SIZE + WRITE_SIZE), PMC passes in " + traffic_src,
+                "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
                 "kernel": kernel_name(kid),
                 "launches": s["launches"], "avg_launch_us": 1e3 * s["ms"] / s["launches"],
                 "algorithmic_gflop_per_launch": s["flops"] / s["launches"] / 1e9,

@@ -113,9 +113,19 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // persistent schedule: this workgroup owns cout tile `cot` and pixel tiles pt0, pt0+nstreams, ...
-    const int cot = blockIdx.x % p.CT;
+    // XCD-aware: workgroups b and b+8 share an XCD (round-robin dispatch).  The CT cout tiles of one pixel-tile
+    // stream are placed on ONE XCD, adjacent in dispatch order, so the input halo they all stage is fetched from
+    // HBM / Infinity Cache once and served to the others by that XCD's L2.
     const int nstreams = gridDim.x / p.CT;
-    int pt = blockIdx.x / p.CT;
+    int cot, pt;
+    if ((nstreams & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        cot = j % p.CT;
+        pt = (j / p.CT) * 8 + xcd;
+    } else {
+        cot = blockIdx.x % p.CT;
+        pt = blockIdx.x / p.CT;
+    }
     if (pt >= p.PT) return;
 
     // the two workgroups that share a CU start in lockstep and would stay in lockstep (same tiles, same
@@ -310,6 +320,167 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 1x1 convolutions (q|k|v, proj_out, nin_shortcut / skip_connection): a step is one 32-channel chunk = 2*NB MFMAs
+// (~0.1 us), far shorter than a memory round trip, so the generic kernel's "load the next chunk during this one"
+// leaves every chunk waiting a full latency (measured 96 us for 256->768 @16x16, B=256; HBM time 33 us).
+// Here U-1 chunks are kept in flight in a static ring of register slots (U = 4 or 6 unrolled steps, Cin % (32 U) == 0),
+// across tile boundaries, and the weight fragments ride the same ring.
+template <int NB, int U>
+__global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv1x1_ring_kernel(ConvArgs p) {
+    constexpr int CK = 32, ROWB = CK * 2 + 16, PPP = CK / 8;
+    constexpr int PM = NB / 2 > 0 ? NB / 2 : 1;   // 16-byte pieces per thread per chunk (tile_px * 4 / 256)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nstreams = gridDim.x / p.CT;
+    int cot, pt;
+    if ((nstreams & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        cot = j % p.CT;
+        pt = (j / p.CT) * 8 + xcd;
+    } else {
+        cot = blockIdx.x % p.CT;
+        pt = blockIdx.x / p.CT;
+    }
+    if (pt >= p.PT) return;
+
+    const int TW = 1 << p.TWl, TH = 1 << p.THl;
+    const int txn = p.OW >> p.TWl, tyn = p.OH >> p.THl;
+    const int nchunks = (p.C0 + p.C1) / CK;   // multiple of U (host-checked)
+    const int BUF = p.lds_buf;
+
+    int hoff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) hoff[nb] = (nb * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+
+    // this thread's pieces: pixel index inside the tile (a 1x1 tile has no halo: LDS image = [tile_px][80 B])
+    const int pcol = tid % PPP;
+    auto tile_srcpix = [&](int t, int (&sp)[PM]) {
+        const int tx = t % txn;
+        const int ty = (t / txn) % tyn;
+        const int n0 = (t / (txn * tyn)) * p.SUBS;
+#pragma unroll
+        for (int q = 0; q < PM; ++q) {
+            const int pix = (tid + q * 256) / PPP;
+            const int x = pix & (TW - 1);
+            const int y = (pix >> p.TWl) & (TH - 1);
+            const int n = n0 + (pix >> (p.TWl + p.THl));
+            sp[q] = (n < p.N && pix < 32 * NB) ? (n * p.IH + (ty << p.THl) + y) * p.IW + (tx << p.TWl) + x : -1;
+        }
+    };
+    auto stage_load = [&](int c, const int (&sp)[PM], bf16x8 (&dst)[PM]) {
+        const int cbase = c * CK;
+        const bool first = cbase < p.C0;
+        const bf16* src = first ? p.in0 : p.in1;
+        const int Cs = first ? p.C0 : p.C1;
+        const int coff = (first ? cbase : cbase - p.C0) + pcol * 8;
+#pragma unroll
+        for (int q = 0; q < PM; ++q) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[q][e] = (bf16)0.f;
+            if (sp[q] >= 0) dst[q] = *reinterpret_cast<const bf16x8*>(src + (size_t)sp[q] * Cs + coff);
+        }
+    };
+    auto stage_store = [&](int buf, const bf16x8 (&src)[PM]) {
+#pragma unroll
+        for (int q = 0; q < PM; ++q) {
+            const int pix = (tid + q * 256) / PPP;
+            if (pix < 32 * NB) *reinterpret_cast<bf16x8*>(smem + buf + pix * ROWB + pcol * 16) = src[q];
+        }
+    };
+
+    f32x16 acc[1][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
+
+    const int cb0 = cot * 4 + wave;
+    const int cbw = cb0 < p.CB ? cb0 : p.CB - 1;
+    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(p.w) + (size_t)cbw * 64 + lane;
+    const int wstep = p.CB * 64;
+    auto load_a = [&](int c, bf16x8 (&dst)[2]) {
+        const bf16x8* w0 = wfrag + (size_t)(c * 2) * wstep;
+        dst[0] = w0[0];
+        dst[1] = w0[wstep];
+    };
+
+    bf16x8 stg[U][PM], Aq[U][2], B[2][2][NB];
+    int srcA[PM];
+
+    // ---- prologue: chunks 0..U-1 of the first tile requested, chunk 0 written to image 0
+    tile_srcpix(pt, srcA);
+#pragma unroll
+    for (int j = 0; j < U; ++j) stage_load(j, srcA, stg[j]);
+#pragma unroll
+    for (int j = 0; j < U; ++j) load_a(j, Aq[j]);
+    stage_store(0, stg[0]);
+    lds_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) B[0][ks][nb] = *reinterpret_cast<const bf16x8*>(smem + hoff[nb] + ks * 32);
+
+    for (;;) {
+        const int pt_next = pt + nstreams;
+        const bool more_tiles = pt_next < p.PT;
+        for (int c = 0; c < nchunks; c += U) {
+            const bool last_iter = c + U >= nchunks;
+            // chunks requested during this iteration: c+U+j of this tile, or (last iteration) chunk j of the next tile
+            if (last_iter) tile_srcpix(more_tiles ? pt_next : pt, srcA);   // uniform branch, no memory operations
+            const int cl = last_iter ? 0 : c + U;
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int set = j & 1;
+                // chunk c+j+1 (slot (j+1)%U; requested U-1 steps ago) -> the other LDS image
+                stage_store(set ? 0 : BUF, stg[(j + 1) % U]);
+                lds_barrier();
+                // slot j is free (its chunk was written one step ago): request the chunk U steps ahead
+                stage_load(cl + j, srcA, stg[j]);
+                if (j > 0) load_a(cl + j - 1, Aq[j - 1]);   // weights of step c+U+j-1: slot of the step just issued
+                const char* nbase = smem + (set ? 0 : BUF);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        B[set ^ 1][ks][nb] = *reinterpret_cast<const bf16x8*>(nbase + hoff[nb] + ks * 32);
+                        acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[j][ks], B[set][ks][nb], acc[0][nb], 0, 0, 0);
+                    }
+                if (j == U - 1) load_a(cl + U - 1, Aq[U - 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        {
+            const int tx = pt % txn;
+            const int ty = (pt / txn) % tyn;
+            const int n0 = (pt / (txn * tyn)) * p.SUBS;
+            conv_epilogue_lds<NB>(p, acc, smem + 2 * BUF, n0, ty << p.THl, tx << p.TWl, cot, wave, lane, tid);
+        }
+        if (!more_tiles) break;
+        pt = pt_next;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
+    }
+}
+
+template <int NB, int U>
+int launch_ring(const ConvArgs& a, int grid, hipStream_t st) {
+    auto kern = conv1x1_ring_kernel<NB, U>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), (size_t)2 * a.lds_buf + EPI_BYTES, st, a);
+    DXMI_CHECK_LAUNCH("dxmi_conv2d_fwd(1x1 ring)");
+    return DXMI_OK;
+}
+
 template <int NB, int PMAX, int KS, int DBG = 0, int AQ = 1>
 int launch_pipe(const ConvArgs& a, int grid, hipStream_t st) {
     auto kern = conv_pipe_kernel<NB, PMAX, KS, DBG, AQ>;
@@ -384,6 +555,7 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     const int resident = 256 * (wg_per_cu > 0 ? wg_per_cu : (NB <= 4 ? 2 : 1));
     int nstreams = resident / CT;
     if (nstreams > b.PT) nstreams = b.PT;
+    if (nstreams >= 8) nstreams &= ~7;   // whole XCD groups (see the kernel's block mapping)
     if (nstreams < 1) nstreams = 1;
     const int grid = nstreams * CT;
     static const int stagger = getenv("DXMI_CONV_STAGGER") ? atoi(getenv("DXMI_CONV_STAGGER")) : 0;
@@ -397,6 +569,16 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
             case 16: return launch_pipe<4, 6, 3, 16>(b, grid, st);
             case 32: return launch_pipe<4, 6, 3, 32>(b, grid, st);
             case 48: return launch_pipe<4, 6, 3, 48>(b, grid, st);
+        }
+    }
+    static const int ring_env = getenv("DXMI_CONV_RING") ? atoi(getenv("DXMI_CONV_RING")) : 1;   // tuning override
+    if (a.ksize == 1 && a.ups == 0 && ring_env && NB <= 4) {
+        const int nch = (a.C0 + a.C1) / 32;
+        const int U = nch % 4 == 0 ? 4 : (nch % 6 == 0 ? 6 : 0);
+        if (U) {
+            b.lds_buf = tile * 80;   // no halo: [tile_px][80 B]
+            if (NB == 4) return U == 4 ? launch_ring<4, 4>(b, grid, st) : launch_ring<4, 6>(b, grid, st);
+            return U == 4 ? launch_ring<2, 4>(b, grid, st) : launch_ring<2, 6>(b, grid, st);
         }
     }
     static const int aq_env = getenv("DXMI_CONV_AQ") ? atoi(getenv("DXMI_CONV_AQ")) : -1;   // tuning override

@@ -181,43 +181,45 @@ struct GnGenArgs {
 };
 
 __global__ __launch_bounds__(256) void gn_gen_stats_kernel(GnGenArgs p) {
-    __shared__ float sm[2][32];
+    // threads = (256 / c8n) rows x c8n pieces: every thread keeps the running sum / sum of squares of its 8 channels
+    // over its rows, then one thread per group adds the per-channel partials in a fixed order (bitwise reproducible).
+    __shared__ float sm[2][256 * 8];
     const int C = p.C0 + p.C1, c8n = C / 8;
     const int n = blockIdx.x / p.chunks, chunk = blockIdx.x % p.chunks;
     const int tid = threadIdx.x;
-    if (tid < 64) sm[tid >> 5][tid & 31] = 0.f;
-    __syncthreads();
+    const int rows_par = 256 / c8n;
+    const int pc = tid % c8n, rl = tid / c8n;
     const int row0 = chunk * p.rows_per_chunk;
     const int row1 = min(row0 + p.rows_per_chunk, p.HW);
-    const long npieces = (long)(row1 - row0) * c8n;
-    float s[2] = {0.f, 0.f}, q[2] = {0.f, 0.f};  // a piece of 8 channels touches at most 2 groups when cpg >= 8... general: flush per element
-    for (long i = tid; i < npieces; i += 256) {
-        const int r = row0 + (int)(i / c8n), pc = (int)(i % c8n);
+    float ls[8], lq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ls[e] = 0.f; lq[e] = 0.f; }
+    if (rl < rows_par) {
         const int c = pc * 8;
         const bool from0 = c < p.C0;
-        const bf16* src = from0 ? p.in0 + ((size_t)n * p.HW + r) * p.C0 + c : p.in1 + ((size_t)n * p.HW + r) * p.C1 + (c - p.C0);
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
-        int gcur = c / p.cpg;
-        float ls = 0.f, lq = 0.f;
+        const bf16* src = from0 ? p.in0 + (size_t)n * p.HW * p.C0 + c : p.in1 + (size_t)n * p.HW * p.C1 + (c - p.C0);
+        const int Cs = from0 ? p.C0 : p.C1;
+        for (int r = row0 + rl; r < row1; r += rows_par) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)r * Cs);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = (float)v[e];
+                ls[e] += f; lq[e] += f * f;
+            }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int g = (c + e) / p.cpg;
-            if (g != gcur) {
-                atomicAdd(&sm[0][gcur], ls);
-                atomicAdd(&sm[1][gcur], lq);
-                ls = 0.f; lq = 0.f; gcur = g;
-            }
-            const float f = (float)v[e];
-            ls += f; lq += f * f;
+            sm[0][rl * C + pc * 8 + e] = ls[e];
+            sm[1][rl * C + pc * 8 + e] = lq[e];
         }
-        atomicAdd(&sm[0][gcur], ls);
-        atomicAdd(&sm[1][gcur], lq);
     }
-    (void)s; (void)q;
     __syncthreads();
     if (tid < 2 * p.groups) {
         const int g = tid % p.groups, w = tid / p.groups;
-        p.part[(((size_t)n * p.chunks + chunk) * p.groups + g) * 2 + w] = sm[w][g];
+        float t = 0.f;
+        for (int r = 0; r < rows_par; ++r)
+            for (int c = g * p.cpg; c < (g + 1) * p.cpg; ++c) t += sm[w][r * C + c];
+        p.part[(((size_t)n * p.chunks + chunk) * p.groups + g) * 2 + w] = t;
     }
 }
 
@@ -552,7 +554,7 @@ extern "C" int dxmi_groupnorm_generic_fwd(const void* in0, int32_t C0, const voi
                                           int32_t apply_silu, void* stream) {
     DXMI_CHECK_ARG(in0 && out && gamma && beta && workspace, "dxmi_groupnorm_generic_fwd: null pointer");
     const int C = C0 + C1;
-    DXMI_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0 && C0 % 8 == 0 && C1 % 8 == 0 && (C1 == 0 || in1),
+    DXMI_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0 && C0 % 8 == 0 && C1 % 8 == 0 && (C1 == 0 || in1) && C <= 2048,
                    "dxmi_groupnorm_generic_fwd: C0=%d C1=%d groups=%d", C0, C1, groups);
     GnGenArgs a;
     a.in0 = (const bf16*)in0; a.in1 = (const bf16*)in1; a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.ss_ld = ss_ld;
