@@ -189,12 +189,23 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restr
         for (int e = 0; e < 8; ++e) part[(size_t)blockIdx.x * C + threadIdx.x * 8 + e] = t[e];
     }
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int C, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// 16 channels per workgroup, 16 row-lanes per channel: every lane adds its strided share of the partial rows, then one
+// lane per channel adds the 16 lane sums in lane order (fixed order -> bitwise reproducible).
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int C, int accumulate) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
-    for (int k = 0; k < nblocks; ++k) s += part[(size_t)k * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C)
+        for (int k = rl; k < nblocks; k += 16) s += part[(size_t)k * C + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][cl];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 int ilog2w(int v) {
@@ -271,7 +282,7 @@ extern "C" int dxmi_colsum_bf16(const void* x, float* out, void* workspace, int6
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks), dim3(cthreads), 0, st, (const bf16*)x, (float*)workspace, (long)P, C,
                        rows_per_block);
     DXMI_CHECK_LAUNCH("dxmi_colsum_bf16");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)workspace, out, nblocks, C,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)workspace, out, nblocks, C,
                        accumulate);
     DXMI_CHECK_LAUNCH("dxmi_colsum_bf16(final)");
     return DXMI_OK;

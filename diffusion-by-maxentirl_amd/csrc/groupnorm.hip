@@ -224,6 +224,9 @@ __global__ __launch_bounds__(256) void gn_gen_stats_kernel(GnGenArgs p) {
 }
 
 __global__ __launch_bounds__(256) void gn_gen_apply_kernel(GnGenArgs p) {
+    // same thread layout as the statistics kernel: a thread owns one 8-channel piece column and strides over rows, so
+    // the per-channel affine (rstd*gamma, beta - mean*rstd*gamma, FiLM scale/shift folded in) is computed once and
+    // the row loop is one FMA (+ SiLU) per element, no integer division.
     __shared__ float mean_s[32], rstd_s[32];
     const int C = p.C0 + p.C1, c8n = C / 8;
     const int n = blockIdx.x / p.chunks, chunk = blockIdx.x % p.chunks;
@@ -241,25 +244,39 @@ __global__ __launch_bounds__(256) void gn_gen_apply_kernel(GnGenArgs p) {
         rstd_s[tid] = rsqrtf(var + p.eps);
     }
     __syncthreads();
+    const int rows_par = 256 / c8n;
+    const int pc = tid % c8n, rl = tid / c8n;
+    if (rl >= rows_par) return;
+    const int c = pc * 8;
+    float A[8], Bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / p.cpg;
+        float a = rstd_s[g] * p.gamma[c + e];
+        float b = p.beta[c + e] - mean_s[g] * a;
+        if (p.ss) {
+            const float sc = 1.f + p.ss[(size_t)n * p.ss_ld + c + e];
+            a *= sc;
+            b = b * sc + p.ss[(size_t)n * p.ss_ld + C + c + e];
+        }
+        A[e] = a; Bv[e] = b;
+    }
+    const bool from0 = c < p.C0;
+    const bf16* src = from0 ? p.in0 + (size_t)n * p.HW * p.C0 + c : p.in1 + (size_t)n * p.HW * p.C1 + (c - p.C0);
+    const int Cs = from0 ? p.C0 : p.C1;
+    bf16* dst = p.out + (size_t)n * p.HW * C + c;
     const int row0 = chunk * p.rows_per_chunk;
     const int row1 = min(row0 + p.rows_per_chunk, p.HW);
-    const long npieces = (long)(row1 - row0) * c8n;
-    for (long i = tid; i < npieces; i += 256) {
-        const int r = row0 + (int)(i / c8n), pc = (int)(i % c8n);
-        const int c = pc * 8;
-        const bool from0 = c < p.C0;
-        const bf16* src = from0 ? p.in0 + ((size_t)n * p.HW + r) * p.C0 + c : p.in1 + ((size_t)n * p.HW + r) * p.C1 + (c - p.C0);
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src);
+    for (int r = row0 + rl; r < row1; r += rows_par) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)r * Cs);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int g = (c + e) / p.cpg;
-            float y = ((float)v[e] - mean_s[g]) * rstd_s[g] * p.gamma[c + e] + p.beta[c + e];
-            if (p.ss) y = y * (1.f + p.ss[(size_t)n * p.ss_ld + c + e]) + p.ss[(size_t)n * p.ss_ld + C + c + e];
+            float y = (float)v[e] * A[e] + Bv[e];
             if (p.silu) y = y / (1.f + __expf(-y));
             o[e] = (bf16)y;
         }
-        *reinterpret_cast<bf16x8*>(p.out + ((size_t)n * p.HW + r) * C + c) = o;
+        *reinterpret_cast<bf16x8*>(dst + (size_t)r * C) = o;
     }
 }
 
