@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
         const int x = pix & (TW - 1);
         const int y = (pix >> p.TWl) & (TH - 1);
         const int sub = pix >> (p.TWl + p.THl);
-        hoff[nb] = sub * p.SP + y * p.RP + x * ROWB + (lane >> 5) * 16;
+        hoff[nb] = sub * p.SP + (y * p.RP + x * ROWB) * p.stride + (lane >> 5) * 16;   // stride 1 or 2
     }
 
     // per-piece halo geometry (tile independent): packed (sub, hy, hx) and the LDS byte offset
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
         for (int q = 0; q < PMAX; ++q) {
             const int gq = geo[q];
             const int n = n0 + (gq >> 20);
-            const int iy = oy0 - p.pad + ((gq >> 10) & 1023);
-            const int ix = ox0 - p.pad + (gq & 1023);
+            const int iy = oy0 * p.stride - p.pad + ((gq >> 10) & 1023);
+            const int ix = ox0 * p.stride - p.pad + (gq & 1023);
             const int sh = p.ups ? 1 : 0;  // ups 1: nearest x2 ; ups 2: zero-stuffed x2 (stride-2 data gradient)
             const bool ok = gq >= 0 && iy >= 0 && ix >= 0 && iy < (p.IH << sh) && ix < (p.IW << sh) && n < p.N &&
                             (p.ups != 2 || (((iy | ix) & 1) == 0));
@@ -504,7 +504,8 @@ int ilog2p(int v) {
 
 int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     if (a.in_mode != DXMI_IN_NHWC_BF16 || a.out_mode != DXMI_OUT_NHWC_BF16) return 1;
-    if (a.stride != 1 || a.Cout % 64 != 0 || (a.C0 + a.C1) % 64 != 0 || a.C0 % 32 != 0) return 1;  // even chunk count
+    if (a.Cout % 64 != 0 || (a.C0 + a.C1) % 64 != 0 || a.C0 % 32 != 0) return 1;  // even chunk count
+    if (a.stride != 1 && !(a.stride == 2 && a.ups == 0 && a.ksize == 3)) return 1;   // stride 2: Downsample convs
     const int CT = (a.Cout + 127) / 128;
     // pixel-tile size: the largest of 256/128/64 that still gives every CU a workgroup
     const long px = (long)a.N * a.OH * a.OW;
@@ -514,6 +515,7 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     // faster than 256-pixel tiles at 1 workgroup / CU: default cap 4.
     static const int nb_cap = getenv("DXMI_CONV_NB") ? atoi(getenv("DXMI_CONV_NB")) : 4;  // tuning override
     while (NB > nb_cap && NB > 2) NB >>= 1;
+    if (a.stride == 2) NB = 2;   // the stride-2 halo of a 64-pixel tile is 17x17 pixels (23 KB)
     const int tile = 32 * NB;
     const int TW = a.OW < 32 ? a.OW : 32;
     int TH = tile / TW;
@@ -522,7 +524,7 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     if (TW * TH * SUBS != tile) return 1;
     ConvArgs b = a;
     b.TWl = ilog2p(TW); b.THl = ilog2p(TH); b.SUBS = SUBS;
-    b.HH = TH + a.ksize - 1; b.HWd = TW + a.ksize - 1;
+    b.HH = (TH - 1) * a.stride + a.ksize; b.HWd = (TW - 1) * a.stride + a.ksize;
     b.tile_px = tile;
     const int ngroups = (a.N + SUBS - 1) / SUBS;
     b.PT = ngroups * (a.OH / TH) * (a.OW / TW);
