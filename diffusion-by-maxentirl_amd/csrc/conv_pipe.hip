@@ -547,8 +547,15 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     const int npieces = HP * 4;
     const int pmax = npieces <= 6 * 256 ? 6 : (npieces <= 9 * 256 ? 9 : 0);
     if (!pmax) return 1;
+    static const int ring_env = getenv("DXMI_CONV_RING") ? atoi(getenv("DXMI_CONV_RING")) : 1;   // tuning override
+    int ringU = 0;
+    if (a.ksize == 1 && a.ups == 0 && ring_env && NB <= 4) {
+        const int nch = (a.C0 + a.C1) / 32;
+        ringU = nch % 4 == 0 ? 4 : (nch % 6 == 0 ? 6 : 0);
+    }
     if (kernel_id) {
-        *kernel_id = 10000 * a.ksize + NB * 100 + pmax;  // kxxyy = conv_pipe_kernel<xx, yy, k>
+        // kxxyy = conv_pipe_kernel<xx, yy, k> ; 2000xu = conv1x1_ring_kernel<x, u>
+        *kernel_id = ringU ? 200000 + NB * 10 + ringU : 10000 * a.ksize + NB * 100 + pmax;
         return DXMI_OK;
     }
     // persistent grid: as many workgroups as are co-resident (2 per CU for NB <= 4, else 1), a
@@ -573,15 +580,10 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
             case 48: return launch_pipe<4, 6, 3, 48>(b, grid, st);
         }
     }
-    static const int ring_env = getenv("DXMI_CONV_RING") ? atoi(getenv("DXMI_CONV_RING")) : 1;   // tuning override
-    if (a.ksize == 1 && a.ups == 0 && ring_env && NB <= 4) {
-        const int nch = (a.C0 + a.C1) / 32;
-        const int U = nch % 4 == 0 ? 4 : (nch % 6 == 0 ? 6 : 0);
-        if (U) {
-            b.lds_buf = tile * 80;   // no halo: [tile_px][80 B]
-            if (NB == 4) return U == 4 ? launch_ring<4, 4>(b, grid, st) : launch_ring<4, 6>(b, grid, st);
-            return U == 4 ? launch_ring<2, 4>(b, grid, st) : launch_ring<2, 6>(b, grid, st);
-        }
+    if (ringU) {
+        b.lds_buf = tile * 80;   // no halo: [tile_px][80 B]
+        if (NB == 4) return ringU == 4 ? launch_ring<4, 4>(b, grid, st) : launch_ring<4, 6>(b, grid, st);
+        return ringU == 4 ? launch_ring<2, 4>(b, grid, st) : launch_ring<2, 6>(b, grid, st);
     }
     static const int aq_env = getenv("DXMI_CONV_AQ") ? atoi(getenv("DXMI_CONV_AQ")) : -1;   // tuning override
     // queue depth by shape: 3x3 at NB=2 (4x4 / 8x8 maps, latency bound) 8 ahead, 3x3 at NB=4 4 ahead (register
