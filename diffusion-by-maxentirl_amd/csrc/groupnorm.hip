@@ -587,6 +587,185 @@ extern "C" int dxmi_groupnorm_generic_fwd(const void* in0, int32_t C0, const voi
     return DXMI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Generic GroupNorm(+FiLM scale-shift)(+SiLU) backward for the shapes of the generic forward (any channels per group,
+// any map size).  With ga = gamma*(1+scale), be = beta*(1+scale)+shift (per image and channel; scale = shift = 0
+// without FiLM):  xh = (x-mean)*rstd ; y = xh*ga + be ; z = silu(y) | y ; dyy = dz * silu'(y)
+//   G0[n,c] = sum_px dyy ; G1[n,c] = sum_px dyy*xh                       (returned: the host folds them into
+//   dgamma, dbeta, dscale, dshift — a few [N,C] element-wise ops)
+//   dx = rstd * (ga*dyy - mean_grp(ga*dyy) - xh * mean_grp(ga*dyy*xh))   (+ optional additive inputs add0 | add1)
+// Three launches: the forward statistics kernel (mean, rstd), a per-(image, row-chunk) partial reduction of G0/G1 in a
+// fixed order, and the apply pass.  Thread layout as in the forward (one 8-channel piece column per thread).
+struct GnGenBwdArgs {
+    const bf16* in0;
+    const bf16* in1;
+    const bf16* dy;
+    const bf16* add0;
+    const bf16* add1;
+    const float* gamma;
+    const float* beta;
+    const float* ss;
+    bf16* dx0;
+    bf16* dx1;
+    const float* part;   // forward statistics partials [N][chunks][groups][2]
+    float* gpart;        // [N][chunks][C][2]
+    float* g_out;        // [2][N][C]: G0 then G1
+    int C0, C1, HW, groups, cpg, chunks, rows_per_chunk, ss_ld, N;
+    float eps;
+    int silu;
+};
+
+__device__ __forceinline__ void gn_gen_group_stats(const GnGenBwdArgs& p, int n, float* mean_s, float* rstd_s) {
+    const int tid = threadIdx.x;
+    if (tid < p.groups) {
+        float s = 0.f, q = 0.f;
+        for (int k = 0; k < p.chunks; ++k) {
+            s += p.part[(((size_t)n * p.chunks + k) * p.groups + tid) * 2 + 0];
+            q += p.part[(((size_t)n * p.chunks + k) * p.groups + tid) * 2 + 1];
+        }
+        const float cnt = (float)p.HW * p.cpg;
+        const float m = s / cnt;
+        mean_s[tid] = m;
+        rstd_s[tid] = rsqrtf(fmaxf(q / cnt - m * m, 0.f) + p.eps);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float gn_dsilu(float y) {
+    const float sg = 1.f / (1.f + __expf(-y));
+    return sg * (1.f + y * (1.f - sg));
+}
+
+__global__ __launch_bounds__(256) void gn_gen_bwd_reduce_kernel(GnGenBwdArgs p) {
+    __shared__ float mean_s[32], rstd_s[32];
+    __shared__ float sm[2][256 * 8];
+    const int C = p.C0 + p.C1, c8n = C / 8;
+    const int n = blockIdx.x / p.chunks, chunk = blockIdx.x % p.chunks;
+    const int tid = threadIdx.x;
+    gn_gen_group_stats(p, n, mean_s, rstd_s);
+    const int rows_par = 256 / c8n;
+    const int pc = tid % c8n, rl = tid / c8n;
+    const int c = pc * 8;
+    if (rl < rows_par) {
+        float A[8], Bv[8], s0[8], s1[8], mu[8], rs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / p.cpg;
+            mu[e] = mean_s[g]; rs[e] = rstd_s[g];
+            float ga = p.gamma[c + e], be = p.beta[c + e];
+            if (p.ss) {
+                const float sc = 1.f + p.ss[(size_t)n * p.ss_ld + c + e];
+                ga *= sc;
+                be = be * sc + p.ss[(size_t)n * p.ss_ld + C + c + e];
+            }
+            A[e] = ga; Bv[e] = be; s0[e] = 0.f; s1[e] = 0.f;
+        }
+        const bool from0 = c < p.C0;
+        const bf16* src = from0 ? p.in0 + (size_t)n * p.HW * p.C0 + c : p.in1 + (size_t)n * p.HW * p.C1 + (c - p.C0);
+        const int Cs = from0 ? p.C0 : p.C1;
+        const bf16* dyp = p.dy + (size_t)n * p.HW * C + c;
+        const int row0 = chunk * p.rows_per_chunk;
+        const int row1 = min(row0 + p.rows_per_chunk, p.HW);
+        for (int r = row0 + rl; r < row1; r += rows_par) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)r * Cs);
+            const bf16x8 d = *reinterpret_cast<const bf16x8*>(dyp + (size_t)r * C);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = ((float)v[e] - mu[e]) * rs[e];
+                float dyy = (float)d[e];
+                if (p.silu) dyy *= gn_dsilu(xh * A[e] + Bv[e]);
+                s0[e] += dyy; s1[e] += dyy * xh;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sm[0][rl * C + c + e] = s0[e];
+            sm[1][rl * C + c + e] = s1[e];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * C; i += 256) {
+        const int w = i / C, cc = i % C;
+        float t = 0.f;
+        for (int r = 0; r < rows_par; ++r) t += sm[w][r * C + cc];
+        p.gpart[(((size_t)n * p.chunks + chunk) * C + cc) * 2 + w] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_gen_bwd_apply_kernel(GnGenBwdArgs p) {
+    __shared__ float mean_s[32], rstd_s[32], m1_s[32], m2_s[32];
+    __shared__ float gsum[2][2048];
+    const int C = p.C0 + p.C1, c8n = C / 8;
+    const int n = blockIdx.x / p.chunks, chunk = blockIdx.x % p.chunks;
+    const int tid = threadIdx.x;
+    gn_gen_group_stats(p, n, mean_s, rstd_s);
+    for (int i = tid; i < 2 * C; i += 256) {
+        const int w = i / C, cc = i % C;
+        float t = 0.f;
+        for (int k = 0; k < p.chunks; ++k) t += p.gpart[(((size_t)n * p.chunks + k) * C + cc) * 2 + w];
+        gsum[w][cc] = t;
+        if (chunk == 0) p.g_out[((size_t)w * p.N + n) * C + cc] = t;
+    }
+    __syncthreads();
+    if (tid < p.groups) {
+        float a = 0.f, b = 0.f;
+        for (int cc = tid * p.cpg; cc < (tid + 1) * p.cpg; ++cc) {
+            float ga = p.gamma[cc];
+            if (p.ss) ga *= 1.f + p.ss[(size_t)n * p.ss_ld + cc];
+            a += ga * gsum[0][cc];
+            b += ga * gsum[1][cc];
+        }
+        const float cnt = (float)p.HW * p.cpg;
+        m1_s[tid] = a / cnt;
+        m2_s[tid] = b / cnt;
+    }
+    __syncthreads();
+    const int rows_par = 256 / c8n;
+    const int pc = tid % c8n, rl = tid / c8n;
+    if (rl >= rows_par) return;
+    const int c = pc * 8;
+    float A[8], Bv[8], mu[8], rs[8], m1[8], m2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / p.cpg;
+        mu[e] = mean_s[g]; rs[e] = rstd_s[g]; m1[e] = m1_s[g]; m2[e] = m2_s[g];
+        float ga = p.gamma[c + e], be = p.beta[c + e];
+        if (p.ss) {
+            const float sc = 1.f + p.ss[(size_t)n * p.ss_ld + c + e];
+            ga *= sc;
+            be = be * sc + p.ss[(size_t)n * p.ss_ld + C + c + e];
+        }
+        A[e] = ga; Bv[e] = be;
+    }
+    const bool from0 = c < p.C0;
+    const int Cs = from0 ? p.C0 : p.C1;
+    const size_t soff = (size_t)n * p.HW * Cs + (from0 ? c : c - p.C0);
+    const bf16* src = (from0 ? p.in0 : p.in1) + soff;
+    const bf16* add = from0 ? p.add0 : p.add1;
+    if (add) add += soff;
+    bf16* dst = (from0 ? p.dx0 : p.dx1) + soff;
+    const bf16* dyp = p.dy + (size_t)n * p.HW * C + c;
+    const int row0 = chunk * p.rows_per_chunk;
+    const int row1 = min(row0 + p.rows_per_chunk, p.HW);
+    for (int r = row0 + rl; r < row1; r += rows_par) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)r * Cs);
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dyp + (size_t)r * C);
+        bf16x8 av;
+        if (add) av = *reinterpret_cast<const bf16x8*>(add + (size_t)r * Cs);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = ((float)v[e] - mu[e]) * rs[e];
+            float dyy = (float)d[e];
+            if (p.silu) dyy *= gn_dsilu(xh * A[e] + Bv[e]);
+            float dx = rs[e] * (A[e] * dyy - m1[e] - xh * m2[e]);
+            if (add) dx += (float)av[e];
+            o[e] = (bf16)dx;
+        }
+        *reinterpret_cast<bf16x8*>(dst + (size_t)r * Cs) = o;
+    }
+}
+
 // 1 when the one-pass register-resident kernel (dxmi_groupnorm_silu_fwd) can serve the shape, else 0
 // (callers then use dxmi_groupnorm_generic_fwd).  Same slicing walk as the launcher below.
 extern "C" int dxmi_groupnorm_silu_supported(int32_t C0, int32_t C1, int32_t HW, int32_t groups) {
@@ -646,4 +825,41 @@ extern "C" int dxmi_groupnorm_silu_fwd(const void* in0, int32_t C0, const void* 
     a.fast = (ppp <= 64) && ((ppp & (ppp - 1)) == 0) && ((ppt & (ppt - 1)) == 0);
     hipStream_t st = (hipStream_t)stream;
     return VEC == 8 ? launch_gn<8>(a, N, pieces, threads, st) : launch_gn<4>(a, N, pieces, threads, st);
+}
+
+extern "C" int64_t dxmi_groupnorm_generic_bwd_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
+    const int chunks = HW >= 1024 ? 16 : (HW >= 256 ? 4 : 1);
+    return (int64_t)N * chunks * 32 * 2 * 4 + (int64_t)N * chunks * C * 2 * 4;
+}
+
+// g_out: fp32 [2][N][C] (G0, G1 above).  dx1 / add0 / add1 / scale_shift may be NULL.
+extern "C" int dxmi_groupnorm_generic_bwd(const void* in0, int32_t C0, const void* in1, int32_t C1, const void* dy,
+                                          const void* add0, const void* add1, const float* gamma, const float* beta,
+                                          const float* scale_shift, int32_t ss_ld, void* dx0, void* dx1, float* g_out,
+                                          void* workspace, int32_t N, int32_t HW, int32_t groups, float eps,
+                                          int32_t apply_silu, void* stream) {
+    DXMI_CHECK_ARG(in0 && dy && gamma && beta && dx0 && g_out && workspace, "dxmi_groupnorm_generic_bwd: null pointer");
+    const int C = C0 + C1;
+    DXMI_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0 && C0 % 8 == 0 && C1 % 8 == 0 && (C1 == 0 || (in1 && dx1)) && C <= 2048,
+                   "dxmi_groupnorm_generic_bwd: C0=%d C1=%d groups=%d", C0, C1, groups);
+    const int chunks = HW >= 1024 ? 16 : (HW >= 256 ? 4 : 1);
+    float* part = (float*)workspace;
+    GnGenArgs f;
+    f.in0 = (const bf16*)in0; f.in1 = (const bf16*)in1; f.gamma = gamma; f.beta = beta; f.ss = scale_shift; f.ss_ld = ss_ld;
+    f.out = nullptr; f.part = part; f.C0 = C0; f.C1 = C1; f.HW = HW; f.groups = groups; f.cpg = C / groups;
+    f.chunks = chunks; f.rows_per_chunk = (HW + chunks - 1) / chunks; f.eps = eps; f.silu = apply_silu;
+    GnGenBwdArgs a;
+    a.in0 = (const bf16*)in0; a.in1 = (const bf16*)in1; a.dy = (const bf16*)dy; a.add0 = (const bf16*)add0; a.add1 = (const bf16*)add1;
+    a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.dx0 = (bf16*)dx0; a.dx1 = (bf16*)dx1; a.part = part;
+    a.gpart = part + (size_t)N * chunks * 32 * 2; a.g_out = g_out;
+    a.C0 = C0; a.C1 = C1; a.HW = HW; a.groups = groups; a.cpg = C / groups; a.chunks = chunks; a.rows_per_chunk = f.rows_per_chunk;
+    a.ss_ld = ss_ld; a.N = N; a.eps = eps; a.silu = apply_silu;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_gen_stats_kernel, dim3(N * chunks), dim3(256), 0, st, f);
+    DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_bwd(stats)");
+    hipLaunchKernelGGL(gn_gen_bwd_reduce_kernel, dim3(N * chunks), dim3(256), 0, st, a);
+    DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_bwd(reduce)");
+    hipLaunchKernelGGL(gn_gen_bwd_apply_kernel, dim3(N * chunks), dim3(256), 0, st, a);
+    DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_bwd(apply)");
+    return DXMI_OK;
 }

@@ -324,6 +324,30 @@ def groupnorm_generic(x, gamma, beta, *, in1=None, groups=32, eps=1e-5, silu=Tru
     return out
 
 
+def groupnorm_generic_bwd(x, dy, gamma, beta, *, in1=None, add0=None, add1=None, groups=32, eps=1e-5, silu=True, scale_shift=None):
+    """-> (dx0, dx1 | None, dgamma [C], dbeta [C], d_scale_shift [N, 2C] | None)."""
+    _need_cuda(x, in1, dy, add0, add1, gamma, beta, scale_shift)
+    N, H, W, C0 = x.shape
+    C1 = in1.shape[3] if in1 is not None else 0
+    C = C0 + C1
+    assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and tuple(dy.shape) == (N, H, W, C)
+    dx0 = torch.empty_like(x)
+    dx1 = torch.empty_like(in1) if in1 is not None else None
+    g = torch.empty((2, N, C), dtype=torch.float32, device=x.device)
+    ss_ld = scale_shift.stride(0) if scale_shift is not None else 0
+    lib = load()
+    ws = _workspace(lib.dxmi_groupnorm_generic_bwd_workspace_bytes(N, H * W, C), x.device)
+    check(lib.dxmi_groupnorm_generic_bwd(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(add0), _ptr(add1), _ptr(gamma), _ptr(beta),
+                                         _ptr(scale_shift), ss_ld, _ptr(dx0), _ptr(dx1), _ptr(g), _ptr(ws), N, H * W, groups,
+                                         float(eps), int(silu), _stream()), "dxmi_groupnorm_generic_bwd")
+    g0, g1 = g[0], g[1]
+    if scale_shift is None:
+        return dx0, dx1, g1.sum(0), g0.sum(0), None
+    one_s = 1.0 + scale_shift[:, :C]
+    d_ss = torch.cat([g1 * gamma + g0 * beta, g0], 1)
+    return dx0, dx1, (g1 * one_s).sum(0), (g0 * one_s).sum(0), d_ss
+
+
 def upsample2x(x, out=None):
     _need_cuda(x, out)
     N, H, W, C = x.shape

@@ -13,7 +13,8 @@ bf16 activations (the reference runs this torso in fp16, use_fp16: True in confi
   * 3x3 / 1x1 MFMA convs with bias, residual and the skip concat (th.cat([h, hs.pop()]), :786) fused;
     ResBlock(up) feeds the conv through its nearest-x2 staging, ResBlock(down) through a 2x2 mean kernel;
   * QKVAttentionLegacy (:401-441; channel layout "(three h d)") as one flash-style MFMA kernel per block.
-No CPU path: non-device tensors raise.  convert_to_fp16/convert_to_fp32 are accepted and change nothing
+No CPU path: non-device tensors raise.  With grad enabled forward() goes through models/cm/unet_train.py (HIP backward).
+convert_to_fp16/convert_to_fp32 are accepted and change nothing
 (storage is bf16, masters fp32).
 """
 import math
@@ -257,7 +258,8 @@ class UNetModel(nn.Module):
         if not x.is_cuda:
             raise DxmiError("models.cm.unet.UNetModel runs only on the HIP device path (no CPU fallback)")
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise DxmiError("UNetModel: the HIP backward of the ADM U-Net is not built yet; call under torch.no_grad()")
+            from .unet_train import forward_with_grad  # autograd wrapper around the HIP kernels
+            return forward_with_grad(self, x, timesteps, y)
         return self.forward_inference(x, timesteps, y)
 
     @torch.no_grad()

@@ -1,0 +1,297 @@
+"""Autograd path of the ADM / EDM U-Net on the gfx950 kernels (policy step of DxMI on the EDM backbones:
+models/DxMI/trainer.py:693-746 back-propagates the sampler loss through OpenAIDiffusion.sample_step into every
+U-Net parameter; reference graph = torch autograd over models/cm/unet.py:761-790).
+
+One torch.autograd.Function wraps the network.  forward() is the inference program of models/cm/unet.py (this
+package) plus a tape of saved NHWC bf16 activations; backward() walks the tape in reverse:
+  conv data gradients   = the forward MFMA kernels on transpose-flipped weight fragments (ResBlock(up) / Upsample:
+                          full-resolution gradient then a 2x2 sum; stride-2 Downsample: zero-stuffed gradient);
+  conv weight gradients = MFMA pixel-GEMM (dxmi_conv2d_wgrad), bias gradients = column sums;
+  GroupNorm32 (+FiLM scale-shift, +SiLU) = dxmi_groupnorm_generic_bwd, which also returns the per-image sums the
+                          scale / shift (= emb_layers output) gradients are formed from;
+  attention             = batched MFMA GEMMs + softmax backward (dxmi_bgemm_bf16), any head count;
+  mean pool / nearest x2 = each other's transposes (dxmi_upsample2x, dxmi_pool_act);
+  time_embed, label_emb, emb_layers = tiny dense layers, re-evaluated and differentiated with torch fp32 matmuls.
+Dropout must be 0 (every DxMI EDM config sets dropout: 0.0).  Parameter gradients come back in net.parameters() order.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from dxmi_hip import ops
+
+
+def _pack_t(net):
+    key = net._param_key()
+    if getattr(net, "_packed_t", None) is not None and net._packed_t_key == key:
+        return net._packed_t
+    from .unet import AttentionBlock, Downsample, ResBlock, Upsample
+    pk = {}
+    for m in net.modules():
+        if isinstance(m, ResBlock):
+            pk[id(m), "conv1"] = ops.pack_conv_weight(m.in_layers[2].weight, transpose_flip=True)
+            pk[id(m), "conv2"] = ops.pack_conv_weight(m.out_layers[3].weight, transpose_flip=True)
+        elif isinstance(m, AttentionBlock):
+            C = m.channels
+            pk[id(m), "qkv"] = ops.pack_conv_weight(m.qkv.weight.reshape(3 * C, C, 1, 1), transpose_flip=True)
+            pk[id(m), "proj"] = ops.pack_conv_weight(m.proj_out.weight.reshape(C, C, 1, 1), transpose_flip=True)
+        elif isinstance(m, Upsample) and m.use_conv:
+            pk[id(m), "conv"] = ops.pack_conv_weight(m.conv.weight, transpose_flip=True)
+        elif isinstance(m, Downsample) and m.use_conv:
+            pk[id(m), "conv"] = ops.pack_conv_weight(m.op.weight, transpose_flip=True)
+    w = net.out[2].weight
+    wpad = torch.zeros((64,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device)
+    wpad[: w.shape[0]] = w.detach()
+    pk["conv_out"] = ops.pack_conv_weight(wpad, transpose_flip=True)
+    net._packed_t, net._packed_t_key = pk, key
+    return pk
+
+
+def _up_sum(g):
+    """transpose of nearest x2: sum over each 2x2 block (mean * 4, exact in bf16)."""
+    out = ops.pool_act(g, True, ops.ACT_NONE)
+    out.mul_(4.0)
+    return out
+
+
+def _pool_t(g):
+    """transpose of the 2x2 mean pool: every gradient value to its 4 sources, times 1/4."""
+    out = ops.upsample2x(g)
+    out.mul_(0.25)
+    return out
+
+
+class _EDMUNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, timesteps, y, *params):
+        from .unet import AttentionBlock, Downsample, ResBlock, Upsample
+        if net.training and net.dropout:
+            raise NotImplementedError("UNetModel HIP training path: dropout > 0 is not implemented (DxMI configs use 0.0)")
+        pk = net.packed()
+        x = x.contiguous().float()
+        sinus = ops.timestep_embedding(timesteps, net.model_channels, order=1)
+        e0 = ops.linear(sinus, pk["te0"], net.time_embed[0].bias, post_act=ops.ACT_SILU)
+        emb = ops.linear(e0, pk["te2"], net.time_embed[2].bias)
+        if net.num_classes is not None:
+            emb = emb + net.label_emb.weight[y]
+        emb_all = ops.linear(emb, pk["emb_w"], pk["emb_b"], pre_act=ops.ACT_SILU)
+        tape = []
+
+        def res(b, x0, x1):
+            gn1, conv1, gn2, conv2 = b.in_layers[0], b.in_layers[2], b.out_layers[0], b.out_layers[3]
+            a1 = ops.groupnorm_silu(x0, gn1.weight, gn1.bias, in1=x1, eps=gn1.eps, silu=True)
+            a1p, xs = a1, x0
+            if b.up:
+                xs = ops.upsample2x(x0)
+            elif b.down:
+                a1p, xs = ops.pool_act(a1, True, ops.ACT_NONE), ops.pool_act(x0, True, ops.ACT_NONE)
+            off, eo = pk[id(b), "eoff"], b.emb_layers[1].out_features
+            e = emb_all[:, off:off + eo]
+            if b.use_scale_shift_norm:
+                h = ops.conv2d(a1p, pk[id(b), "conv1"], bias=conv1.bias, upsample=b.up)
+                a2 = ops.groupnorm_silu(h, gn2.weight, gn2.bias, eps=gn2.eps, silu=True, scale_shift=e)
+            else:
+                h = ops.conv2d(a1p, pk[id(b), "conv1"], bias=conv1.bias, upsample=b.up, addvec=e)
+                a2 = ops.groupnorm_silu(h, gn2.weight, gn2.bias, eps=gn2.eps, silu=True)
+            if (id(b), "skip") in pk:
+                xs = ops.conv2d(x0, pk[id(b), "skip"], in1=x1, bias=b.skip_connection.bias)
+            out = ops.conv2d(a2, pk[id(b), "conv2"], bias=conv2.bias, residual=xs)
+            tape.append(("res", b, x0, x1, a1p, h, a2))
+            return out
+
+        def attn(m, xa):
+            N, H, W, C = xa.shape
+            hn = ops.groupnorm_silu(xa, m.norm.weight, m.norm.bias, eps=m.norm.eps, silu=False)
+            qkv = ops.conv2d(hn, pk[id(m), "qkv"], bias=m.qkv.bias)
+            a = ops.attention(qkv.view(N, H * W, 3 * C), heads=m.num_heads, scale=1.0 / math.sqrt(C // m.num_heads))
+            out = ops.conv2d(a.view(N, H, W, C), pk[id(m), "proj"], bias=m.proj_out.bias, residual=xa)
+            tape.append(("attn", m, xa, hn, qkv, a))
+            return out
+
+        def seq(mods, h, skip):
+            for m in mods:
+                if isinstance(m, ResBlock):
+                    h = res(m, h, skip)
+                    skip = None
+                elif isinstance(m, AttentionBlock):
+                    h = attn(m, h)
+                elif isinstance(m, Downsample):
+                    tape.append(("down", m, h))
+                    h = ops.conv2d(h, pk[id(m), "conv"], bias=m.op.bias, stride=2, pad=1) if m.use_conv \
+                        else ops.pool_act(h, True, ops.ACT_NONE)
+                elif isinstance(m, Upsample):
+                    tape.append(("up", m, h))
+                    h = ops.conv2d(h, pk[id(m), "conv"], bias=m.conv.bias, upsample=True) if m.use_conv else ops.upsample2x(h)
+            return h
+
+        conv_in = net.input_blocks[0][0]
+        h = ops.conv2d(x, pk["conv_in"], bias=conv_in.bias) if pk["conv_in"].k27 else \
+            ops.conv2d(ops.nchw_f32_to_nhwc_bf16(x), pk["conv_in"], bias=conv_in.bias)
+        hs = [h]
+        for i in range(1, len(net.input_blocks)):
+            h = seq(net.input_blocks[i], h, None)
+            tape.append(("push", None, len(hs)))
+            hs.append(h)
+        h = seq(net.middle_block, h, None)
+        for blk in net.output_blocks:
+            tape.append(("skip", None, len(hs) - 1))
+            h = seq(blk, h, hs.pop())
+        gn = net.out[0]
+        a_out = ops.groupnorm_silu(h, gn.weight, gn.bias, eps=gn.eps, silu=True)
+        out = ops.conv2d(a_out, pk["conv_out"], bias=net.out[2].bias, out_nchw_f32=True)
+        ctx.net, ctx.tape, ctx.h_last, ctx.a_out, ctx.x, ctx.sinus, ctx.y = net, tape, h, a_out, x, sinus, y
+        ctx.emb_all_shape = emb_all.shape
+        ctx.emb_all = emb_all
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        from .unet import ResBlock
+        net, tape = ctx.net, ctx.tape
+        pk, pkt = net.packed(), _pack_t(net)
+        grads = {}
+        N = d_out.shape[0]
+        dev = d_out.device
+        d_emb_all = torch.zeros(ctx.emb_all_shape, dtype=torch.float32, device=dev)
+        emb_all = ctx.emb_all
+
+        def conv_wb(conv, x0, gy, k, x1=None, **kw):
+            grads[conv.weight] = ops.conv2d_wgrad(x0, gy, k, in1=x1, **kw).reshape(conv.weight.shape)
+            grads[conv.bias] = ops.colsum(gy)
+
+        def gn_bwd(norm, xin, dy, *, in1=None, add0=None, add1=None, silu=True, scale_shift=None):
+            dx0, dx1, dg, db, d_ss = ops.groupnorm_generic_bwd(xin, dy, norm.weight, norm.bias, in1=in1, add0=add0, add1=add1,
+                                                               eps=norm.eps, silu=silu, scale_shift=scale_shift)
+            grads[norm.weight], grads[norm.bias] = dg, db
+            return dx0, dx1, d_ss
+
+        # ---- head: out = conv(silu(gn(h_last)))
+        H, W = d_out.shape[2], d_out.shape[3]
+        d_pad = torch.zeros((N, H, W, 64), dtype=torch.bfloat16, device=dev)
+        d_pad[..., : d_out.shape[1]] = d_out.permute(0, 2, 3, 1).to(torch.bfloat16)
+        wg = ops.conv2d_wgrad(ctx.a_out, d_pad, 3)
+        grads[net.out[2].weight] = wg[: net.out_channels].contiguous()
+        grads[net.out[2].bias] = d_out.float().sum((0, 2, 3))
+        d_a = ops.conv2d(d_pad, pkt["conv_out"])
+        g, _, _ = gn_bwd(net.out[0], ctx.h_last, d_a)
+
+        gskip = {}
+
+        def res_bwd(entry, g):
+            _, b, x0, x1, a1p, h, a2 = entry
+            gn1, conv1, gn2, conv2 = b.in_layers[0], b.in_layers[2], b.out_layers[0], b.out_layers[3]
+            conv_wb(conv2, a2, g, 3)
+            d_a2 = ops.conv2d(g, pkt[id(b), "conv2"])
+            off, eo = pk[id(b), "eoff"], b.emb_layers[1].out_features
+            if b.use_scale_shift_norm:
+                d_h, _, d_ss = gn_bwd(gn2, h, d_a2, scale_shift=emb_all[:, off:off + eo])
+                d_emb_all[:, off:off + eo] = d_ss
+            else:
+                d_h, _, _ = gn_bwd(gn2, h, d_a2)
+                d_emb_all[:, off:off + eo] = ops.colsum_per_image(d_h)
+            conv_wb(conv1, a1p, d_h, 3, upsample=b.up)
+            d_a1 = ops.conv2d(d_h, pkt[id(b), "conv1"])
+            if b.up:
+                d_a1 = _up_sum(d_a1)
+            elif b.down:
+                d_a1 = _pool_t(d_a1)
+            if (id(b), "skip") in pk:
+                sk = b.skip_connection
+                k = sk.weight.shape[-1]
+                conv_wb(sk, x0, g, k, x1=x1)
+                dxg0, dxg1, _ = gn_bwd(gn1, x0, d_a1, in1=x1)
+                C0 = x0.shape[3]
+                w = sk.weight
+                d_x0 = ops.conv2d(g, ops.pack_conv_weight(w[:, :C0].contiguous(), transpose_flip=True), residual=dxg0)
+                d_x1 = None
+                if x1 is not None:
+                    d_x1 = ops.conv2d(g, ops.pack_conv_weight(w[:, C0:].contiguous(), transpose_flip=True), residual=dxg1)
+                return d_x0, d_x1
+            assert x1 is None
+            g_id = _up_sum(g) if b.up else (_pool_t(g) if b.down else g)
+            d_x0, _, _ = gn_bwd(gn1, x0, d_a1, add0=g_id)
+            return d_x0, None
+
+        def attn_bwd(entry, g):
+            _, m, xa, hn, qkv, a = entry
+            Nn, Hh, Ww, C = xa.shape
+            conv_wb(m.proj_out, a.view(Nn, Hh, Ww, C), g, 1)
+            d_a = ops.conv2d(g, pkt[id(m), "proj"])
+            d_qkv = ops.attention_bwd(qkv.view(Nn, Hh * Ww, 3 * C), d_a.view(Nn, Hh * Ww, C), m.num_heads,
+                                      1.0 / math.sqrt(C // m.num_heads)).view(Nn, Hh, Ww, 3 * C)
+            conv_wb(m.qkv, hn, d_qkv, 1)
+            d_hn = ops.conv2d(d_qkv, pkt[id(m), "qkv"])
+            d_x, _, _ = gn_bwd(m.norm, xa, d_hn, add0=g, silu=False)
+            return d_x
+
+        i = len(tape) - 1
+        while i >= 0:
+            e = tape[i]
+            kind = e[0]
+            if kind == "res":
+                d_x0, d_x1 = res_bwd(e, g)
+                g = d_x0
+                if e[3] is not None:     # first layer of an output block: (h, skip) concat
+                    assert tape[i - 1][0] == "skip"
+                    gskip[tape[i - 1][2]] = d_x1
+                    i -= 1
+            elif kind == "attn":
+                g = attn_bwd(e, g)
+            elif kind == "up":
+                _, m, xin = e
+                if m.use_conv:
+                    conv_wb(m.conv, xin, g, 3, upsample=True)
+                    g = _up_sum(ops.conv2d(g, pkt[id(m), "conv"]))
+                else:
+                    g = _up_sum(g)
+            elif kind == "down":
+                _, m, xin = e
+                if m.use_conv:
+                    conv_wb(m.op, xin, g, 3, stride=2, pad=1)
+                    g = ops.conv2d(g, pkt[id(m), "conv"], pad=1, pad_br=1, upsample=2)
+                else:
+                    g = _pool_t(g)
+            elif kind == "push":
+                idx = e[2]
+                if idx in gskip:
+                    g = g + gskip.pop(idx)
+            elif kind == "skip":
+                raise AssertionError("skip entry must directly precede the ResBlock that consumes it")
+            i -= 1
+        if 0 in gskip:
+            g = g + gskip.pop(0)
+        conv_in = net.input_blocks[0][0]
+        grads[conv_in.bias] = ops.colsum(g)
+        grads[conv_in.weight] = ops.stem_conv_wgrad(ctx.x, g)
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = ops.conv2d(g, ops.pack_conv_weight(conv_in.weight, transpose_flip=True), out_nchw_f32=True)
+
+        # ---- embedding graph: time_embed MLP, label embedding, every emb_layers Linear (tiny; torch fp32 autograd)
+        blocks = [m for m in net.modules() if isinstance(m, ResBlock)]
+        leaves = [net.time_embed[0].weight, net.time_embed[0].bias, net.time_embed[2].weight, net.time_embed[2].bias]
+        if net.num_classes is not None:
+            leaves.append(net.label_emb.weight)
+        nfix = len(leaves)
+        leaves += [b.emb_layers[1].weight for b in blocks] + [b.emb_layers[1].bias for b in blocks]
+        with torch.enable_grad():
+            lv = [p.detach().requires_grad_(True) for p in leaves]
+            emb = F.linear(F.silu(F.linear(ctx.sinus, lv[0], lv[1])), lv[2], lv[3])
+            if net.num_classes is not None:
+                emb = emb + F.embedding(ctx.y, lv[4])
+            nb = len(blocks)
+            ea = F.linear(F.silu(emb), torch.cat(lv[nfix:nfix + nb], 0), torch.cat(lv[nfix + nb:], 0))
+            gl = torch.autograd.grad(ea, lv, grad_outputs=d_emb_all)
+        for p, gp in zip(leaves, gl):
+            grads[p] = gp
+
+        out = [None, dx, None, None]
+        for prm in net.parameters():
+            out.append(grads.get(prm))
+        return tuple(out)
+
+
+def forward_with_grad(net, x, timesteps, y=None):
+    return _EDMUNetFn.apply(net, x, timesteps, y, *list(net.parameters()))

@@ -239,6 +239,15 @@ int dxmi_groupnorm_generic_fwd(const void* in0, int32_t C0, const void* in1, int
                                const float* beta, const float* scale_shift, int32_t ss_ld, void* out,
                                void* workspace, int32_t N, int32_t HW, int32_t groups, float eps,
                                int32_t apply_silu, void* stream);
+/* Backward of dxmi_groupnorm_generic_fwd: dx0 | dx1 (bf16, optional additive inputs add0 | add1 fused) and
+ * g_out fp32 [2][N][C] = per-image sums of dyy and dyy*xhat, from which the caller forms dgamma, dbeta and the FiLM
+ * gradients (dscale = G1*gamma + G0*beta, dshift = G0).  Replaces autograd through models/cm/unet.py:228-260. */
+int64_t dxmi_groupnorm_generic_bwd_workspace_bytes(int32_t N, int32_t HW, int32_t C);
+int dxmi_groupnorm_generic_bwd(const void* in0, int32_t C0, const void* in1, int32_t C1, const void* dy,
+                               const void* add0, const void* add1, const float* gamma, const float* beta,
+                               const float* scale_shift, int32_t ss_ld, void* dx0, void* dx1, float* g_out,
+                               void* workspace, int32_t N, int32_t HW, int32_t groups, float eps,
+                               int32_t apply_silu, void* stream);
 int dxmi_upsample2x(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int dxmi_edm_precond(const float* x, const float* sigma, float* x_in, float* t_out, int32_t N, int32_t CHW,
                      float sigma_data, void* stream);

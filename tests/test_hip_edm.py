@@ -345,3 +345,71 @@ def test_cli_generate_large(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     arr = np.load(os.path.join(logdir, "samples_8.npz"))["arr_0"]
     assert arr.shape == (8, 16, 16, 3) and arr.dtype == np.uint8
+
+
+# ------------------------------------------------------------------------------------------ backward
+@pytest.mark.parametrize("N,C0,C1,H,silu,ss", [(2, 192, 0, 32, True, True), (2, 384, 192, 16, True, False),
+                                                 (2, 64, 0, 16, False, False), (1, 768, 576, 8, True, True)])
+def test_groupnorm_generic_bwd(ops, N, C0, C1, H, silu, ss):
+    g = torch.Generator().manual_seed(C0 + H)
+    C = C0 + C1
+    x = bf(torch.randn(N, C, H, H, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.1).requires_grad_(True)
+    dy = bf(torch.randn(N, C, H, H, generator=g))
+    add = bf(torch.randn(N, C, H, H, generator=g))
+    sst = (torch.randn(N, 2 * C, generator=g) * 0.3).requires_grad_(True) if ss else None
+    y = F.group_norm(x, 32, gamma, beta, 1e-5)
+    if ss:
+        y = y * (1 + sst[:, :C, None, None]) + sst[:, C:, None, None]
+    if silu:
+        y = F.silu(y)
+    (y * dy).sum().backward()
+    xd = x.detach()
+    x0, x1 = nhwc(xd[:, :C0]), (nhwc(xd[:, C0:]) if C1 else None)
+    a0, a1 = nhwc(add[:, :C0]), (nhwc(add[:, C0:]) if C1 else None)
+    dx0, dx1, dg, db, dss = ops.groupnorm_generic_bwd(x0, nhwc(dy), gamma.detach().to(DEV), beta.detach().to(DEV), in1=x1, add0=a0,
+                                                      add1=a1, eps=1e-5, silu=silu, scale_shift=sst.detach().to(DEV) if ss else None)
+    ref_dx = x.grad + add
+    got = torch.cat([nchw(dx0)] + ([nchw(dx1)] if C1 else []), 1)
+    assert rel_l2(got, ref_dx) < 6e-3
+    assert rel_l2(dg.cpu(), gamma.grad) < 2e-3 and rel_l2(db.cpu(), beta.grad) < 2e-3
+    if ss:
+        assert rel_l2(dss.cpu(), sst.grad) < 2e-3
+
+
+@pytest.mark.parametrize("tag", ["", "_plain"])
+def test_unet_backward_vs_oracle(golden_dir, tag):
+    """Every parameter gradient of the shrunken ADM U-Net (both variants) against torch autograd through the pinned
+    oracle in fp32; the bound is the oracle's own bf16-storage-model noise floor (as for the DDPM U-Net)."""
+    from oracle import Precision, edm
+    net, _, sd = build(TINY_KW, PLAIN if tag else None)
+    cc = not tag
+    cfg = edm.EDMConfig(image_size=16, model_channels=64, num_res_blocks=1, attention_resolutions=(2,), channel_mult=(1, 2),
+                        **(dict(num_classes=None, use_scale_shift_norm=False, resblock_updown=False) if tag else {}))
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 3, 16, 16, generator=g)
+    t = torch.tensor([700.0, -900.0])
+    y = torch.tensor([5, 321])
+    w_out = torch.randn(2, 3, 16, 16, generator=g)
+    for p in net.parameters():
+        p.requires_grad_(True)
+    out = net(x.to(DEV), t.to(DEV), **({"y": y.to(DEV)} if cc else {}))
+    assert out.requires_grad
+    (out * w_out.to(DEV)).sum().backward()
+    ref = {}
+    for mode in ("fp32", "bf16"):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        yo = edm.unet_forward(leaves, cfg, x, t, prec=Precision(mode), **({"y": y} if cc else {}))
+        (yo * w_out).sum().backward()
+        ref[mode] = {k: leaves[k].grad for k in leaves}
+    P = dict(net.named_parameters())
+    worst = ("", 0.0)
+    for k, p in P.items():
+        assert p.grad is not None and p.grad.shape == ref["fp32"][k].shape, k
+        r = rel_l2(p.grad.cpu(), ref["fp32"][k])
+        fl = rel_l2(ref["bf16"][k], ref["fp32"][k])
+        assert r < 2.0 * fl + 1.5e-2, (k, r, fl)
+        if r > worst[1]:
+            worst = (k, r)
+    print(f"edm unet{tag} backward: worst parameter-gradient rel-L2 vs oracle fp32 = {worst[1]:.2e} ({worst[0]})")
