@@ -79,10 +79,29 @@ class OpenAIDiffusion:
             sigma_up = s
         x = x.contiguous().float()
         z = torch.randn_like(x) if noise is None else noise
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
+            return self._sample_step_grad(x, z, sigma, sigma_down, sigma_up, model_kwargs)
         x_in, rescaled_t = ops.edm_precond(x, sigma.contiguous(), self.diffusion.sigma_data)
         model_output = self.net(x_in, rescaled_t, **model_kwargs)
         samples, mu = ops.edm_step(x, model_output, z.contiguous(), sigma.contiguous(), sigma_down.contiguous(),
                                    sigma_up.detach().float().contiguous(), self.diffusion.sigma_data)
+        return {"sample": samples, "mean": mu, "sigma": sigma_up.clamp(1e-4, None)}
+
+    def _sample_step_grad(self, x, z, sigma, sigma_down, sigma_up, model_kwargs):
+        """Training path (policy update, trainer.py:693-746): the U-Net runs its HIP forward/backward through
+        models/cm/unet_train.py; the few element-wise lines around it stay torch autograd ops so that the loss reaches
+        the network output and the learnable `log_betas` exactly as in the reference (:71-94)."""
+        sd = self.diffusion.sigma_data
+        e = lambda v: v[:, None, None, None]
+        c_skip = sd ** 2 / (sigma ** 2 + sd ** 2)
+        c_out = sigma * sd / (sigma ** 2 + sd ** 2) ** 0.5
+        c_in = 1 / (sigma ** 2 + sd ** 2) ** 0.5
+        rescaled_t = 1000 * 0.25 * torch.log(sigma + 1e-44)
+        model_output = self.net(e(c_in) * x, rescaled_t, **model_kwargs)
+        denoised = e(c_out) * model_output + e(c_skip) * x
+        d = (x - denoised) / e(sigma)
+        mu = x + d * e(sigma_down - sigma)
+        samples = mu + z * e(sigma_up)
         return {"sample": samples, "mean": mu, "sigma": sigma_up.clamp(1e-4, None)}
 
     def sample(self, n_sample, device, i_class=None, enable_grad=False, x0=None, noise=None):

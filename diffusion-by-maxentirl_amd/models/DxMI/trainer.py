@@ -48,7 +48,7 @@ def append_buffer(state_buffer, d_sample):
     for key in ("logp", "control", "entropy", "mean", "sigma"):
         if key in d_sample:
             put(key, d_sample[key][:n_seq])
-    if "y" in d_sample:
+    if d_sample.get("y") is not None:   # unconditional OpenAIDiffusion hands back y=None
         put("y", [d_sample["y"]] * n_seq)
     return state_buffer
 
@@ -232,3 +232,173 @@ class DxMI_Trainer:
         dev = next(v.device for v in logs.values() if torch.is_tensor(v))
         vals = torch.stack([torch.as_tensor(logs[k], dtype=torch.float32, device=dev).reshape(()) for k in keys]).tolist()
         return dict(zip(keys, vals))
+
+
+class DxMI_Trainer_Cond(DxMI_Trainer):
+    """DxMI trainer of the EDM backbones (ImageNet-64, LSUN): time-independent value net, optional class labels,
+    sampler update over ALL T*B buffered transitions through a MixedPrecisionTrainer (reference :412-809).
+    Differences from DxMI_Trainer are the reference's own: `betas_for_q = sigmas[:-1]**2` for an OpenAIDiffusion
+    sampler (:516-517), forward beta ordering by default (:527-534), extra value-target options, `y` plumbing."""
+
+    def __init__(self, batchsize, tau1=0.0, tau2=0.0, gamma=None, q_beta_schedule="constant", q_beta_start=1.0, q_beta_end=1.0,
+                 adavelreg=None, n_timesteps=10, value_update_order="backward", entropy_in_value=None, velocity_in_value=None,
+                 entropy_value_scale=1, skip_sampler_tau=0, sigma_scale=None, use_sampler_beta=False, aug=None, time_cost=None,
+                 time_cost_sig=None, time_cost_sig_center=None, repeat_value_update=1, skip_running_last=False,
+                 value_resample=False, beta_ordering="forward", value_grad_clip=False):
+        super().__init__(batchsize, tau1=tau1, tau2=tau2, gamma=gamma, q_beta_schedule=q_beta_schedule, q_beta_start=q_beta_start,
+                         q_beta_end=q_beta_end, adavelreg=adavelreg, n_timesteps=n_timesteps, value_update_order=value_update_order,
+                         entropy_in_value=entropy_in_value, velocity_in_value=velocity_in_value, use_sampler_beta=use_sampler_beta,
+                         time_cost=time_cost, time_cost_sig=time_cost_sig, repeat_value_update=repeat_value_update,
+                         value_resample=value_resample, value_grad_clip=value_grad_clip, skip_sampler_tau=skip_sampler_tau)
+        if aug is not None:
+            raise NotImplementedError("aug (StyleGAN2-ADA augmentation) is not part of any shipped DxMI config")
+        assert beta_ordering in {"reversed", "forward"}
+        self.entropy_value_scale, self.sigma_scale = entropy_value_scale, sigma_scale
+        self.time_cost_sig_center, self.skip_running_last, self.beta_ordering = time_cost_sig_center, skip_running_last, beta_ordering
+
+    def set_models(self, v, sampler, optimizer, optimizer_v, f=None, optimizer_fstar=None):
+        """reference :496-525."""
+        self.f, self.v, self.sampler = f, v, sampler
+        self.optimizer, self.optimizer_fstar, self.optimizer_v = optimizer, optimizer_fstar, optimizer_v
+        from dxmi_hip.dist import FlatGradSync
+        self.sync_v = FlatGradSync(v) if v is not None else (lambda: None)
+        self.sync_sampler = lambda: None   # the MixedPrecisionTrainer reduces the sampler gradients in optimize()
+        if self.use_sampler_beta:
+            if hasattr(self.sampler, "user_defined_eta"):
+                self.betas_for_q = torch.tensor(self.sampler.user_defined_eta, dtype=torch.float32)
+            elif hasattr(self.sampler, "log_betas"):
+                self.betas_for_q = torch.exp(self.sampler.log_betas * 0.5)
+            else:   # OpenAIDiffusion
+                self.betas_for_q = self.sampler.sigmas[:-1] ** 2
+        else:
+            self.betas_for_q = make_beta_schedule(schedule=self.q_beta_schedule, n_timesteps=self.n_timesteps,
+                                                  start=self.q_beta_start, end=self.q_beta_end)
+
+    def get_running_cost(self, state, next_state, pred_mean, pred_std, t):
+        if self.beta_ordering == "reversed":
+            t = self.n_timesteps - t - 1
+        beta_next = extract(self.betas_for_q, t, state).to(state.device)
+        return (((next_state - state) ** 2) / (2 * beta_next)).view(len(state), -1).mean(dim=1)
+
+    def update_adaptive_vel_reg(self, d_sample):
+        device = d_sample["sample"].device
+        samples = torch.stack(d_sample["l_sample"])
+        diff = ((samples[1:] - samples[:-1]) ** 2).view(samples.shape[0] - 1, -1).mean(dim=1)
+        if self.beta_ordering == "reversed":
+            diff = diff.flip(0)
+        self.betas_for_q = (self.betas_for_q.to(device) * self.adavelreg + (1 - self.adavelreg) * diff.to(device)).detach()
+
+    def update_f_v(self, img, d_sample, state_dict, y=None):
+        """reference :553-691."""
+        if self.adavelreg is not None:
+            self.update_adaptive_vel_reg(d_sample)
+        x0 = d_sample["l_sample"][-1]
+        n_steps, batchsize, device = self.n_timesteps, self.batchsize, img.device
+        self.optimizer_v.zero_grad()
+        self.v.train()
+        Tt = n_steps * torch.ones(len(img) + len(x0), dtype=torch.long, device=device)
+        ys = torch.cat((y, y), 0) if y is not None else None
+        output = self.v(torch.cat((img.detach(), x0.detach()), 0), Tt, y=ys)
+        pos_e, neg_e = output[:x0.shape[0]], output[x0.shape[0]:]
+        d_loss = pos_e.mean() - neg_e.mean()
+        if self.gamma is not None:
+            reg = pos_e.pow(2).mean() + neg_e.pow(2).mean()
+            d_loss = d_loss + self.gamma * reg
+        else:
+            reg = torch.zeros((), device=device)
+        d_loss.backward()
+        self.sync_v()
+        self.optimizer_v.step()
+        self.optimizer_v.zero_grad()
+
+        permutation = torch.randperm(batchsize * n_steps)
+        indices = (permutation + (state_dict["state"].shape[0] - batchsize * n_steps)).to(device)
+        ts_perm = state_dict["timestep"][indices]
+        d_running_cost, d_value = {}, {}
+        running_cost = v_loss = None
+        for _ in range(self.repeat_value_update):
+            if self.value_update_order == "random":
+                update_order = torch.randperm(n_steps)
+            for i in range(n_steps):
+                update_t = int(update_order[i]) if self.value_update_order == "random" else n_steps - i - 1
+                if self.value_update_order == "shuffle":
+                    rows = indices[torch.arange(batchsize, device=device) + i * batchsize]
+                else:
+                    rows = indices[torch.nonzero(ts_perm == update_t).flatten()]
+                state = state_dict["state"][rows]
+                timestep = state_dict["timestep"][rows]
+                yb = state_dict["y"][rows] if y is not None and len(state_dict["y"]) == len(state_dict["state"]) else y
+                if self.value_resample:
+                    with torch.no_grad():
+                        d_step = self.sampler.sample_step(state, timestep, **({"y": yb} if yb is not None else {}))
+                    next_state, pred_mean, pred_std = d_step["sample"], d_step["mean"], d_step["sigma"]
+                else:
+                    next_state = state_dict["next_state"][rows]
+                    pred_mean = state_dict["mean"][rows]
+                    pred_std = state_dict["sigma"][rows]
+                running_cost = self.get_running_cost(state, next_state, pred_mean, pred_std, timestep)
+                entropy = torch.log(pred_std.squeeze() / self.sigma_scale) if self.sigma_scale is not None else torch.log(pred_std.squeeze())
+                self.v.eval()
+                with torch.no_grad():
+                    target = self.v(next_state, timestep + 1, y=y).squeeze()
+                if self.time_cost is not None:
+                    target = target + self.time_cost
+                if self.time_cost_sig is not None:
+                    center = self.n_timesteps // 2 if self.time_cost_sig_center is None else self.time_cost_sig_center
+                    target = target + self.time_cost_sig * torch.sigmoid(-timestep + center) \
+                        - self.time_cost_sig * torch.sigmoid(-timestep - 1 + center)
+                if self.velocity_in_value is not None:
+                    target = target + running_cost * self.tau2 * (timestep < n_steps - self.velocity_in_value).float()
+                if self.entropy_in_value is not None:
+                    assert isinstance(self.entropy_in_value, int), "self.entropy_in_value should be interger"
+                    target = target - entropy * self.tau1 * (timestep < n_steps - self.entropy_in_value).float() * self.entropy_value_scale
+                self.v.train()
+                v_xt = self.v(state, timestep, y=y).squeeze()
+                v_loss = F.mse_loss(v_xt, target.detach())
+                v_loss.backward()
+                self.sync_v()
+                if self.value_grad_clip:
+                    torch.nn.utils.clip_grad_norm_(self.v.parameters(), 0.1)
+                self.optimizer_v.step()
+                self.optimizer_v.zero_grad()
+                d_running_cost[f"running_cost/step_{update_t}_"] = running_cost.detach().mean()
+                d_value[f"value/step_{update_t}_"] = v_xt.detach().mean()
+        logs = {"ebm/d_loss_": d_loss.detach(), "ebm/v_loss_": v_loss.detach(), "ebm/pos_e_": pos_e.detach().mean(),
+                "ebm/neg_e_": neg_e.detach().mean(), "ebm/running_cost_": running_cost.detach().mean(), "ebm/reg_": reg.detach()}
+        logs.update(d_running_cost)
+        logs.update(d_value)
+        if self.adavelreg is not None:
+            for t, beta in enumerate(self.betas_for_q):
+                logs[f"adavelreg/beta{t}_"] = beta
+        return self._to_floats(logs)
+
+    def update_sampler_mixed_precision(self, state_dict, mp_trainer, d_sample=None):
+        """reference :693-746: one optimiser step per `batchsize` slice of ALL buffered transitions."""
+        self.v.eval()
+        self.sampler.train()
+        permutation = torch.randperm(state_dict["state"].shape[0])
+        batchsize = self.batchsize
+        device = state_dict["state"].device
+        for m in range(0, len(permutation), batchsize):
+            mp_trainer.zero_grad()
+            indices = permutation[m:m + batchsize].to(device)
+            state = state_dict["state"][indices]
+            t = state_dict["timestep"][indices]
+            y = state_dict["y"][indices] if self.sampler.class_cond else None
+            d_step = self.sampler.sample_step(state, t, **({"y": y} if y is not None else {}))
+            next_state, pred_mean, pred_std = d_step["sample"], d_step["mean"], d_step["sigma"]
+            running_cost = self.get_running_cost(state, next_state, pred_mean, pred_std, t)
+            causal_entropy = torch.log(pred_std.squeeze())
+            sampler_value_loss = self.v(next_state, t + 1, y=y).squeeze()
+            non_terminal = (t < self.n_timesteps - self.skip_sampler_tau).float()
+            sampler_loss = (sampler_value_loss + (running_cost * self.tau2 - causal_entropy * self.tau1) * non_terminal).mean()
+            mp_trainer.backward(sampler_loss)
+            mp_trainer.optimize(self.optimizer)
+        logs = {"sampler/sampler_loss_": sampler_loss.detach().mean(), "sampler/sampler_value_loss_": sampler_value_loss.detach().mean(),
+                "sampler/running_cost_": running_cost.detach().mean(), "sampler/causal_entropy_": causal_entropy.detach().mean()}
+        if self.sampler.trainable_beta:
+            net = self.sampler.net.module if hasattr(self.sampler.net, "module") else self.sampler.net
+            sigma = torch.exp(net.log_betas.detach())
+            for t in range(len(sigma)):
+                logs[f"sigma/sigma_{t}_"] = sigma[t]
+        return self._to_floats(logs)

@@ -1,0 +1,152 @@
+"""`models.cm.fp16_util.MixedPrecisionTrainer` with the reference's surface (reference: models/cm/fp16_util.py:35-248),
+as train_image_large.py:157-170 and DxMI_Trainer_Cond.update_sampler_mixed_precision use it.
+
+On the HIP path the model parameters ARE fp32 masters (kernels read bf16 fragments re-packed from them), so
+`use_fp16=True` keeps the reference's bookkeeping — flat fp32 master tensors in the reference's three groups
+(`special_key` vector, other <=1-D parameters, matrices viewed (1,-1)), loss scaled by 2**lg_loss_scale, overflow check,
+scale growth — while the "model" side it copies to and from is fp32 too.  bf16 gradients have the fp32 exponent range, so
+the scaling is exact and never the reason for an overflow; it is kept so `lg_loss_scale` and the skip-on-NaN behaviour
+match.  Gradients are all-reduced over ranks (RCCL) in `optimize()` before the norms are taken: the reference gets the
+same from its DDP wrapper during backward (train_image_large.py:173).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+
+INITIAL_LOG_LOSS_SCALE = 20.0
+
+
+def get_param_groups_and_shapes(named_model_params, special_key=None):
+    named_model_params = list(named_model_params)
+    groups = []
+    if special_key is not None:
+        groups.append(([(n, p) for (n, p) in named_model_params if special_key in n], (-1)))
+        named_model_params = [(n, p) for (n, p) in named_model_params if special_key not in n]
+    groups.append(([(n, p) for (n, p) in named_model_params if p.ndim <= 1], (-1)))
+    groups.append(([(n, p) for (n, p) in named_model_params if p.ndim > 1], (1, -1)))
+    return groups
+
+
+def make_master_params(param_groups_and_shapes):
+    master_params = []
+    for param_group, shape in param_groups_and_shapes:
+        mp = nn.Parameter(_flatten_dense_tensors([p.detach().float() for (_, p) in param_group]).view(shape))
+        mp.requires_grad = True
+        master_params.append(mp)
+    return master_params
+
+
+def param_grad_or_zeros(param):
+    return param.grad.data.detach() if param.grad is not None else torch.zeros_like(param)
+
+
+def model_grads_to_master_grads(param_groups_and_shapes, master_params):
+    for master_param, (param_group, shape) in zip(master_params, param_groups_and_shapes):
+        master_param.grad = _flatten_dense_tensors([param_grad_or_zeros(p).float() for (_, p) in param_group]).view(shape)
+
+
+def unflatten_master_params(param_group, master_param):
+    return _unflatten_dense_tensors(master_param, [p for (_, p) in param_group])
+
+
+def master_params_to_model_params(param_groups_and_shapes, master_params):
+    for master_param, (param_group, _) in zip(master_params, param_groups_and_shapes):
+        for (_, param), unflat in zip(param_group, unflatten_master_params(param_group, master_param.view(-1))):
+            param.detach().copy_(unflat)
+
+
+def zero_master_grads(master_params):
+    for param in master_params:
+        param.grad = None
+
+
+def zero_grad(model_params):
+    for param in model_params:
+        if param.grad is not None:
+            param.grad.detach_()
+            param.grad.zero_()
+
+
+def check_overflow(value):
+    return (value == float("inf")) or (value == -float("inf")) or (value != value)
+
+
+class MixedPrecisionTrainer:
+    def __init__(self, *, model, use_fp16=False, fp16_scale_growth=1e-3, initial_lg_loss_scale=INITIAL_LOG_LOSS_SCALE,
+                 special_key=None):
+        self.model, self.use_fp16, self.fp16_scale_growth = model, use_fp16, fp16_scale_growth
+        self.model_params = list(self.model.parameters())
+        self.master_params = self.model_params
+        self.param_groups_and_shapes = None
+        self.lg_loss_scale = initial_lg_loss_scale
+        self.log = {}     # last grad_norm / param_norm / lg_loss_scale (the reference sends these to its logger)
+        if self.use_fp16:
+            self.param_groups_and_shapes = get_param_groups_and_shapes(self.model.named_parameters(), special_key=special_key)
+            self.master_params = make_master_params(self.param_groups_and_shapes)
+        from dxmi_hip.dist import FlatGradSync
+        self._sync = FlatGradSync(model)
+
+    def zero_grad(self):
+        zero_grad(self.model_params)
+
+    def backward(self, loss):
+        if self.use_fp16:
+            (loss * 2 ** self.lg_loss_scale).backward()
+        else:
+            loss.backward()
+
+    def optimize(self, opt):
+        self._sync()   # data-parallel mean of the gradients (no-op on one process)
+        return self._optimize_fp16(opt) if self.use_fp16 else self._optimize_normal(opt)
+
+    def _optimize_fp16(self, opt):
+        self.log["lg_loss_scale"] = self.lg_loss_scale
+        model_grads_to_master_grads(self.param_groups_and_shapes, self.master_params)
+        grad_norm, param_norm = self._compute_norms(grad_scale=2 ** self.lg_loss_scale)
+        if check_overflow(grad_norm):
+            self.lg_loss_scale -= 1
+            zero_master_grads(self.master_params)
+            return False
+        self.log["grad_norm"], self.log["param_norm"] = grad_norm, param_norm
+        for p in self.master_params:
+            p.grad.mul_(1.0 / (2 ** self.lg_loss_scale))
+        opt.step()
+        zero_master_grads(self.master_params)
+        master_params_to_model_params(self.param_groups_and_shapes, self.master_params)
+        self.lg_loss_scale += self.fp16_scale_growth
+        return True
+
+    def _optimize_normal(self, opt):
+        grad_norm, param_norm = self._compute_norms()
+        self.log["grad_norm"], self.log["param_norm"] = grad_norm, param_norm
+        opt.step()
+        return True
+
+    def _compute_norms(self, grad_scale=1.0):
+        """One device->host transfer for both norms (the reference does two .item() per master tensor)."""
+        with torch.no_grad():
+            pn = torch.stack([torch.norm(p, p=2, dtype=torch.float32) ** 2 for p in self.master_params]).sum()
+            gs = [torch.norm(p.grad, p=2, dtype=torch.float32) ** 2 for p in self.master_params if p.grad is not None]
+            gn = torch.stack(gs).sum() if gs else torch.zeros((), device=pn.device)
+            gn, pn = torch.stack([gn, pn]).tolist()
+        return np.sqrt(gn) / grad_scale, np.sqrt(pn)
+
+    def master_params_to_state_dict(self, master_params):
+        state_dict = self.model.state_dict()
+        if self.use_fp16:
+            for master_param, (param_group, _) in zip(master_params, self.param_groups_and_shapes):
+                for (name, _), unflat in zip(param_group, unflatten_master_params(param_group, master_param.view(-1))):
+                    assert name in state_dict
+                    state_dict[name] = unflat
+        else:
+            for i, (name, _v) in enumerate(self.model.named_parameters()):
+                assert name in state_dict
+                state_dict[name] = master_params[i]
+        return state_dict
+
+    def state_dict_to_master_params(self, state_dict):
+        if self.use_fp16:
+            named = [(name, state_dict[name]) for name, _ in self.model.named_parameters()]
+            return make_master_params(get_param_groups_and_shapes(named))
+        return [state_dict[name] for name, _ in self.model.named_parameters()]

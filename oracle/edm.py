@@ -296,12 +296,12 @@ def sample_step(model, sch, x, indices, z, log_betas=None, **kw):
     return {"sample": mu + z * sigma_up[:, None, None, None], "mean": mu, "sigma": sigma_up.clamp(1e-4, None)}
 
 
-def sample(model, sch, x0, noises, **kw):
+def sample(model, sch, x0, noises, log_betas=None, **kw):
     """OpenAIDiffusion.sample (openai_diffusion.py:102-129): x0 = randn * sigma_max supplied by the caller."""
     x = x0
     l_x, l_mean, l_sigma = [x], [], []
     for i in range(sch.n_timesteps):
-        d = sample_step(model, sch, x, i * torch.ones(len(x), dtype=torch.long), noises[i], **kw)
+        d = sample_step(model, sch, x, i * torch.ones(len(x), dtype=torch.long), noises[i], log_betas=log_betas, **kw)
         x = d["sample"]
         l_x.append(x)
         l_mean.append(d["mean"])

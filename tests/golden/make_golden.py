@@ -263,8 +263,53 @@ def gen_edm():
         save(f"edm_sample_step_T4{tag}", seed=seed + 1, x=x * 3, idx=idx, y=y, **ds)
 
 
+def gen_edm_trainer():
+    """One DxMI_Trainer_Cond step on a shrunken class-conditional EDM net at 32x32 (sample -> append_buffer -> update_f_v ->
+    update_sampler_mixed_precision), B=4, T=4, through the reference's MixedPrecisionTrainer with use_fp16=True
+    bookkeeping (flat fp32 masters in 3 groups, 2**20 loss scale) over an fp32 model, RAdam, CPU generator seeded."""
+    import contextlib, io
+    import models.DxMI.trainer as ref_tr
+    import models.DxMI.openai_diffusion as ref_oa
+    import models.cm.fp16_util as ref_fp16
+    from torch.optim import RAdam, Adam
+    B, T = 4, 4
+    net, diffusion = build_edm(image_size=32, attention_resolutions="16")
+    with contextlib.redirect_stdout(io.StringIO()):
+        sampler = ref_oa.OpenAIDiffusion(net, diffusion, n_timesteps=T, sample_shape=(3, 32, 32), class_cond=True, num_classes=1000,
+                                         trainable_beta="fix_last", stochastic_last=True, rho=4.0)
+    v = build_value()
+    mp = ref_fp16.MixedPrecisionTrainer(model=net, use_fp16=True, initial_lg_loss_scale=20, special_key="log_betas")
+    opt = RAdam([{"params": mp.master_params[1:], "lr": 1e-6}, {"params": mp.master_params[0:1], "lr": 1e-4}], weight_decay=0.0)
+    opt_v = Adam(v.parameters(), lr=1e-5)
+    trainer = ref_tr.DxMI_Trainer_Cond(batchsize=B, tau1=0.1, tau2=0.01, gamma=1, n_timesteps=T, use_sampler_beta=True, adavelreg=0.99,
+                                       entropy_in_value=None, velocity_in_value=None, value_grad_clip=True, time_cost=0,
+                                       skip_sampler_tau=1, time_cost_sig=1)
+    with contextlib.redirect_stdout(io.StringIO()):
+        trainer.set_models(v=v, sampler=sampler, optimizer=opt, optimizer_v=opt_v)
+    g = torch.Generator().manual_seed(556)
+    img = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    y = torch.tensor([3, 977, 14, 500])
+    seed = 1357
+    torch.manual_seed(seed)
+    sampler.eval()
+    d_sample = sampler.sample(B, device="cpu", i_class=y)
+    buf = ref_tr.append_buffer(ref_tr.reset_buffer("cpu"), d_sample)
+    w0 = {k: p.detach().clone() for k, p in net.named_parameters()}
+    d_energy = trainer.update_f_v(img, d_sample, buf, y=y)
+    d_sampler = trainer.update_sampler_mixed_precision(buf, mp_trainer=mp)
+    nsd = dict(net.named_parameters())
+    pick = ["out.2.weight", "input_blocks.1.0.in_layers.2.weight", "middle_block.1.qkv.weight", "input_blocks.1.0.emb_layers.1.bias",
+            "label_emb.weight", "time_embed.2.weight"]
+    save("edm_trainer_step", seed=seed, B=B, T=T, img=img, y=y,
+         energy_keys=np.array(list(d_energy.keys())), energy_vals=np.array(list(d_energy.values()), dtype=np.float64),
+         sampler_keys=np.array(list(d_sampler.keys())), sampler_vals=np.array(list(d_sampler.values()), dtype=np.float64),
+         betas_for_q=trainer.betas_for_q, buffer_timestep=buf["timestep"], buffer_y=buf["y"], buffer_state_sum=buf["state"].double().sum(),
+         lg_loss_scale_after=np.float64(mp.lg_loss_scale), log_betas_after=nsd["log_betas"].detach(),
+         delta_keys=np.array(pick), **{f"delta_{i}": (nsd[k].detach() - w0[k]) for i, k in enumerate(pick)})
+
+
 GENS = {"schedule": gen_schedule, "unet": gen_unet_forward, "var_sampling": gen_var_sampling,
-        "sample_step": gen_sample_step, "value": gen_value, "trainer": gen_trainer_step, "edm": gen_edm}
+        "sample_step": gen_sample_step, "value": gen_value, "trainer": gen_trainer_step, "edm": gen_edm, "edm_trainer": gen_edm_trainer}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

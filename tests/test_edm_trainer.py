@@ -1,0 +1,147 @@
+"""DxMI train step on the EDM backbone (row a13): oracle pinned to the reference's golden DxMI_Trainer_Cond step (CPU) and
+the HIP train step (U-Net forward/backward through models/cm/unet_train.py, MixedPrecisionTrainer, RAdam) against the
+same golden step (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+EDM_KW = dict(image_size=32, class_cond=True, learn_sigma=False, num_channels=64, num_res_blocks=1, channel_mult="1,2",
+              num_heads=4, num_head_channels=64, num_heads_upsample=-1, attention_resolutions="16", dropout=0.0,
+              use_checkpoint=False, use_scale_shift_norm=True, resblock_updown=True, use_fp16=True,
+              use_new_attention_order=False, weight_schedule="uniform")
+SAMPLER_KW = dict(n_timesteps=4, sample_shape=(3, 32, 32), class_cond=True, num_classes=1000, trainable_beta="fix_last",
+                  stochastic_last=True, rho=4.0)
+TRAINER_KW = dict(tau1=0.1, tau2=0.01, gamma=1, n_timesteps=4, use_sampler_beta=True, adavelreg=0.99, entropy_in_value=None,
+                  velocity_in_value=None, value_grad_clip=True, time_cost=0, skip_sampler_tau=1, time_cost_sig=1)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def golden_logs(g, which):
+    return dict(zip([str(k) for k in g[f"{which}_keys"]], [float(v) for v in g[f"{which}_vals"]]))
+
+
+def value_sd():
+    from models.modules import IGEBMEncoderV2
+    from models.value import TimeIndependentValue
+    from oracle.weights import formula_tensor
+    v = TimeIndependentValue(IGEBMEncoderV2(in_chan=3, out_chan=1, use_spectral_norm=False, keepdim=False,
+                                            out_activation="linear", avg_pool_dim=1, learn_out_scale=True, nh=128))
+    sd = {k: formula_tensor(k, t.shape) for k, t in v.state_dict().items()}
+    v.load_state_dict(sd)
+    return v, sd
+
+
+def test_oracle_edm_trainer_step_matches_reference(golden_dir):
+    from oracle import edm
+    from oracle.edm_trainer import OracleDxMICond
+    from oracle.weights import formula_tensor
+    torch.set_num_threads(8)
+    g = load(golden_dir, "edm_trainer_step")
+    B, T = int(g["B"]), int(g["T"])
+    cfg = edm.EDMConfig(image_size=32, model_channels=64, num_res_blocks=1, attention_resolutions=(2,), channel_mult=(1, 2))
+    sch = edm.EDMSchedule(T, stochastic_last=True, rho=4.0, trainable_beta="fix_last")
+    net_sd = {k: formula_tensor(k, s) for k, s in edm.state_dict_shapes(cfg).items()}
+    net_sd["log_betas"] = sch.log_betas.clone()
+    _, vsd = value_sd()
+    o = OracleDxMICond(net_sd, vsd, cfg, sch, B, T, skip_sampler_tau=1)
+    img, y = torch.from_numpy(g["img"]), torch.from_numpy(g["y"])
+    torch.manual_seed(int(g["seed"]))
+    x0 = torch.randn(B, 3, 32, 32) * 80.0
+    zs = [torch.randn(B, 3, 32, 32) for _ in range(T)]
+    d = o.sample(x0, zs, y)
+    buf = o.append_buffer(o.reset_buffer(), d)
+    assert torch.equal(buf["timestep"], torch.from_numpy(g["buffer_timestep"])) and torch.equal(buf["y"], torch.from_numpy(g["buffer_y"]))
+    assert abs(buf["state"].double().sum().item() - float(g["buffer_state_sum"])) < 1e-1
+    le = o.update_f_v(img, d, buf)
+    w0 = {k: p.detach().clone() for k, p in o.net.items()}
+    ls = o.update_sampler_mixed_precision(buf)
+    ge, gs = golden_logs(g, "energy"), golden_logs(g, "sampler")
+    assert list(le.keys()) == list(ge.keys()) and list(ls.keys()) == list(gs.keys())
+    for got, ref in ((le, ge), (ls, gs)):
+        for k in ref:
+            assert abs(got[k] - ref[k]) <= 5e-4 * max(1.0, abs(ref[k])), (k, got[k], ref[k])
+    np.testing.assert_allclose(o.betas_for_q.numpy(), g["betas_for_q"], rtol=1e-5)
+    np.testing.assert_allclose(o.net["log_betas"].detach().numpy(), g["log_betas_after"], rtol=1e-5, atol=1e-6)
+    assert abs(o.lg_loss_scale - float(g["lg_loss_scale_after"])) < 1e-9
+    for i, k in enumerate(str(s) for s in g["delta_keys"]):
+        got, ref = (o.net[k].detach() - w0[k]).numpy(), g[f"delta_{i}"]
+        big = np.abs(ref) > 0.3 * np.abs(ref).max()
+        assert np.mean(np.sign(got[big]) == np.sign(ref[big])) > 0.97, k
+        np.testing.assert_allclose(got[big], ref[big], rtol=0.1, atol=1e-9, err_msg=k)
+
+
+def test_product_mixed_precision_trainer_bookkeeping_cpu():
+    """fp16_util shim on CPU tensors: 3 master groups, loss scale growth, overflow skip, copy-back."""
+    from models.cm.fp16_util import MixedPrecisionTrainer
+    m = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    m.register_parameter("log_betas", torch.nn.Parameter(torch.zeros(5)))
+    mp = MixedPrecisionTrainer(model=m, use_fp16=True, initial_lg_loss_scale=10, special_key="log_betas")
+    assert [tuple(p.shape) for p in mp.master_params] == [(5,), (5,), (1, 18)]
+    opt = torch.optim.SGD(mp.master_params, lr=0.1)
+    w0 = m[0].weight.detach().clone()
+    loss = m(torch.ones(2, 4)).sum() + m.log_betas.sum()
+    mp.zero_grad()
+    mp.backward(loss)
+    assert mp.optimize(opt) and abs(mp.lg_loss_scale - 10.001) < 1e-12
+    assert torch.allclose(m.log_betas.detach(), torch.full((5,), -0.1)) and not torch.equal(m[0].weight.detach(), w0)
+    mp.zero_grad()
+    mp.backward(m(torch.full((2, 4), float("inf"))).sum())
+    assert not mp.optimize(opt) and abs(mp.lg_loss_scale - 9.001) < 1e-12
+
+
+@pytest.mark.gpu
+def test_hip_edm_trainer_step_vs_reference(golden_dir):
+    """Full HIP EDM train step at the golden configuration: bf16 activations/gradients against the reference's fp32 —
+    scalar statistics within 5e-2 relative (|.|<1: absolute), integer paths exact, parameter updates in direction."""
+    from torch.optim import RAdam, Adam
+    from models.DxMI.openai_diffusion import OpenAIDiffusion
+    from models.DxMI.trainer import DxMI_Trainer_Cond, append_buffer, reset_buffer
+    from models.cm.fp16_util import MixedPrecisionTrainer
+    from models.cm.script_util import create_model_and_diffusion
+    from oracle.weights import formula_tensor
+    DEV = "cuda:0"
+    g = load(golden_dir, "edm_trainer_step")
+    B, T = int(g["B"]), int(g["T"])
+    net, diffusion = create_model_and_diffusion(**EDM_KW)
+    net.load_state_dict({k: formula_tensor(k, v.shape) for k, v in net.state_dict().items()})
+    sampler = OpenAIDiffusion(net, diffusion, **SAMPLER_KW)
+    net.to(DEV)
+    v, _ = value_sd()
+    v.to(DEV)
+    mp = MixedPrecisionTrainer(model=net, use_fp16=True, initial_lg_loss_scale=20, special_key="log_betas")
+    opt = RAdam([{"params": mp.master_params[1:], "lr": 1e-6}, {"params": mp.master_params[0:1], "lr": 1e-4}], weight_decay=0.0)
+    opt_v = Adam(v.parameters(), lr=1e-5)
+    trainer = DxMI_Trainer_Cond(batchsize=B, **TRAINER_KW)
+    trainer.set_models(v=v, sampler=sampler, optimizer=opt, optimizer_v=opt_v)
+    img, y = torch.from_numpy(g["img"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    torch.manual_seed(int(g["seed"]))
+    noise = torch.stack([torch.randn(B, 3, 32, 32) for _ in range(T + 1)])     # the reference's CPU draws, in its order
+    sampler.eval()
+    d = sampler.sample(B, device=DEV, i_class=y, noise=noise)
+    buf = append_buffer(reset_buffer(DEV), d)
+    assert torch.equal(buf["timestep"].cpu(), torch.from_numpy(g["buffer_timestep"])) and torch.equal(buf["y"].cpu(), torch.from_numpy(g["buffer_y"]))
+    assert abs(buf["state"].double().sum().item() - float(g["buffer_state_sum"])) < 2e-2 * abs(float(g["buffer_state_sum"])) + 50
+    le = trainer.update_f_v(img, d, buf, y=y)
+    pick = [str(s) for s in g["delta_keys"]]
+    P = dict(net.named_parameters())
+    w0 = {k: P[k].detach().clone() for k in pick}
+    orig = sampler.sample_step
+    sampler.sample_step = lambda x, t, **kw: orig(x, t, noise=torch.randn(x.shape).to(x.device), **kw)   # CPU draw, reference order
+    ls = trainer.update_sampler_mixed_precision(buf, mp_trainer=mp)
+    ge, gs = golden_logs(g, "energy"), golden_logs(g, "sampler")
+    assert list(le.keys()) == list(ge.keys()) and list(ls.keys()) == list(gs.keys())
+    bad = [(k, got[k], ref[k]) for got, ref in ((le, ge), (ls, gs)) for k in ref if abs(got[k] - ref[k]) > 5e-2 * max(1.0, abs(ref[k]))]
+    assert not bad, bad
+    np.testing.assert_allclose(trainer.betas_for_q.cpu().numpy(), g["betas_for_q"], rtol=5e-3)
+    assert abs(mp.lg_loss_scale - float(g["lg_loss_scale_after"])) < 1e-9
+    assert np.allclose(net.log_betas.detach().cpu().numpy(), g["log_betas_after"], atol=2e-4)
+    for i, k in enumerate(pick):
+        got, ref = (P[k].detach() - w0[k]).cpu().numpy(), g[f"delta_{i}"]
+        big = np.abs(ref) > 0.3 * np.abs(ref).max()
+        agree = np.mean(np.sign(got[big]) == np.sign(ref[big]))
+        assert agree > 0.9, (k, agree)
