@@ -45,13 +45,18 @@ CONFIGS["imagenet64_T10"] = {
     "diffusion": dict(_EDM_COMMON, image_size=64, num_channels=192, class_cond=True),
     "sampler": {"sample_shape": [3, 64, 64], "n_timesteps": 10, "class_cond": True, "num_classes": 1000,
                 "trainable_beta": "fix_last", "sigma_min": 0.002, "sigma_max": 80.0},
+    "trainer": {"_target_": "models.DxMI.trainer.DxMI_Trainer_Cond", "tau1": 0.1, "tau2": 0.01, "gamma": 1, "n_timesteps": 10,
+                "use_sampler_beta": True, "adavelreg": 0.99, "entropy_in_value": None, "velocity_in_value": None,
+                "value_grad_clip": True, "time_cost": 0, "skip_sampler_tau": 3, "time_cost_sig": 1},
     "value": _VALUE_IGEBM,
-    "training": {"pretrained_path": "pretrained/imagenet64_edm/edm_imagenet64_ema.pt", "batchsize": 128,
-                 "sampling_batchsize": 100, "seed": 42, "lr": 1e-8, "v_lr": 1e-5, "beta_lr": 1e-6},
-    "data": {"name": "imagenet64"},
+    "training": {"pretrained_path": "pretrained/imagenet64_edm/edm_imagenet64_ema.pt", "value_ckpt": None, "n_iter": 10000,
+                 "batchsize": 128, "sampling_batchsize": 100, "n_fid_samples": 5000, "seed": 42, "lr": 1e-8, "v_lr": 1e-5,
+                 "beta_lr": 1e-6, "weight_decay": 0.0, "initial_log_loss_scale": 20, "log_every": 20, "fid_every": 100},
+    "data": {"name": "imagenet64", "image_size": 64, "class_cond": True, "n_class": 1000},
 }
 CONFIGS["imagenet64_T4"] = copy.deepcopy(CONFIGS["imagenet64_T10"])
 CONFIGS["imagenet64_T4"]["sampler"].update({"n_timesteps": 4, "stochastic_last": True, "rho": 4.0})
+CONFIGS["imagenet64_T4"]["trainer"].update({"n_timesteps": 4, "skip_sampler_tau": 0, "skip_running_last": 1})
 CONFIGS["lsun_bedroom_T4"] = {
     "diffusion": dict(_EDM_COMMON, image_size=256, num_channels=256, class_cond=False),
     "sampler": {"sample_shape": [3, 256, 256], "n_timesteps": 4, "class_cond": False, "num_classes": 1000,

@@ -40,8 +40,8 @@ def create_model(image_size, num_channels, num_res_blocks, channel_mult="", lear
             raise ValueError(f"unsupported image size: {image_size}")
         channel_mult = table[image_size]
     else:
-        channel_mult = tuple(int(m) for m in channel_mult.split(","))
-    attention_ds = tuple(image_size // int(res) for res in attention_resolutions.split(","))
+        channel_mult = tuple(int(m) for m in str(channel_mult).split(","))
+    attention_ds = tuple(image_size // int(res) for res in str(attention_resolutions).split(","))   # str(): a CLI override "16" arrives as int
     return UNetModel(image_size=image_size, in_channels=3, model_channels=num_channels,
                      out_channels=(3 if not learn_sigma else 6), num_res_blocks=num_res_blocks,
                      attention_resolutions=attention_ds, dropout=dropout, channel_mult=channel_mult,

@@ -1,0 +1,155 @@
+"""DxMI training on the EDM backbones (ImageNet-64, LSUN) on MI355X; CLI-compatible with the reference's
+train_image_large.py:94-330 for the training path.
+
+    torchrun --nproc_per_node=N train_image_large.py --config configs/imagenet64/T10.yaml \
+        --dataset configs/imagenet64/imagenet64.yaml --run myrun [--training.lr 1e-8 ...]
+    (or --config builtin:imagenet64_T10 --dataset builtin --synthetic_data for a self-contained run)
+
+Same flow as the reference: config merge + `--a.b.c v` overrides, seeding with seed+rank, create_model_and_diffusion,
+pretrained EDM weights when the file exists, OpenAIDiffusion, value net from `_target_`, MixedPrecisionTrainer with the
+`log_betas` special key and RAdam on its master tensors (:152-168), Adam for the value net, per-rank batch =
+batchsize // world, and per iteration sample -> append_buffer -> update_f_v -> update_sampler_mixed_precision ->
+reset_buffer (:301-321).  Differences, all outside the accelerated path: gradients are exchanged by one flat RCCL
+all-reduce per backward (dxmi_hip/dist.py) instead of DDP buckets; FID / wandb / tensorboard are skipped unless their
+packages and statistics files exist; `--synthetic_data` feeds uniform images and random labels.
+Checkpoints: `sampler.pth` ({'state_dict', 'fid', 'i_iter'}) and `value.pth`, the names generate_large.py reads.
+"""
+import argparse
+import os
+import random
+
+import numpy as np
+import torch
+from torch.optim import Adam, RAdam
+
+import cmd_utils as cmd
+import dxmi_config
+from dxmi_hip.dist import broadcast_parameters
+from models.cm.fp16_util import MixedPrecisionTrainer
+from models.cm.script_util import create_model_and_diffusion
+from models.DxMI.openai_diffusion import OpenAIDiffusion
+from models.DxMI.trainer import append_buffer, reset_buffer
+from utils import mkdir_p, print0
+
+
+def synthetic_batches(batchsize, image_size, class_cond, n_class, device, seed):
+    g = torch.Generator(device=device).manual_seed(seed)
+    while True:
+        data = torch.rand(batchsize, 3, image_size, image_size, device=device, generator=g) * 2 - 1
+        cond = {"y": torch.randint(0, n_class, (batchsize,), device=device, generator=g)} if class_cond else {}
+        yield data, cond
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, required=True)
+    ap.add_argument("--dataset", type=str, required=True)
+    ap.add_argument("--run", type=str, required=True)
+    ap.add_argument("--synthetic_data", action="store_true")
+    ap.add_argument("--max_iters", type=int, default=None, help="stop after this many iterations (smoke runs)")
+    args, unknown = ap.parse_known_args()
+    d_cmd_cfg = cmd.parse_nested_args(cmd.parse_unknown_args(unknown))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if local_rank == 0:
+        print("Overriding", d_cmd_cfg)
+
+    if args.config.startswith("builtin:"):
+        import configs_builtin
+        cfg = configs_builtin.get(args.config.split(":", 1)[1])
+    else:
+        cfg = dxmi_config.merge(dxmi_config.load(args.config), dxmi_config.load(args.dataset))
+    cfg = dxmi_config.merge(cfg, d_cmd_cfg)
+
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(device)
+    seed = cfg.training.seed
+    torch.manual_seed(seed + local_rank)
+    np.random.seed(seed + local_rank)
+    torch.cuda.manual_seed_all(seed + local_rank)
+    random.seed(seed + local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl", init_method="env://")   # RCCL
+
+    unet, diffusion = create_model_and_diffusion(**cfg.diffusion)
+    pre = cfg.training.get("pretrained_path")
+    if pre and os.path.exists(pre):
+        unet.load_state_dict(torch.load(pre, map_location="cpu"))
+        print0(f"pretrained EDM weights loaded from {pre}")
+    else:
+        print0("no pretrained EDM checkpoint found: random initialisation (zero-initialised output layers stay zero)")
+    sampler = OpenAIDiffusion(unet, diffusion, **cfg.sampler)
+    unet.to(device)
+    if cfg.diffusion.use_fp16:
+        unet.convert_to_fp16()
+    v = dxmi_config.instantiate(cfg.value)
+    if cfg.training.get("value_ckpt") is not None:
+        v.load_pretrained(torch.load(cfg.training.value_ckpt, map_location="cpu"))
+    v.to(device)
+    broadcast_parameters(unet)
+    broadcast_parameters(v)
+
+    lls = cfg.training.get("initial_log_loss_scale", 20)
+    if cfg.training.get("beta_lr") is not None:
+        mp_trainer = MixedPrecisionTrainer(model=unet, use_fp16=cfg.diffusion.use_fp16, initial_lg_loss_scale=lls, special_key="log_betas")
+        if cfg.diffusion.use_fp16:
+            groups = [{"params": mp_trainer.master_params[1:], "lr": cfg.training.lr},
+                      {"params": mp_trainer.master_params[0:1], "lr": cfg.training.beta_lr}]
+        else:   # masters are the model parameters themselves: split by name
+            groups = [{"params": [p for n, p in unet.named_parameters() if "log_betas" not in n], "lr": cfg.training.lr},
+                      {"params": [unet.log_betas], "lr": cfg.training.beta_lr}]
+        opt = RAdam(groups, weight_decay=cfg.training.get("weight_decay", 0.0))
+    else:
+        mp_trainer = MixedPrecisionTrainer(model=unet, use_fp16=cfg.diffusion.use_fp16, initial_lg_loss_scale=lls)
+        opt = RAdam(mp_trainer.master_params, lr=cfg.training.lr, weight_decay=cfg.training.get("weight_decay", 0.0))
+    opt_v = Adam(v.parameters(), lr=cfg.training.v_lr)
+
+    batchsize = cfg.training.batchsize // world
+    class_cond = bool(cfg.data.get("class_cond", cfg.sampler.get("class_cond", False)))
+    if args.synthetic_data:
+        loader = synthetic_batches(batchsize, cfg.diffusion.image_size, class_cond, cfg.data.get("n_class", 1000), device, seed + local_rank)
+    else:
+        from models.cm.dxmi_util import infinite_loader, load_data   # the reference's image-folder pipeline (out of scope here)
+        from torch.utils.data import DataLoader
+        from torch.utils.data.distributed import DistributedSampler
+        ds = load_data(data_dir=cfg.data.data_dir, cachefile=cfg.data.cachefile, batch_size=cfg.training.batchsize,
+                       image_size=cfg.data.image_size, class_cond=cfg.data.class_cond, deterministic=cfg.data.deterministic,
+                       random_crop=False, random_flip=True)
+        dsamp = DistributedSampler(ds) if world > 1 else None
+        loader = infinite_loader(DataLoader(ds, batch_size=batchsize, shuffle=dsamp is None, sampler=dsamp, num_workers=4, drop_last=True))
+
+    model_cfg_name = os.path.basename(args.config).split(".")[0].replace("builtin:", "")
+    logdir = os.path.join(f"results/{cfg.data.name}/{model_cfg_name}", args.run)
+    if local_rank == 0:
+        mkdir_p(logdir)
+        dxmi_config.save(cfg, os.path.join(logdir, "config.yaml"))
+
+    trainer = dxmi_config.instantiate(cfg.trainer, batchsize=batchsize)
+    trainer.set_models(v=v, sampler=sampler, optimizer=opt, optimizer_v=opt_v)
+
+    n_iter = cfg.training.n_iter if args.max_iters is None else min(cfg.training.n_iter, args.max_iters)
+    state_dict = reset_buffer(device)
+    i_iter = -1
+    for i_iter in range(n_iter):
+        data, cond = next(loader)
+        data = data.to(device)
+        y = cond.get("y", None)
+        y = y.to(device) if y is not None else None
+        sampler.eval()
+        d_sample = sampler.sample(len(data), device=device, i_class=y)
+        append_buffer(state_dict, d_sample)
+        d_energy = trainer.update_f_v(data, d_sample, state_dict, y=y)
+        d_sampler = trainer.update_sampler_mixed_precision(state_dict, mp_trainer=mp_trainer, d_sample=d_sample)
+        state_dict = reset_buffer(device)
+        if (i_iter + 1) % cfg.training.log_every == 0:
+            print0(f"iter {i_iter}: d_loss {d_energy['ebm/d_loss_']:.4f} v_loss {d_energy['ebm/v_loss_']:.4f} "
+                   f"sampler_loss {d_sampler['sampler/sampler_loss_']:.4f} lg_loss_scale {mp_trainer.lg_loss_scale:.3f}")
+    if local_rank == 0:
+        torch.save({"state_dict": unet.state_dict(), "fid": None, "i_iter": i_iter}, os.path.join(logdir, "sampler.pth"))
+        torch.save({"state_dict": v.state_dict()}, os.path.join(logdir, "value.pth"))
+        print0(f"saved {logdir}/sampler.pth and value.pth after {i_iter + 1} iterations")
+
+
+if __name__ == "__main__":
+    main()

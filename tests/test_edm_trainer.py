@@ -145,3 +145,31 @@ def test_hip_edm_trainer_step_vs_reference(golden_dir):
         big = np.abs(ref) > 0.3 * np.abs(ref).max()
         agree = np.mean(np.sign(got[big]) == np.sign(ref[big]))
         assert agree > 0.9, (k, agree)
+
+
+@pytest.mark.gpu
+def test_cli_train_image_large_then_generate(tmp_path):
+    """train_image_large.py (2 synthetic iterations on a shrunken imagenet64-style config through cmd overrides), then
+    generate_large.py from the log dir it wrote."""
+    import shutil
+    import subprocess
+    import sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffusion-by-maxentirl_amd")
+    env = dict(os.environ, LOCAL_RANK="0", WORLD_SIZE="1")
+    over = ["--diffusion.image_size", "32", "--diffusion.num_channels", "64", "--diffusion.num_res_blocks", "1",
+            "--diffusion.channel_mult", "1,2", "--diffusion.attention_resolutions", "16", "--sampler.sample_shape", "[3,32,32]",
+            "--sampler.n_timesteps", "4", "--trainer.n_timesteps", "4", "--trainer.skip_sampler_tau", "1",
+            "--training.batchsize", "4", "--training.log_every", "1", "--data.image_size", "32"]
+    r = subprocess.run([sys.executable, "train_image_large.py", "--config", "builtin:imagenet64_T10", "--dataset", "builtin",
+                        "--run", "t", "--synthetic_data", "--max_iters", "2"] + over, cwd=pkg, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    logdir = os.path.join(pkg, "results", "imagenet64", "imagenet64_T10", "t")
+    ck = torch.load(os.path.join(logdir, "sampler.pth"), map_location="cpu")
+    assert "log_betas" in ck["state_dict"] and "input_blocks.0.0.weight" in ck["state_dict"] and ck["i_iter"] == 1
+    assert all(torch.isfinite(v).all() for v in ck["state_dict"].values())
+    r2 = subprocess.run([sys.executable, "generate_large.py", "--log_dir", logdir, "--n_sample", "4", "--batchsize", "4", "--skip_fid"],
+                        cwd=pkg, env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
+    assert len([f for f in os.listdir(os.path.join(logdir, "generated")) if f.endswith(".png")]) == 4
+    shutil.rmtree(os.path.join(pkg, "results"), ignore_errors=True)
