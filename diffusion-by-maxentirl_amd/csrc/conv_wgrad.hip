@@ -165,14 +165,18 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
 
 // column sums of a [P][C] bf16 matrix -> fp32 [C] (bias gradient); fixed-order two-level reduction
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ x, float* __restrict__ part, long P,
-                                                            int C, int rows_per_block) {
-    // thread t handles 8-channel piece (t % (C/8)); rows strided by 256/(C/8)
+                                                            int Cfull, int rows_per_block) {
+    // thread t handles 8-channel piece (t % (C/8)); rows strided by 256/(C/8).  gridDim.y column blocks of
+    // C = Cfull / gridDim.y channels each (rows keep the full pitch) serve Cfull > 2048.
+    const int C = Cfull / gridDim.y;
+    x += blockIdx.y * C;
+    part += blockIdx.y * C;
     const int c8n = C / 8;
     const int pc = threadIdx.x % c8n, r0 = threadIdx.x / c8n, rstep = blockDim.x / c8n;  // blockDim.x = rstep * c8n
     const long base = (long)blockIdx.x * rows_per_block;
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (long r = base + r0; r < base + rows_per_block && r < P; r += rstep) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * C + pc * 8);
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + r * Cfull + pc * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
     }
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restr
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] += red[k][e];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) part[(size_t)blockIdx.x * C + threadIdx.x * 8 + e] = t[e];
+        for (int e = 0; e < 8; ++e) part[(size_t)blockIdx.x * Cfull + threadIdx.x * 8 + e] = t[e];
     }
 }
 // 16 channels per workgroup, 16 row-lanes per channel: every lane adds its strided share of the partial rows, then one
@@ -273,13 +277,17 @@ extern "C" int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int
 extern "C" int dxmi_colsum_bf16(const void* x, float* out, void* workspace, int64_t P, int32_t C, int32_t accumulate,
                                 void* stream) {
     DXMI_CHECK_ARG(x && out && workspace, "dxmi_colsum_bf16: null pointer");
-    DXMI_CHECK_ARG(C % 8 == 0 && C / 8 <= 256, "dxmi_colsum_bf16: C=%d unsupported", C);
-    const int cthreads = (256 / (C / 8)) * (C / 8);
+    int cblocks = 1;
+    while (C % cblocks != 0 || (C / cblocks) % 8 != 0 || C / cblocks > 2048) {
+        ++cblocks;
+        DXMI_CHECK_ARG(cblocks <= 64, "dxmi_colsum_bf16: C=%d unsupported", C);
+    }
+    const int cthreads = (256 / (C / cblocks / 8)) * (C / cblocks / 8);
     int rows_per_block = 512;
     while ((P + rows_per_block - 1) / rows_per_block > 256) rows_per_block *= 2;  // <= 256 partial rows
     const int nblocks = (int)((P + rows_per_block - 1) / rows_per_block);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks), dim3(cthreads), 0, st, (const bf16*)x, (float*)workspace, (long)P, C,
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblocks, cblocks), dim3(cthreads), 0, st, (const bf16*)x, (float*)workspace, (long)P, C,
                        rows_per_block);
     DXMI_CHECK_LAUNCH("dxmi_colsum_bf16");
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)workspace, out, nblocks, C,

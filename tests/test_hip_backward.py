@@ -79,6 +79,9 @@ def test_colsum_and_pool_bwd_and_head_bwd(ops):
     N, C, H = 5, 256, 8
     dy = bf(torch.randn(N, C, H, H, generator=g))
     assert rel_l2(ops.colsum(nhwc(dy)).cpu(), dy.sum((0, 2, 3))) < 1e-5
+    for Cw, Hw in ((2304, 8), (768, 16), (192, 32)):   # EDM widths: q|k|v of 768 channels goes through 2 column blocks
+        dw = bf(torch.randn(3, Cw, Hw, Hw, generator=g))
+        assert rel_l2(ops.colsum(nhwc(dw)).cpu(), dw.sum((0, 2, 3))) < 1e-5, Cw
     a = bf(torch.randn(N, C, H, H, generator=g))
     ref = dy * torch.where(a > 0, 1.0, 0.2)
     assert rel_l2(nchw(ops.pool_act_bwd(nhwc(dy), nhwc(a), False, 0.2)), ref) < 4e-3

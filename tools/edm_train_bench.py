@@ -1,0 +1,57 @@
+"""Full-size EDM DxMI train step on one GPU (synthetic data): python tools/edm_train_bench.py imagenet64_T10 16 [steps]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "diffusion-by-maxentirl_amd")]
+import torch
+from torch.optim import Adam, RAdam
+import configs_builtin, dxmi_config
+from models.cm.fp16_util import MixedPrecisionTrainer
+from models.cm.script_util import create_model_and_diffusion
+from models.DxMI.openai_diffusion import OpenAIDiffusion
+from models.DxMI.trainer import append_buffer, reset_buffer
+
+name, B = sys.argv[1], int(sys.argv[2])
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+dev = "cuda:0"
+cfg = configs_builtin.get(name)
+torch.manual_seed(0)
+unet, diffusion = create_model_and_diffusion(**cfg.diffusion)
+for p in unet.parameters():
+    if p.abs().max() == 0:
+        torch.nn.init.normal_(p, std=0.02)
+sampler = OpenAIDiffusion(unet, diffusion, **cfg.sampler)
+unet.to(dev)
+v = dxmi_config.instantiate(cfg.value).to(dev)
+mp = MixedPrecisionTrainer(model=unet, use_fp16=True, initial_lg_loss_scale=20, special_key="log_betas")
+opt = RAdam([{"params": mp.master_params[1:], "lr": 1e-8}, {"params": mp.master_params[0:1], "lr": 1e-6}])
+opt_v = Adam(v.parameters(), lr=1e-5)
+trainer = dxmi_config.instantiate(cfg.trainer, batchsize=B)
+trainer.set_models(v=v, sampler=sampler, optimizer=opt, optimizer_v=opt_v)
+res = cfg.diffusion.image_size
+g = torch.Generator(device=dev).manual_seed(1)
+
+
+def step():
+    data = torch.rand(B, 3, res, res, device=dev, generator=g) * 2 - 1
+    y = torch.randint(0, 1000, (B,), device=dev, generator=g) if cfg.sampler.class_cond else None
+    t = [time.perf_counter()]
+    sampler.eval()
+    d = sampler.sample(B, device=dev, i_class=y)
+    torch.cuda.synchronize(); t.append(time.perf_counter())
+    buf = append_buffer(reset_buffer(dev), d)
+    le = trainer.update_f_v(data, d, buf, y=y)
+    torch.cuda.synchronize(); t.append(time.perf_counter())
+    ls = trainer.update_sampler_mixed_precision(buf, mp_trainer=mp)
+    torch.cuda.synchronize(); t.append(time.perf_counter())
+    return [b - a for a, b in zip(t[:-1], t[1:])], le, ls
+
+
+step()
+tot = [0, 0, 0]
+for _ in range(steps):
+    dt, le, ls = step()
+    tot = [a + b for a, b in zip(tot, dt)]
+tot = [x / steps for x in tot]
+print(f"{name} B={B}: sample {tot[0]*1e3:.0f} ms, update_f_v {tot[1]*1e3:.0f} ms, update_sampler {tot[2]*1e3:.0f} ms -> {1/sum(tot):.3f} steps/s; "
+      f"v_loss {le['ebm/v_loss_']:.4f} sampler_loss {ls['sampler/sampler_loss_']:.4f} lg_loss_scale {mp.lg_loss_scale:.3f} "
+      f"peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
