@@ -58,8 +58,6 @@ def main():
     torch.cuda.manual_seed_all(seed + local_rank)
     random.seed(seed + local_rank)
     assert args.n_generate % args.batchsize == 0, "n_generate must be a multiple of batchsize"
-    if args.guidance_scale is not None:
-        raise NotImplementedError("value-guided sampling (--guidance_scale) is a 'next' row (SURVEY 8f rank 3)")
 
     if args.synthetic:
         import configs_builtin
@@ -69,7 +67,7 @@ def main():
         if not os.path.exists(config_path):
             raise ValueError(f"Config not found at {config_path}")
         run_config = dxmi_config.load(config_path)
-    output_path = os.path.join(args.log_dir, "generated")
+    output_path = os.path.join(args.log_dir, "generated" if args.guidance_scale is None else f"generated_{args.guidance_scale}")
     mkdir_p(output_path)
 
     net = dxmi_config.instantiate(run_config.sampler_net)
@@ -85,6 +83,20 @@ def main():
         print0(f"Loaded sampler from {sampler_path} (epoch {ckpt.get('epoch')}, FID {ckpt.get('fid')})")
     sampler.eval()
 
+    trainer = None
+    if args.guidance_scale is not None:   # reference :160-191: value net from value_best.pth, trainer only as the sampling driver
+        v = dxmi_config.instantiate(run_config.value).to(device)
+        if not args.synthetic:
+            value_path = os.path.join(args.log_dir, "value_best.pth")
+            if not os.path.exists(value_path) and os.path.exists(os.path.join(args.log_dir, f"value_{args.epoch}.pth")):
+                value_path = os.path.join(args.log_dir, f"value_{args.epoch}.pth")
+            if not os.path.exists(value_path):
+                raise ValueError(f"Value ftn not found at {value_path}")
+            v.load_state_dict(torch.load(value_path, map_location=device)["state_dict"])
+        v.eval()
+        trainer = dxmi_config.instantiate(run_config.trainer, batchsize=args.batchsize)
+        trainer.set_models(f=None, v=v, sampler=sampler, optimizer=None, optimizer_fstar=None, optimizer_v=None)
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group(backend="nccl", init_method="env://")  # RCCL; only the final barrier uses it
@@ -95,7 +107,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(n_batches):
         with torch.no_grad():
-            d_sample = sampler.sample(args.batchsize, device=device)
+            if trainer is not None:
+                d_sample = trainer.sample_guidance(n_sample=args.batchsize, device=device, guidance_scale=args.guidance_scale)
+            else:
+                d_sample = sampler.sample(args.batchsize, device=device)
         # one device->host copy per batch, already quantisation-ready
         sample = rescale(d_sample["sample"]).clamp(0, 1).cpu()
         if args.save_images:

@@ -35,8 +35,6 @@ def main():
     ap.add_argument("--skip_fid", action="store_true")
     ap.add_argument("--synthetic", type=str, default=None, help="builtin config name, e.g. imagenet64_T10 (random weights)")
     args, unknown = ap.parse_known_args()
-    if args.guidance_scale is not None:
-        raise NotImplementedError("value-guided sampling (--guidance_scale) is a 'next' row (SURVEY 8f)")
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -67,6 +65,18 @@ def main():
         unet.convert_to_fp16()
     sampler.eval()
 
+    trainer = None
+    if args.guidance_scale is not None:   # reference :132-148: value.pth + the trainer as the sampling driver
+        v = dxmi_config.instantiate(cfg.value).to(device)
+        if not args.synthetic:
+            value_path = os.path.join(args.log_dir, "value.pth")
+            if not os.path.exists(value_path):
+                raise ValueError(f"Value ftn not found at {value_path}")
+            v.load_state_dict(torch.load(value_path, map_location=device)["state_dict"])
+        v.eval()
+        trainer = dxmi_config.instantiate(cfg.trainer, batchsize=args.batchsize)
+        trainer.set_models(v=v, sampler=sampler, optimizer=None, optimizer_v=None)
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group(backend="nccl", init_method="env://")  # RCCL
@@ -76,7 +86,10 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n_batches):
-        d_sample = sampler.sample(args.batchsize, device=device, i_class=None, enable_grad=False)
+        if trainer is not None:
+            d_sample = trainer.sample_guidance(n_sample=args.batchsize, device=device, guidance_scale=args.guidance_scale)
+        else:
+            d_sample = sampler.sample(args.batchsize, device=device, i_class=None, enable_grad=False)
         sample = d_sample["sample"]
         if args.skip_fid:
             sample = ((sample + 1) / 2).clamp(0, 1).cpu()

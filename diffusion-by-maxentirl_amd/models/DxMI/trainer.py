@@ -225,6 +225,49 @@ class DxMI_Trainer:
                 logs[f"sigma/sigma_{t}_"] = sigma[t]
         return self._to_floats(logs)
 
+    # ------------------------------------------------------------------ value-guided sampling
+    def sample_guidance(self, n_sample, device, x0=None, guidance_scale=None, t_select=None, noise=None):
+        """reference :171-216: after every sampler transition, move the sample along the gradient of the value net at
+        the next step, scaled by guidance_scale * sigma.  The transition is the fused HIP step; the input gradient of the
+        value net is its HIP backward (models/value_train.py).  noise: optional per-step draws (extension, as in sample)."""
+        from torch.distributions import Normal
+        from ..modules import process_single_t
+        assert guidance_scale is not None, "guidance_scale must be given"
+        self.v.eval()
+        if x0 is None:
+            x0 = self._guidance_x0_scale(torch.randn(n_sample, *self.sampler.sample_shape, device=device))
+        x0 = x0.to(device)
+        l_x, l_guidance, l_logp, l_logp_orig = [x0.detach().clone()], [], [], []
+        x = x0
+        kw = self._guidance_model_kwargs(n_sample, device)
+        for t in range(self.n_timesteps):
+            tt = process_single_t(x, t)
+            with torch.no_grad():
+                d_step = self.sampler.sample_step(x, tt, **kw) if noise is None else self.sampler.sample_step(x, tt, noise=noise[t], **kw)
+            next_x = d_step["sample"].detach()
+            with torch.enable_grad():
+                next_x = next_x.requires_grad_(True)
+                value = self.v(next_x, tt + 1).squeeze()
+                grad = torch.autograd.grad(value.sum(), next_x)[0]
+            sigma = d_step["sigma"]
+            sigma = sigma.reshape(-1, *([1] * (x.ndim - 1))) if sigma.dim() == 1 else sigma
+            guidance = grad * guidance_scale * sigma
+            x = next_x + guidance if (t_select is None or t in t_select) else next_x
+            x = x.detach()
+            l_logp.append(d_step.get("logp", torch.tensor(0.)))
+            l_logp_orig.append(Normal(d_step["mean"], sigma).log_prob(x).mean(-1).mean(-1).mean(-1))
+            l_guidance.append(guidance)
+            l_x.append(x.clone())
+        return {"sample": x, "l_sample": l_x, "logp": l_logp, "logp_on": l_logp_orig,
+                "logp_traj": torch.stack([torch.as_tensor(v).to(x.device) * torch.ones(len(x), device=x.device) for v in l_logp]).sum(dim=0),
+                "logp_on_traj": torch.stack(l_logp_orig).sum(dim=0), "guidance": l_guidance}
+
+    def _guidance_x0_scale(self, x0):
+        return x0
+
+    def _guidance_model_kwargs(self, n_sample, device):
+        return {}
+
     @staticmethod
     def _to_floats(logs):
         """One device->host synchronisation for the whole dictionary."""
@@ -371,6 +414,14 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
             for t, beta in enumerate(self.betas_for_q):
                 logs[f"adavelreg/beta{t}_"] = beta
         return self._to_floats(logs)
+
+    def _guidance_x0_scale(self, x0):          # reference :818-820: EDM trajectories start at sigma_max * N(0, I)
+        return x0 * self.sampler.sigma_max
+
+    def _guidance_model_kwargs(self, n_sample, device):   # reference :829-831 ("hard coding": random ImageNet labels)
+        if not self.sampler.class_cond:
+            return {}
+        return {"y": torch.randint(0, self.sampler.num_classes or 1000, (n_sample,), device=device)}
 
     def update_sampler_mixed_precision(self, state_dict, mp_trainer, d_sample=None):
         """reference :693-746: one optimiser step per `batchsize` slice of ALL buffered transitions."""

@@ -111,6 +111,23 @@ class OracleDxMI:
             logs[f"adavelreg/beta{t}_"] = b.item()
         return logs
 
+    # ---- trainer.py:171-216
+    def sample_guidance(self, x0, noises, guidance_scale):
+        x = x0
+        l_x, l_g, l_on = [x0.clone()], [], []
+        for t in range(self.T):
+            tt = torch.full((len(x),), t, dtype=torch.long)
+            with torch.no_grad():
+                d = ovs.sample_step(self.unet, self.sched, self.net["log_betas"].detach(), x, tt, noises[t])
+            nx = d["sample"].detach().requires_grad_(True)
+            grad = torch.autograd.grad(self.v(nx).squeeze().sum(), nx)[0]
+            guidance = grad * guidance_scale * d["sigma"]
+            x = (nx + guidance).detach()
+            l_on.append(torch.distributions.Normal(d["mean"], d["sigma"]).log_prob(x).mean(-1).mean(-1).mean(-1))
+            l_g.append(guidance)
+            l_x.append(x.clone())
+        return {"sample": x, "l_sample": l_x, "guidance": l_g, "logp_on": l_on}
+
     # ---- trainer.py:348-408 (n_generator = 1)
     def update_sampler(self, buf, z):
         permutation = torch.randperm(buf["state"].shape[0])

@@ -194,6 +194,24 @@ def gen_trainer_step():
          net_conv_out_w_delta=(nsd["conv_out.weight"] - formula_state_dict({"conv_out.weight": nsd["conv_out.weight"]})["conv_out.weight"]))
 
 
+def gen_guidance():
+    """Value-guided sampling (trainer.py:171-216) with the CIFAR T=10 sampler and value net, guidance_scale 2.0."""
+    import models.DxMI.trainer as ref_tr
+    T, B = 10, 2
+    net, sampler = build_sampler(T)
+    v = build_value()
+    trainer = ref_tr.DxMI_Trainer(batchsize=B, tau1=0.1, tau2=0.01, gamma=1, use_sampler_beta=True, n_timesteps=T)
+    trainer.set_models(f=None, v=v, sampler=sampler, optimizer=None, optimizer_fstar=None, optimizer_v=None)
+    g = torch.Generator().manual_seed(808)
+    x0 = torch.randn(B, 3, 32, 32, generator=g)
+    seed = 8080
+    torch.manual_seed(seed)
+    sampler.eval()
+    d = trainer.sample_guidance(B, "cpu", x0=x0, guidance_scale=2.0)
+    save("sample_guidance_T10", seed=seed, x0=x0, scale=2.0, sample=d["sample"].detach(), l_sample=torch.stack(d["l_sample"]),
+         guidance=torch.stack([t.detach() for t in d["guidance"]]), logp_on=torch.stack([t.detach() for t in d["logp_on"]]))
+
+
 EDM_TINY = dict(image_size=16, class_cond=True, learn_sigma=False, num_channels=64, num_res_blocks=1, channel_mult="1,2",
                 num_heads=4, num_head_channels=64, num_heads_upsample=-1, attention_resolutions="8", dropout=0.0,
                 use_checkpoint=False, use_scale_shift_norm=True, resblock_updown=True, use_fp16=False,
@@ -309,7 +327,7 @@ def gen_edm_trainer():
 
 
 GENS = {"schedule": gen_schedule, "unet": gen_unet_forward, "var_sampling": gen_var_sampling,
-        "sample_step": gen_sample_step, "value": gen_value, "trainer": gen_trainer_step, "edm": gen_edm, "edm_trainer": gen_edm_trainer}
+        "sample_step": gen_sample_step, "value": gen_value, "trainer": gen_trainer_step, "guidance": gen_guidance, "edm": gen_edm, "edm_trainer": gen_edm_trainer}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

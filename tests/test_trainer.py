@@ -160,3 +160,47 @@ def test_hip_trainer_step_vs_reference(golden_dir):
     assert agree > 0.9, agree
     lb = net.log_betas.detach().cpu().numpy()
     assert np.allclose(lb, g["log_betas_after"], atol=3e-5), (lb, g["log_betas_after"])
+
+
+def test_oracle_sample_guidance_matches_reference(golden_dir):
+    from oracle import schedule as osched
+    from oracle.trainer import OracleDxMI
+    torch.set_num_threads(8)
+    g = load(golden_dir, "sample_guidance_T10")
+    T, B = 10, 2
+    net, sampler, v = build_models()
+    s = osched.var_schedule(T)
+    sched = {k: torch.from_numpy(np.asarray(val, dtype=np.float32)) for k, val in s.items() if k != "user_defined_eta"}
+    o = OracleDxMI({k: t.detach() for k, t in net.state_dict().items()}, {k: t.detach() for k, t in v.state_dict().items()},
+                   sched, B, T, eta=s["user_defined_eta"])
+    torch.manual_seed(int(g["seed"]))
+    zs = [torch.randn(B, 3, 32, 32) for _ in range(T)]
+    d = o.sample_guidance(torch.from_numpy(g["x0"]), zs, float(g["scale"]))
+    np.testing.assert_allclose(torch.stack(d["l_sample"]).numpy(), g["l_sample"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(torch.stack(d["guidance"]).numpy(), g["guidance"], rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(torch.stack(d["logp_on"]).numpy(), g["logp_on"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_sample_guidance_vs_reference(golden_dir):
+    """Value-guided sampling on the HIP path (fused transitions + value-net input gradient) against the reference."""
+    from models.DxMI.trainer import DxMI_Trainer
+    DEV = "cuda:0"
+    g = load(golden_dir, "sample_guidance_T10")
+    T, B = 10, 2
+    net, sampler, v = build_models()
+    sampler, v = sampler.to(DEV), v.to(DEV)
+    trainer = DxMI_Trainer(batchsize=B, tau1=0.1, tau2=0.01, gamma=1, use_sampler_beta=True, n_timesteps=T)
+    trainer.set_models(f=None, v=v, sampler=sampler, optimizer=None, optimizer_fstar=None, optimizer_v=None)
+    torch.manual_seed(int(g["seed"]))
+    zs = [torch.randn(B, 3, 32, 32).to(DEV) for _ in range(T)]
+    sampler.eval()
+    with torch.no_grad():
+        d = trainer.sample_guidance(B, DEV, x0=torch.from_numpy(g["x0"]), guidance_scale=float(g["scale"]), noise=zs)
+    ls = torch.stack(d["l_sample"]).cpu().numpy()
+    assert ls.shape == g["l_sample"].shape
+    rel = np.linalg.norm(ls - g["l_sample"]) / np.linalg.norm(g["l_sample"])
+    gd = torch.stack(d["guidance"]).cpu().numpy()
+    relg = np.linalg.norm(gd - g["guidance"]) / np.linalg.norm(g["guidance"])
+    assert rel < 3e-2 and relg < 1e-1, (rel, relg)
+    assert torch.stack(d["logp_on"]).shape == (T, B) and d["logp_on_traj"].shape == (B,)
