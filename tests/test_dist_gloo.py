@@ -59,3 +59,46 @@ def test_single_process_is_noop():
     g = m.weight.grad.clone()
     FlatGradSync(m)()
     assert torch.equal(m.weight.grad, g)
+
+
+def _mp_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "diffusion-by-maxentirl_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dxmi_hip.dist import broadcast_parameters
+    from models.cm.fp16_util import MixedPrecisionTrainer
+    torch.manual_seed(7 + rank)
+    m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.SiLU(), torch.nn.Linear(5, 2))
+    m.register_parameter("log_betas", torch.nn.Parameter(torch.zeros(3)))
+    broadcast_parameters(m, src=0)
+    mp_tr = MixedPrecisionTrainer(model=m, use_fp16=True, initial_lg_loss_scale=8, special_key="log_betas")
+    opt = torch.optim.SGD(mp_tr.master_params, lr=0.5)
+    x = torch.full((3, 6), float(rank + 1))
+    mp_tr.zero_grad()
+    mp_tr.backward(m(x).sum() * (rank + 1) + m.log_betas.sum() * (rank + 1))
+    ok = mp_tr.optimize(opt)          # all-reduces the model gradients (mean over ranks) before the master step
+    q.put((rank, ok, [p.detach().tolist() for p in m.parameters()], mp_tr.lg_loss_scale))   # plain lists: no shared-memory handles
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mixed_precision_trainer_syncs_gradients_gloo():
+    """EDM sampler update on 2 ranks: identical parameters after one optimise() although the ranks saw different data."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, ok_a, pa, ls_a), (_, ok_b, pb, ls_b) = res
+    assert ok_a and ok_b and ls_a == ls_b
+    assert pa == pb
+    assert torch.allclose(torch.tensor(pa[0]), torch.full((3,), -0.5 * 1.5))      # log_betas (root parameter, listed first): mean gradient (1 + 2) / 2, lr 0.5
