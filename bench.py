@@ -38,6 +38,8 @@ UNET_KW = dict(ch=128, out_ch=3, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_re
 
 def kernel_name(kid):
     """dxmi_conv2d_kernel_id -> the template instantiation name rocprofv3 prints."""
+    if kid >= 300000:
+        return "conv_stem_kernel"
     if kid >= 200000:
         return f"conv1x1_ring_kernel<{(kid // 10) % 10}, {kid % 10}>"
     if kid >= 10000:

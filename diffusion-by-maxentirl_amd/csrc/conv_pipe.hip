@@ -481,6 +481,90 @@ int launch_ring(const ConvArgs& a, int grid, hipStream_t st) {
     return DXMI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Stem convolution (3 -> Cout, 3x3/s1/p1, NCHW fp32 image in, NHWC bf16 out): one k-chunk (27 taps padded to 32), so
+// the launch is all epilogue — 128-pixel tiles, im2col straight from the image (thread = pixel: coalesced per tap),
+// 8 MFMAs per wave, then the same LDS-transposed 256-byte-row stores as conv_pipe (the generic kernel's scattered
+// 8-byte stores made this layer 5x slower than its output write).
+__global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs p) {
+    constexpr int NB = 4, ROWB = 80;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cot = blockIdx.x % p.CT;
+    const int pt = blockIdx.x / p.CT;
+    const int TW = 1 << p.TWl, TH = 1 << p.THl;
+    const int txn = p.OW >> p.TWl, tyn = p.OH >> p.THl;
+    const int tx = pt % txn, ty = (pt / txn) % tyn;
+    const int n0 = (pt / (txn * tyn)) * p.SUBS, oy0 = ty << p.THl, ox0 = tx << p.TWl;
+    {
+        // thread = (pixel, half of the 32 k-values); k = ci*9 + ky*3 + kx
+        const float* xin = reinterpret_cast<const float*>(p.in0);
+        const int pix = tid & 127, half = tid >> 7;
+        const int x = pix & (TW - 1);
+        const int y = (pix >> p.TWl) & (TH - 1);
+        const int n = n0 + (pix >> (p.TWl + p.THl));
+        const int oy = oy0 + y, ox = ox0 + x;
+        bf16x8 v[2];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = half * 16 + j;
+            const int ci = k / 9, r = k - ci * 9, ky = r / 3, kx = r - ky * 3;
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            float f = 0.f;
+            if (k < 27 && n < p.N && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) f = xin[((n * 3 + ci) * p.IH + iy) * p.IW + ix];
+            v[j >> 3][j & 7] = (bf16)f;
+        }
+        *reinterpret_cast<bf16x8*>(smem + pix * ROWB + half * 32) = v[0];
+        *reinterpret_cast<bf16x8*>(smem + pix * ROWB + half * 32 + 16) = v[1];
+    }
+    const int cb0 = cot * 4 + wave;
+    const int cbw = cb0 < p.CB ? cb0 : p.CB - 1;
+    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(p.w) + (size_t)cbw * 64 + lane;
+    bf16x8 A[2];
+    A[0] = wfrag[0];
+    A[1] = wfrag[(size_t)p.CB * 64];
+    f32x16 acc[1][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
+    lds_barrier();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + (nb * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16 + ks * 32);
+            acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks], b, acc[0][nb], 0, 0, 0);
+        }
+    conv_epilogue_lds<NB>(p, acc, smem + 128 * ROWB, n0, oy0, ox0, cot, wave, lane, tid);
+}
+
+int ilog2p(int v);
+
+int conv_stem_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
+    const int tile = 128;
+    const int TW = a.OW < 32 ? a.OW : 32;
+    int TH = tile / TW;
+    if (TH > a.OH) TH = a.OH;
+    const int SUBS = tile / (TW * TH);
+    if (TW * TH * SUBS != tile) return 1;
+    if (kernel_id) {
+        *kernel_id = 300000;
+        return DXMI_OK;
+    }
+    ConvArgs b = a;
+    b.TWl = ilog2p(TW); b.THl = ilog2p(TH); b.SUBS = SUBS;
+    const int ngroups = (a.N + SUBS - 1) / SUBS;
+    b.PT = ngroups * (a.OH / TH) * (a.OW / TW);
+    b.CT = (a.Cout + 127) / 128;
+    b.tile_px = tile;
+    hipLaunchKernelGGL(conv_stem_kernel, dim3(b.PT * b.CT), dim3(256), (size_t)128 * 80 + EPI_BYTES, st, b);
+    DXMI_CHECK_LAUNCH("dxmi_conv2d_fwd(stem)");
+    return DXMI_OK;
+}
+
 template <int NB, int PMAX, int KS, int DBG = 0, int AQ = 1>
 int launch_pipe(const ConvArgs& a, int grid, hipStream_t st) {
     auto kern = conv_pipe_kernel<NB, PMAX, KS, DBG, AQ>;
@@ -503,6 +587,7 @@ int ilog2p(int v) {
 }  // namespace
 
 int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
+    if (a.in_mode == DXMI_IN_NCHW_F32_K27 && a.out_mode == DXMI_OUT_NHWC_BF16 && a.Cout % 64 == 0) return conv_stem_launch(a, st, kernel_id);
     if (a.in_mode != DXMI_IN_NHWC_BF16 || a.out_mode != DXMI_OUT_NHWC_BF16) return 1;
     if (a.Cout % 64 != 0 || (a.C0 + a.C1) % 64 != 0 || a.C0 % 32 != 0) return 1;  // even chunk count
     if (a.stride != 1 && !(a.stride == 2 && a.ups == 0 && a.ksize == 3)) return 1;   // stride 2: Downsample convs
