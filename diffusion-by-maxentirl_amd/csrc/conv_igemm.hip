@@ -400,12 +400,81 @@ extern "C" int dxmi_conv2d_kernel_id(const dxmi_conv_desc* d) {
     return rc == DXMI_OK ? id : rc;
 }
 
+// Small dense layers (timestep-embedding MLP, temb_proj / emb_layers: P = batch rows, K <= 2048): the conv kernel gives
+// such a GEMM 1-22 workgroups walking K chunk by chunk (~100 us, pure latency).  Here every wave owns one 32-row x 32-col
+// output tile, reads its weight fragments and its fp32 rows straight from global memory (no LDS, no barrier) with four
+// k16 steps of loads in flight, so the launch is P/32 x M/128 workgroups of independent MFMA chains.
+namespace {
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, const bf16* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int P, int K,
+                                                          int M, int CB, int pre_act, int post_act) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cb = blockIdx.y * 4 + wave;
+    if (cb >= CB) return;
+    const int row = blockIdx.x * 32 + (lane & 31);
+    const int h = lane >> 5;
+    const bool rvalid = row < P;
+    const float* xr = x + (size_t)(rvalid ? row : 0) * K + 8 * h;
+    const bf16x8* wf = reinterpret_cast<const bf16x8*>(w) + (size_t)cb * 64 + lane;
+    const size_t wstep = (size_t)CB * 64;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int ksteps = K / 16;
+    for (int k0 = 0; k0 < ksteps; k0 += 4) {
+        bf16x8 a[4];
+        f32x4 lo[4], hi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ks = k0 + u < ksteps ? k0 + u : ksteps - 1;
+            a[u] = wf[ks * wstep];
+            lo[u] = *reinterpret_cast<const f32x4*>(xr + ks * 16);
+            hi[u] = *reinterpret_cast<const f32x4*>(xr + ks * 16 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + u < ksteps) {
+                bf16x8 b;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    b[e] = (bf16)(rvalid ? dxmi_act(lo[u][e], pre_act) : 0.f);
+                    b[4 + e] = (bf16)(rvalid ? dxmi_act(hi[u][e], pre_act) : 0.f);
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b, acc, 0, 0, 0);
+            }
+        }
+    }
+    if (!rvalid) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int co = cb * 32 + 8 * g + 4 * h;
+        if (co + 3 < M) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = dxmi_act(acc[4 * g + e] + (bias ? bias[co + e] : 0.f), post_act);
+            *reinterpret_cast<f32x4*>(out + (size_t)row * M + co) = o;
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (co + e < M) out[(size_t)row * M + co + e] = dxmi_act(acc[4 * g + e] + (bias ? bias[co + e] : 0.f), post_act);
+        }
+    }
+}
+}  // namespace
+
 // Dense layer on the same MFMA path: out[P][M] = post(pre(x[P][K]) @ W[M][K]^T + b), fp32 rows
 // in/out, bf16 operands.  W packed by dxmi_pack_conv_weight(ksize=1).
 extern "C" int dxmi_linear_fwd(const float* x, const void* wpacked, const float* bias, float* out, int32_t P,
                                int32_t K, int32_t M, int32_t pre_act, int32_t post_act, void* stream) {
     DXMI_CHECK_ARG(x && wpacked && out, "dxmi_linear_fwd: null pointer");
     DXMI_CHECK_ARG(P > 0 && M > 0 && K > 0 && K % 32 == 0, "dxmi_linear_fwd: K (%d) must be a positive multiple of 32", K);
+    if (P <= 4096 && M % 4 == 0) {   // row counts of the embedding MLPs (batch); larger row counts keep the tiled conv path
+        const int CB = (M + 31) / 32;
+        hipLaunchKernelGGL(linear_small_kernel, dim3((P + 31) / 32, (CB + 3) / 4), dim3(256), 0, (hipStream_t)stream, x,
+                           (const bf16*)wpacked, bias, out, P, K, M, CB, pre_act, post_act);
+        DXMI_CHECK_LAUNCH("dxmi_linear_fwd(small)");
+        return DXMI_OK;
+    }
     ConvArgs a;
     a.in0 = (const bf16*)x; a.in1 = nullptr; a.w = (const bf16*)wpacked; a.bias = bias; a.addvec = nullptr;
     a.residual = nullptr; a.out = out; a.mask_src = nullptr; a.mask_slope = 0.f;
