@@ -20,7 +20,7 @@ import torch
 
 import cmd_utils as cmd  # noqa: F401  (kept for CLI parity: unknown --a.b overrides are parsed the same way)
 import dxmi_config
-from utils import mkdir_p, print0
+from utils import mkdir_p, print0, to_uint8_nhwc, write_png_batch
 
 
 def rescale(X):
@@ -29,9 +29,7 @@ def rescale(X):
 
 def save_png(img_chw, path):
     """uint8 PNG of a [3,H,W] tensor in [0,1] (torchvision.utils.save_image rounding: x*255+0.5)."""
-    from PIL import Image
-    arr = img_chw.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(torch.uint8).numpy()
-    Image.fromarray(arr).save(path)
+    write_png_batch(to_uint8_nhwc(img_chw[None]), [path], workers=1)
 
 
 def main():
@@ -103,6 +101,8 @@ def main():
 
     n_batches = int(args.n_generate / args.batchsize / world)
     i_img = 0
+    from concurrent.futures import ThreadPoolExecutor
+    png_pool, pending = ThreadPoolExecutor(max_workers=8), []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n_batches):
@@ -111,12 +111,14 @@ def main():
                 d_sample = trainer.sample_guidance(n_sample=args.batchsize, device=device, guidance_scale=args.guidance_scale)
             else:
                 d_sample = sampler.sample(args.batchsize, device=device)
-        # one device->host copy per batch, already quantisation-ready
-        sample = rescale(d_sample["sample"]).clamp(0, 1).cpu()
         if args.save_images:
-            for s in sample:
-                save_png(s, os.path.join(output_path, f"{local_rank}_{i_img}.png"))
-                i_img += 1
+            # quantise on the device, one device->host copy per batch, PNGs from a thread pool
+            u8 = to_uint8_nhwc(rescale(d_sample["sample"]).clamp(0, 1))
+            pending += write_png_batch(u8, [os.path.join(output_path, f"{local_rank}_{i_img + k}.png") for k in range(len(u8))], pool=png_pool)
+            i_img += len(u8)
+    for f in pending:
+        f.result()
+    png_pool.shutdown()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:

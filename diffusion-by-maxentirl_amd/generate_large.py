@@ -20,10 +20,9 @@ import numpy as np
 import torch
 
 import dxmi_config
-from generate_cifar10 import save_png
 from models.cm.script_util import create_model_and_diffusion
 from models.DxMI.openai_diffusion import OpenAIDiffusion
-from utils import mkdir_p, print0
+from utils import mkdir_p, print0, to_uint8_nhwc, write_png_batch
 
 
 def main():
@@ -83,6 +82,8 @@ def main():
 
     n_batches = int(args.n_sample / args.batchsize / world)
     l_sample, i_img = [], 0
+    from concurrent.futures import ThreadPoolExecutor
+    png_pool, pending = ThreadPoolExecutor(max_workers=8), []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n_batches):
@@ -92,12 +93,14 @@ def main():
             d_sample = sampler.sample(args.batchsize, device=device, i_class=None, enable_grad=False)
         sample = d_sample["sample"]
         if args.skip_fid:
-            sample = ((sample + 1) / 2).clamp(0, 1).cpu()
-            for s in sample:
-                save_png(s, os.path.join(output_path, f"{local_rank}_{i_img}.png"))
-                i_img += 1
+            u8 = to_uint8_nhwc(((sample + 1) / 2).clamp(0, 1))
+            pending += write_png_batch(u8, [os.path.join(output_path, f"{local_rank}_{i_img + k}.png") for k in range(len(u8))], pool=png_pool)
+            i_img += len(u8)
         else:
             l_sample.append(((sample + 1) * 127.5).clamp(0, 255).to(torch.uint8))
+    for f in pending:
+        f.result()
+    png_pool.shutdown()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print0(f"generated {n_batches * args.batchsize} images/rank x {world} ranks, "

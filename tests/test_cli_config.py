@@ -49,3 +49,21 @@ def test_fix_legacy_dict():
     out = fix_legacy_dict({"model": sd})
     assert list(out.keys()) == ["a.weight", "b.bias"]
     assert list(fix_legacy_dict({"state_dict": {"x": 1, "y": 2}}).keys()) == ["x", "y"]
+
+
+def test_png_writer_roundtrip(tmp_path):
+    """The thread-pool PNG writer produces standard 8-bit RGB PNGs with save_image's rounding."""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from utils import to_uint8_nhwc, write_png_batch
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(9, 3, 32, 32, generator=g)
+    u8 = to_uint8_nhwc(x)
+    ref = x.mul(255).add(0.5).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).numpy()
+    assert u8.shape == (9, 32, 32, 3) and np.array_equal(u8, ref)
+    paths = [str(tmp_path / f"0_{i}.png") for i in range(9)]
+    write_png_batch(u8, paths, workers=4)
+    for i, p in enumerate(paths):
+        im = Image.open(p)
+        assert im.mode == "RGB" and im.size == (32, 32) and np.array_equal(np.asarray(im), u8[i])
