@@ -3,11 +3,14 @@
 // Work split: a workgroup = 4 waves = 128 queries of one (image, head); each wave owns 32
 // queries.  Keys/values are streamed in blocks of 64 through LDS.
 //   S^T[key][query] = K . Q^T      A = K block (LDS, row = key, k = d), B = Q (registers)
-//   O^T[d][query]  += V^T . P^T    A = V^T block (LDS image transposed while staging),
+//   O^T[d][query]  += V^T . P^T    A = V^T tile, read from the ROW-MAJOR V image through transposing LDS
+//                                  loads (ds_read_b64_tr_b16; staging V is plain 16-byte writes),
 //                                  B = P^T taken straight from the S^T accumulators (the k
 //                                  order of an accumulator tile is permuted: element j of
 //                                  lane-half h is key 16s + 8(j>>2) + 4h + (j&3); the V^T
 //                                  fragment is read in the same order).
+// Wide heads (D >= 128) run one wave per SIMD, so block kb+1 of K/V is fetched into registers while
+// block kb is computed.
 // With the query on the lane (column of every accumulator), the running max / sum are
 // lane-local apart from one lane<->lane+32 exchange.
 //
@@ -16,6 +19,9 @@
 #include "common.h"
 
 namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#define LDS_S16X4(p) ((__attribute__((address_space(3))) s16x4*)(p))
 
 struct AttnArgs {
     const bf16* qkv;
@@ -31,12 +37,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     constexpr int DK = D / 16;           // k-steps over d
     constexpr int DB = D / 32;           // 32-row blocks of O^T
     constexpr int KPITCH = D * 2 + 16;   // bytes per key row of the K image
-    constexpr int VPITCH = KB * 2 + 8;   // bytes per d row of the V^T image
+    constexpr int VPITCH = D * 2 + 64;   // bytes per key row of the V image (row-major; PV reads it through transposing LDS loads)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* kimg = smem;
     char* vimg = smem + KB * KPITCH;
 
     const int tid = threadIdx.x, lane = tid & 63;
+    // tr-read lane roles (ds_read_b64_tr_b16): 16-lane group g -> d half (g&1), key half (g>>1); lane 4q+pp -> key row q, d 4pp..
+    const int trg = lane >> 4, trq = (lane & 15) >> 2, trp = lane & 3;
+    const int tr_doff = (16 * (trg & 1) + 4 * trp) * 2;
+    const int tr_krow = 4 * (trg >> 1) + trq;   // key order of a k-step follows the S^T accumulator layout: 8(j>>2) + 4h + (j&3)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qblocks = (p.T + 127) / 128;
     const int qb = blockIdx.x % qblocks;
@@ -70,25 +80,49 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     float m = -INFINITY, l = 0.f;
 
     const int nkb = (p.T + KB - 1) / KB;
-    for (int kb = 0; kb < nkb; ++kb) {
-        __syncthreads();
-        // ---- stage K block (row-major) and V block (transposed) into LDS, zero-filled past T
-        constexpr int PIECES = KB * (D / 8);  // 16-byte pieces per operand block
-        for (int i = tid; i < PIECES; i += 256) {
+    constexpr bool PF = D >= 128;
+    constexpr int PIECES = KB * (D / 8);   // 16-byte pieces per operand block
+    constexpr int NP = PIECES / 256;
+    bf16x8 kreg[NP], vreg[NP];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int i = tid + q * 256;
             const int key = i / (D / 8), pc = i % (D / 8);
             const int gk = kb * KB + key;
-            bf16x8 kv, vv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { kv[e] = (bf16)0.f; vv[e] = (bf16)0.f; }
+            for (int e = 0; e < 8; ++e) { kreg[q][e] = (bf16)0.f; vreg[q][e] = (bf16)0.f; }
             if (gk < p.T) {
-                kv = *reinterpret_cast<const bf16x8*>(base + (size_t)gk * C3 + kc + pc * 8);
-                vv = *reinterpret_cast<const bf16x8*>(base + (size_t)gk * C3 + vc + pc * 8);
+                kreg[q] = *reinterpret_cast<const bf16x8*>(base + (size_t)gk * C3 + kc + pc * 8);
+                vreg[q] = *reinterpret_cast<const bf16x8*>(base + (size_t)gk * C3 + vc + pc * 8);
             }
-            *reinterpret_cast<bf16x8*>(kimg + key * KPITCH + pc * 16) = kv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) *reinterpret_cast<bf16*>(vimg + (pc * 8 + e) * VPITCH + key * 2) = vv[e];
         }
-        __syncthreads();
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int i = tid + q * 256;
+            const int key = i / (D / 8), pc = i % (D / 8);
+            *reinterpret_cast<bf16x8*>(kimg + key * KPITCH + pc * 16) = kreg[q];
+            *reinterpret_cast<bf16x8*>(vimg + key * VPITCH + pc * 16) = vreg[q];
+        }
+    };
+    for (int kb = 0; kb < nkb; ++kb) {
+        // ---- K block (row-major) and V block (transposed) in LDS, zero-filled past T.  Wide heads (D >= 128: one
+        // wave per SIMD, nothing else hides latency) fetch block kb+1 into registers while block kb is computed.
+        if constexpr (PF) {
+            if (kb == 0) {
+                gload(0);
+                lstore();
+                __syncthreads();
+            }
+            if (kb + 1 < nkb) gload(kb + 1);
+        } else {
+            __syncthreads();
+            gload(kb);
+            lstore();
+            __syncthreads();
+        }
 
         // ---- S^T = K . Q^T for the 2 x 32 keys of this block
         f32x16 s[2];
@@ -141,13 +175,22 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
             for (int jj = 0; jj < 8; ++jj) pb[jj] = (bf16)s[kh][8 * sl + jj];
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
-                const char* row = vimg + (db * 32 + (lane & 31)) * VPITCH + (kh * 32 + 16 * sl + 4 * h) * 2;
-                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row);
-                const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + 16);
+                // A = V^T tile [32 d][16 keys]: lane holds d = db*32 + (lane&31), keys 8h..8h+7 of this k-step
+                const char* row = vimg + (kh * 32 + 16 * sl + tr_krow) * VPITCH + db * 64 + tr_doff;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(row));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(row + 8 * VPITCH));
                 bf16x8 a;
+                short* as = reinterpret_cast<short*>(&a);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { a[e] = lo[e]; a[4 + e] = hi[e]; }
+                for (int e = 0; e < 4; ++e) { as[e] = lo[e]; as[4 + e] = hi[e]; }
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[db], 0, 0, 0);
+            }
+        }
+        if constexpr (PF) {
+            if (kb + 1 < nkb) {
+                __syncthreads();   // every wave is done with block kb's LDS images
+                lstore();
+                __syncthreads();
             }
         }
     }
@@ -171,7 +214,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
 template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t st) {
     auto kern = attention_kernel<D>;
-    const size_t lds = 64 * (D * 2 + 16) + D * (64 * 2 + 8);
+    const size_t lds = 64 * (D * 2 + 16) + 64 * (D * 2 + 64);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
