@@ -25,7 +25,8 @@ def _worker(rank, world, port, q):
     m(x).sum().backward()
     local = [p.grad.clone() for p in m.parameters()]
     FlatGradSync(m)()
-    q.put((rank, w0, m.buf.clone(), local, [p.grad.clone() for p in m.parameters()]))
+    # numpy copies travel by value; tensors would travel as shared-memory handles that die with this process
+    q.put((rank, w0.numpy(), m.buf.clone().numpy(), [g.numpy() for g in local], [p.grad.clone().numpy() for p in m.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -44,6 +45,8 @@ def test_flat_grad_allreduce_and_broadcast_gloo():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    res = [(r, torch.from_numpy(w), torch.from_numpy(b), [torch.from_numpy(x) for x in lo], [torch.from_numpy(x) for x in sy])
+           for r, w, b, lo, sy in res]
     (_, w_a, buf_a, loc_a, syn_a), (_, w_b, buf_b, loc_b, syn_b) = res
     assert torch.equal(w_a, w_b) and torch.equal(buf_a, buf_b) and float(buf_b[0]) == 0.0   # broadcast from rank 0
     for la, lb, sa, sb in zip(loc_a, loc_b, syn_a, syn_b):
