@@ -39,18 +39,26 @@ class FlatGradSync:
         ps = [p for p in self.params if p.grad is not None]
         if not ps:
             return
-        n = sum(p.grad.numel() for p in ps)
-        if self.flat is None or self.flat.numel() != n or self.flat.device != ps[0].grad.device:
-            self.flat = torch.empty(n, dtype=torch.float32, device=ps[0].grad.device)
+        grads = [p.grad for p in ps]
+        if all(g.dtype == torch.float32 for g in grads):
+            # one gather kernel, one collective, one multi-tensor scatter (instead of 2 x len(ps) small copies)
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.div_(dist.get_world_size())
+            torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+            return
+        n = sum(g.numel() for g in grads)
+        if self.flat is None or self.flat.numel() != n or self.flat.device != grads[0].device:
+            self.flat = torch.empty(n, dtype=torch.float32, device=grads[0].device)
         off = 0
-        for p in ps:
-            k = p.grad.numel()
-            self.flat[off:off + k].copy_(p.grad.reshape(-1))
+        for g in grads:
+            k = g.numel()
+            self.flat[off:off + k].copy_(g.reshape(-1))
             off += k
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.div_(dist.get_world_size())
         off = 0
-        for p in ps:
-            k = p.grad.numel()
-            p.grad.copy_(self.flat[off:off + k].view_as(p.grad))
+        for g in grads:
+            k = g.numel()
+            g.copy_(self.flat[off:off + k].view_as(g))
             off += k
