@@ -598,7 +598,8 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     while (NB > 2 && (px / (32 * NB)) * CT < 512) NB >>= 1;   // two workgroups per CU
     // 128-pixel tiles (2 workgroups / CU: one's tile switch hides under the other's MFMAs) measured
     // faster than 256-pixel tiles at 1 workgroup / CU: default cap 4.
-    static const int nb_cap = getenv("DXMI_CONV_NB") ? atoi(getenv("DXMI_CONV_NB")) : 4;  // tuning override
+    static const int nb_env = getenv("DXMI_CONV_NB") ? atoi(getenv("DXMI_CONV_NB")) : 4;  // tuning override (2 or 4)
+    const int nb_cap = nb_env >= 4 ? 4 : 2;
     while (NB > nb_cap && NB > 2) NB >>= 1;
     if (a.stride == 2) NB = 2;   // the stride-2 halo of a 64-pixel tile is 17x17 pixels (23 KB)
     const int tile = 32 * NB;
@@ -630,8 +631,8 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     b.lds_buf = SUBS * b.SP;
     if (2 * b.lds_buf + EPI_BYTES > 160 * 1024) return 1;
     const int npieces = HP * 4;
-    const int pmax = npieces <= 6 * 256 ? 6 : (npieces <= 9 * 256 ? 9 : 0);
-    if (!pmax) return 1;
+    const int pmax = 6;                       // staging pieces per thread; larger halos go to the generic kernel
+    if (npieces > pmax * 256) return 1;
     static const int ring_env = getenv("DXMI_CONV_RING") ? atoi(getenv("DXMI_CONV_RING")) : 1;   // tuning override
     int ringU = 0;
     if (a.ksize == 1 && a.ups == 0 && ring_env && NB <= 4) {
@@ -654,29 +655,13 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     const int grid = nstreams * CT;
     static const int stagger = getenv("DXMI_CONV_STAGGER") ? atoi(getenv("DXMI_CONV_STAGGER")) : 2;   // measured: 0 -> 2 = -2 % conv time
     b.stagger = (grid > 256 && b.PT / nstreams >= 2) ? stagger : 0;
-    static const int dbg = getenv("DXMI_CONV_DBG") ? atoi(getenv("DXMI_CONV_DBG")) : 0;
-    if (dbg && a.ksize == 3 && pmax == 6 && NB == 4) {
-        switch (dbg) {
-            case 1: return launch_pipe<4, 6, 3, 1>(b, grid, st);
-            case 8: return launch_pipe<4, 6, 3, 8>(b, grid, st);
-            case 15: return launch_pipe<4, 6, 3, 15>(b, grid, st);
-            case 16: return launch_pipe<4, 6, 3, 16>(b, grid, st);
-            case 32: return launch_pipe<4, 6, 3, 32>(b, grid, st);
-            case 48: return launch_pipe<4, 6, 3, 48>(b, grid, st);
-        }
-    }
     if (ringU) {
         b.lds_buf = tile * 80;   // no halo: [tile_px][80 B]
         if (NB == 4) return ringU == 4 ? launch_ring<4, 4>(b, grid, st) : launch_ring<4, 6>(b, grid, st);
         return ringU == 4 ? launch_ring<2, 4>(b, grid, st) : launch_ring<2, 6>(b, grid, st);
     }
-    static const int aq_env = getenv("DXMI_CONV_AQ") ? atoi(getenv("DXMI_CONV_AQ")) : -1;   // tuning override
     // queue depth by shape: 3x3 at NB=2 (4x4 / 8x8 maps, latency bound) 8 ahead, 3x3 at NB=4 4 ahead (register
     // budget of two workgroups per CU), 1x1 (short K loops, measured no gain) 1 ahead
-#define DXMI_PIPE(NB_, PM_) (a.ksize == 3 ? (aq_env == 1 ? launch_pipe<NB_, PM_, 3>(b, grid, st) : launch_pipe<NB_, PM_, 3, 0, (NB_ == 2 ? 8 : (NB_ == 4 ? 4 : 1))>(b, grid, st)) \
-                                          : launch_pipe<NB_, PM_, 1>(b, grid, st))
-    if (NB == 8) return pmax == 6 ? DXMI_PIPE(8, 6) : DXMI_PIPE(8, 9);
-    if (NB == 4) return pmax == 6 ? DXMI_PIPE(4, 6) : DXMI_PIPE(4, 9);
-    return pmax == 6 ? DXMI_PIPE(2, 6) : DXMI_PIPE(2, 9);
-#undef DXMI_PIPE
+    if (a.ksize == 3) return NB == 4 ? launch_pipe<4, 6, 3, 0, 4>(b, grid, st) : launch_pipe<2, 6, 3, 0, 8>(b, grid, st);
+    return NB == 4 ? launch_pipe<4, 6, 1>(b, grid, st) : launch_pipe<2, 6, 1>(b, grid, st);
 }
