@@ -37,11 +37,38 @@ template <int NB>
 __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&acc)[1][NB], char* eb, int n0, int oy0,
                                                   int ox0, int cot, int wave, int lane, int tid) {
     constexpr int EPB = 2;  // 32-pixel blocks per pass (64 pixels)
+    constexpr int NP = NB / EPB;
     const int TW = 1 << p.TWl, TH = 1 << p.THl;
     const int h = lane >> 5;
     const int co_l = wave * 32 + 4 * h;  // + 8g
+    const int pc = tid & 15;
+    const bool pc_ok = cot * 128 + pc * 8 < p.Cout;
+    // output offset of this thread's k-th 16-byte piece of a pass (-1: outside the batch / cout range)
+    auto out_off = [&](int pass, int k) -> long {
+        const int lp = (tid >> 4) + 16 * k;
+        const int pix = pass * 64 + lp;
+        const int x = pix & (TW - 1);
+        const int y = (pix >> p.TWl) & (TH - 1);
+        const int n = n0 + (pix >> (p.TWl + p.THl));
+        return (n < p.N && pc_ok) ? (long)((((size_t)n * p.OH + oy0 + y) * p.OW + ox0 + x) * p.Cout + cot * 128 + pc * 8) : -1;
+    };
+    // the residual of a pass is requested one phase early (before the slab is written / during the previous pass's
+    // stores), so its latency overlaps the LDS transpose instead of following it
+    bf16x8 rv[4];
+    auto res_load = [&](int pass) {
+        if (p.residual) {
 #pragma unroll
-    for (int pass = 0; pass < NB / EPB; ++pass) {
+            for (int k = 0; k < 4; ++k) {
+                const long o = out_off(pass, k);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rv[k][e] = (bf16)0.f;
+                if (o >= 0) rv[k] = *reinterpret_cast<const bf16x8*>(p.residual + o);
+            }
+        }
+    };
+    res_load(0);
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
 #pragma unroll
         for (int e2 = 0; e2 < EPB; ++e2) {
             const int nb = pass * EPB + e2;
@@ -67,25 +94,19 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&ac
             }
         }
         lds_barrier();
-        const int pc = tid & 15;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int lp = (tid >> 4) + 16 * k;
-            const int pix = pass * 64 + lp;
-            const int x = pix & (TW - 1);
-            const int y = (pix >> p.TWl) & (TH - 1);
-            const int n = n0 + (pix >> (p.TWl + p.THl));
-            if (n < p.N && cot * 128 + pc * 8 < p.Cout) {
-                const size_t o = (((size_t)n * p.OH + oy0 + y) * p.OW + ox0 + x) * p.Cout + cot * 128 + pc * 8;
+            const long o = out_off(pass, k);
+            if (o >= 0) {
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(eb + lp * EPI_PITCH + pc * 32);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(eb + lp * EPI_PITCH + pc * 32 + 16);
                 float v[8];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
                 if (p.residual) {
-                    const bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.residual + o);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[k][e];
                 }
                 if (p.mask_src) {
                     const bf16x8 mv = *reinterpret_cast<const bf16x8*>(p.mask_src + o);
@@ -98,6 +119,7 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&ac
                 *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + o) = ov;
             }
         }
+        if (pass + 1 < NP) res_load(pass + 1);
         lds_barrier();
     }
 }
