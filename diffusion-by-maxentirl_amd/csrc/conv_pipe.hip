@@ -343,167 +343,6 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// 1x1 convolutions (q|k|v, proj_out, nin_shortcut / skip_connection): a step is one 32-channel chunk = 2*NB MFMAs
-// (~0.1 us), far shorter than a memory round trip, so the generic kernel's "load the next chunk during this one"
-// leaves every chunk waiting a full latency (measured 96 us for 256->768 @16x16, B=256; HBM time 33 us).
-// Here U-1 chunks are kept in flight in a static ring of register slots (U = 4 or 6 unrolled steps, Cin % (32 U) == 0),
-// across tile boundaries, and the weight fragments ride the same ring.
-template <int NB, int U>
-__global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv1x1_ring_kernel(ConvArgs p) {
-    constexpr int CK = 32, ROWB = CK * 2 + 16, PPP = CK / 8;
-    constexpr int PM = NB / 2 > 0 ? NB / 2 : 1;   // 16-byte pieces per thread per chunk (tile_px * 4 / 256)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nstreams = gridDim.x / p.CT;
-    int cot, pt;
-    if ((nstreams & 7) == 0) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        cot = j % p.CT;
-        pt = (j / p.CT) * 8 + xcd;
-    } else {
-        cot = blockIdx.x % p.CT;
-        pt = blockIdx.x / p.CT;
-    }
-    if (pt >= p.PT) return;
-
-    const int TW = 1 << p.TWl, TH = 1 << p.THl;
-    const int txn = p.OW >> p.TWl, tyn = p.OH >> p.THl;
-    const int nchunks = (p.C0 + p.C1) / CK;   // multiple of U (host-checked)
-    const int BUF = p.lds_buf;
-
-    int hoff[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) hoff[nb] = (nb * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16;
-
-    // this thread's pieces: pixel index inside the tile (a 1x1 tile has no halo: LDS image = [tile_px][80 B])
-    const int pcol = tid % PPP;
-    auto tile_srcpix = [&](int t, int (&sp)[PM]) {
-        const int tx = t % txn;
-        const int ty = (t / txn) % tyn;
-        const int n0 = (t / (txn * tyn)) * p.SUBS;
-#pragma unroll
-        for (int q = 0; q < PM; ++q) {
-            const int pix = (tid + q * 256) / PPP;
-            const int x = pix & (TW - 1);
-            const int y = (pix >> p.TWl) & (TH - 1);
-            const int n = n0 + (pix >> (p.TWl + p.THl));
-            sp[q] = (n < p.N && pix < 32 * NB) ? (n * p.IH + (ty << p.THl) + y) * p.IW + (tx << p.TWl) + x : -1;
-        }
-    };
-    auto stage_load = [&](int c, const int (&sp)[PM], bf16x8 (&dst)[PM]) {
-        const int cbase = c * CK;
-        const bool first = cbase < p.C0;
-        const bf16* src = first ? p.in0 : p.in1;
-        const int Cs = first ? p.C0 : p.C1;
-        const int coff = (first ? cbase : cbase - p.C0) + pcol * 8;
-#pragma unroll
-        for (int q = 0; q < PM; ++q) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dst[q][e] = (bf16)0.f;
-            if (sp[q] >= 0) dst[q] = *reinterpret_cast<const bf16x8*>(src + (size_t)sp[q] * Cs + coff);
-        }
-    };
-    auto stage_store = [&](int buf, const bf16x8 (&src)[PM]) {
-#pragma unroll
-        for (int q = 0; q < PM; ++q) {
-            const int pix = (tid + q * 256) / PPP;
-            if (pix < 32 * NB) *reinterpret_cast<bf16x8*>(smem + buf + pix * ROWB + pcol * 16) = src[q];
-        }
-    };
-
-    f32x16 acc[1][NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
-
-    const int cb0 = cot * 4 + wave;
-    const int cbw = cb0 < p.CB ? cb0 : p.CB - 1;
-    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(p.w) + (size_t)cbw * 64 + lane;
-    const int wstep = p.CB * 64;
-    auto load_a = [&](int c, bf16x8 (&dst)[2]) {
-        const bf16x8* w0 = wfrag + (size_t)(c * 2) * wstep;
-        dst[0] = w0[0];
-        dst[1] = w0[wstep];
-    };
-
-    bf16x8 stg[U][PM], Aq[U][2], B[2][2][NB];
-    int srcA[PM];
-
-    // ---- prologue: chunks 0..U-1 of the first tile requested, chunk 0 written to image 0
-    tile_srcpix(pt, srcA);
-#pragma unroll
-    for (int j = 0; j < U; ++j) stage_load(j, srcA, stg[j]);
-#pragma unroll
-    for (int j = 0; j < U; ++j) load_a(j, Aq[j]);
-    stage_store(0, stg[0]);
-    lds_barrier();
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) B[0][ks][nb] = *reinterpret_cast<const bf16x8*>(smem + hoff[nb] + ks * 32);
-
-    for (;;) {
-        const int pt_next = pt + nstreams;
-        const bool more_tiles = pt_next < p.PT;
-        for (int c = 0; c < nchunks; c += U) {
-            const bool last_iter = c + U >= nchunks;
-            // chunks requested during this iteration: c+U+j of this tile, or (last iteration) chunk j of the next tile
-            if (last_iter) tile_srcpix(more_tiles ? pt_next : pt, srcA);   // uniform branch, no memory operations
-            const int cl = last_iter ? 0 : c + U;
-#pragma unroll
-            for (int j = 0; j < U; ++j) {
-                const int set = j & 1;
-                // chunk c+j+1 (slot (j+1)%U; requested U-1 steps ago) -> the other LDS image
-                stage_store(set ? 0 : BUF, stg[(j + 1) % U]);
-                lds_barrier();
-                // slot j is free (its chunk was written one step ago): request the chunk U steps ahead
-                stage_load(cl + j, srcA, stg[j]);
-                if (j > 0) load_a(cl + j - 1, Aq[j - 1]);   // weights of step c+U+j-1: slot of the step just issued
-                const char* nbase = smem + (set ? 0 : BUF);
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        B[set ^ 1][ks][nb] = *reinterpret_cast<const bf16x8*>(nbase + hoff[nb] + ks * 32);
-                        acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Aq[j][ks], B[set][ks][nb], acc[0][nb], 0, 0, 0);
-                    }
-                if (j == U - 1) load_a(cl + U - 1, Aq[U - 1]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        {
-            const int tx = pt % txn;
-            const int ty = (pt / txn) % tyn;
-            const int n0 = (pt / (txn * tyn)) * p.SUBS;
-            conv_epilogue_lds<NB>(p, acc, smem + 2 * BUF, n0, ty << p.THl, tx << p.TWl, cot, wave, lane, tid);
-        }
-        if (!more_tiles) break;
-        pt = pt_next;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
-    }
-}
-
-template <int NB, int U>
-int launch_ring(const ConvArgs& a, int grid, hipStream_t st) {
-    auto kern = conv1x1_ring_kernel<NB, U>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), (size_t)2 * a.lds_buf + EPI_BYTES, st, a);
-    DXMI_CHECK_LAUNCH("dxmi_conv2d_fwd(1x1 ring)");
-    return DXMI_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Stem convolution (3 -> Cout, 3x3/s1/p1, NCHW fp32 image in, NHWC bf16 out): one k-chunk (27 taps padded to 32), so
 // the launch is all epilogue — 128-pixel tiles, im2col straight from the image (thread = pixel: coalesced per tap),
 // 8 MFMAs per wave, then the same LDS-transposed 256-byte-row stores as conv_pipe (the generic kernel's scattered
@@ -561,6 +400,138 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs p) {
             acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks], b, acc[0][nb], 0, 0, 0);
         }
     conv_epilogue_lds<NB>(p, acc, smem + 128 * ROWB, n0, oy0, ox0, cot, wave, lane, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 1x1 convolution (q|k|v, proj_out, nin_shortcut / skip_connection), streaming form: these layers are short dot products
+// (K = 128..1344) over large maps - memory-bound.  One workgroup = one (64-pixel tile, 128-cout tile); RC chunks of the
+// K extent (input pieces AND weight fragments) are requested at once, so a round is one memory round trip, two
+// barriers and 2*RC k-steps of MFMAs; the next round's input flies during the MFMAs.  No persistence, no ring: with
+// 108 registers and 33 KB of LDS FOUR workgroups share a CU and the hardware scheduler overlaps one tile's loads with
+// another's MFMAs and stores (measured against the persistent register-ring variant it replaces: q|k|v 256->768 @16x16
+// 86 -> 60 us, proj_out 39 -> 30 us; fewer, larger tiles were slower at every occupancy).  The epilogue slab reuses the
+// input image.
+template <int NB, int RC, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv1x1_stream_kernel(ConvArgs p) {
+    constexpr int CK = 32, ROWB = CK * 2 + 16, PPP = CK / 8;
+    constexpr int PM = NB / 2;           // pieces per thread per 32-channel chunk (tile_px * 4 / 256)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware: the CT cout tiles of one pixel tile sit on one XCD, adjacent in dispatch order
+    const int nstreams = gridDim.x / p.CT;
+    int cot, pt;
+    if ((nstreams & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        cot = j % p.CT;
+        pt = (j / p.CT) * 8 + xcd;
+    } else {
+        cot = blockIdx.x % p.CT;
+        pt = blockIdx.x / p.CT;
+    }
+    const int TW = 1 << p.TWl, TH = 1 << p.THl;
+    const int txn = p.OW >> p.TWl, tyn = p.OH >> p.THl;
+    const int tx = pt % txn, ty = (pt / txn) % tyn;
+    const int n0 = (pt / (txn * tyn)) * p.SUBS, oy0 = ty << p.THl, ox0 = tx << p.TWl;
+    const int nchunks = (p.C0 + p.C1) / CK;
+    const int IMG = 32 * NB * ROWB;      // bytes of one chunk image
+
+    int hoff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) hoff[nb] = (nb * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+    const int pcol = tid % PPP;
+    int sp[PM];
+#pragma unroll
+    for (int q = 0; q < PM; ++q) {
+        const int pix = (tid + q * 256) / PPP;
+        const int x = pix & (TW - 1);
+        const int y = (pix >> p.TWl) & (TH - 1);
+        const int n = n0 + (pix >> (p.TWl + p.THl));
+        sp[q] = n < p.N ? (n * p.IH + oy0 + y) * p.IW + ox0 + x : -1;
+    }
+    const int cb0 = cot * 4 + wave;
+    const int cbw = cb0 < p.CB ? cb0 : p.CB - 1;
+    const bf16x8* wfrag = reinterpret_cast<const bf16x8*>(p.w) + (size_t)cbw * 64 + lane;
+    const size_t wstep = (size_t)p.CB * 64;
+
+    f32x16 acc[1][NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][nb][r] = 0.f;
+
+    bf16x8 stg[RC][PM], A[RC][2];
+    auto request_in = [&](int c0) {      // input pieces of chunks c0 .. c0+RC-1 (clamped)
+#pragma unroll
+        for (int j = 0; j < RC; ++j) {
+            const int c = c0 + j < nchunks ? c0 + j : nchunks - 1;
+            const int cbase = c * CK;
+            const bool first = cbase < p.C0;
+            const bf16* src = first ? p.in0 : p.in1;
+            const int Cs = first ? p.C0 : p.C1;
+            const int coff = (first ? cbase : cbase - p.C0) + pcol * 8;
+#pragma unroll
+            for (int q = 0; q < PM; ++q) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) stg[j][q][e] = (bf16)0.f;
+                if (sp[q] >= 0) stg[j][q] = *reinterpret_cast<const bf16x8*>(src + (size_t)sp[q] * Cs + coff);
+            }
+        }
+    };
+    auto request_w = [&](int c0) {       // weight fragments of the same chunks
+#pragma unroll
+        for (int j = 0; j < RC; ++j) {
+            const int c = c0 + j < nchunks ? c0 + j : nchunks - 1;
+            A[j][0] = wfrag[(size_t)(c * 2) * wstep];
+            A[j][1] = wfrag[(size_t)(c * 2 + 1) * wstep];
+        }
+    };
+    request_in(0);
+    request_w(0);
+    for (int c0 = 0; c0 < nchunks; c0 += RC) {
+        if (c0) lds_barrier();           // every wave is done reading the previous round's images
+#pragma unroll
+        for (int j = 0; j < RC; ++j)
+#pragma unroll
+            for (int q = 0; q < PM; ++q) {
+                const int pix = (tid + q * 256) / PPP;
+                *reinterpret_cast<bf16x8*>(smem + j * IMG + pix * ROWB + pcol * 16) = stg[j][q];
+            }
+        lds_barrier();
+        const int left = nchunks - c0;
+        if (left > RC) request_in(c0 + RC);   // next round's input flies during this round's MFMAs
+#pragma unroll
+        for (int j = 0; j < RC; ++j) {
+            if (j < left) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + j * IMG + hoff[nb] + ks * 32);
+                        acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[j][ks], b, acc[0][nb], 0, 0, 0);
+                    }
+            }
+        }
+        if (left > RC) request_w(c0 + RC);
+    }
+    lds_barrier();                        // images are dead: the epilogue slab reuses them
+    conv_epilogue_lds<NB>(p, acc, smem, n0, oy0, ox0, cot, wave, lane, tid);
+}
+
+template <int NB, int RC, int OCC>
+int launch_stream(const ConvArgs& a, int grid, hipStream_t st) {
+    auto kern = conv1x1_stream_kernel<NB, RC, OCC>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    size_t lds = (size_t)RC * 32 * NB * 80;
+    if (lds < (size_t)EPI_BYTES) lds = EPI_BYTES;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+    DXMI_CHECK_LAUNCH("dxmi_conv2d_fwd(1x1 stream)");
+    return DXMI_OK;
 }
 
 int ilog2p(int v);
@@ -624,6 +595,7 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     const int nb_cap = nb_env >= 4 ? 4 : 2;
     while (NB > nb_cap && NB > 2) NB >>= 1;
     if (a.stride == 2) NB = 2;   // the stride-2 halo of a 64-pixel tile is 17x17 pixels (23 KB)
+    if (a.ksize == 1 && a.ups == 0) NB = 2;   // 1x1: 64-pixel tiles, four workgroups per CU (conv1x1_stream_kernel)
     const int tile = 32 * NB;
     const int TW = a.OW < 32 ? a.OW : 32;
     int TH = tile / TW;
@@ -655,15 +627,10 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     const int npieces = HP * 4;
     const int pmax = 6;                       // staging pieces per thread; larger halos go to the generic kernel
     if (npieces > pmax * 256) return 1;
-    static const int ring_env = getenv("DXMI_CONV_RING") ? atoi(getenv("DXMI_CONV_RING")) : 1;   // tuning override
-    int ringU = 0;
-    if (a.ksize == 1 && a.ups == 0 && ring_env && NB <= 4) {
-        const int nch = (a.C0 + a.C1) / 32;
-        ringU = nch % 4 == 0 ? 4 : (nch % 6 == 0 ? 6 : 0);
-    }
+    const bool stream1x1 = a.ksize == 1 && a.ups == 0;
     if (kernel_id) {
-        // kxxyy = conv_pipe_kernel<xx, yy, k> ; 2000xu = conv1x1_ring_kernel<x, u>
-        *kernel_id = ringU ? 200000 + NB * 10 + ringU : 10000 * a.ksize + NB * 100 + pmax;
+        // kxxyy = conv_pipe_kernel<xx, yy, k> ; 200000 = conv1x1_stream_kernel<2, 4, 4>
+        *kernel_id = stream1x1 ? 200000 : 10000 * a.ksize + NB * 100 + pmax;
         return DXMI_OK;
     }
     // persistent grid: as many workgroups as are co-resident (2 per CU for NB <= 4, else 1), a
@@ -677,13 +644,9 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     const int grid = nstreams * CT;
     static const int stagger = getenv("DXMI_CONV_STAGGER") ? atoi(getenv("DXMI_CONV_STAGGER")) : 2;   // measured: 0 -> 2 = -2 % conv time
     b.stagger = (grid > 256 && b.PT / nstreams >= 2) ? stagger : 0;
-    if (ringU) {
-        b.lds_buf = tile * 80;   // no halo: [tile_px][80 B]
-        if (NB == 4) return ringU == 4 ? launch_ring<4, 4>(b, grid, st) : launch_ring<4, 6>(b, grid, st);
-        return ringU == 4 ? launch_ring<2, 4>(b, grid, st) : launch_ring<2, 6>(b, grid, st);
-    }
+    if (stream1x1) return launch_stream<2, 4, 4>(b, b.PT * CT, st);
     // queue depth by shape: 3x3 at NB=2 (4x4 / 8x8 maps, latency bound) 8 ahead, 3x3 at NB=4 4 ahead (register
     // budget of two workgroups per CU), 1x1 (short K loops, measured no gain) 1 ahead
     if (a.ksize == 3) return NB == 4 ? launch_pipe<4, 6, 3, 0, 4>(b, grid, st) : launch_pipe<2, 6, 3, 0, 8>(b, grid, st);
-    return NB == 4 ? launch_pipe<4, 6, 1>(b, grid, st) : launch_pipe<2, 6, 1>(b, grid, st);
+    return NB == 4 ? launch_pipe<4, 6, 1>(b, grid, st) : launch_pipe<2, 6, 1>(b, grid, st);   // 1x1 behind an upsample (unused by the nets)
 }
