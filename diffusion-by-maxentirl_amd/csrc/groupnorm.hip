@@ -199,13 +199,22 @@ __global__ __launch_bounds__(256) void gn_gen_stats_kernel(GnGenArgs p) {
         const bool from0 = c < p.C0;
         const bf16* src = from0 ? p.in0 + (size_t)n * p.HW * p.C0 + c : p.in1 + (size_t)n * p.HW * p.C1 + (c - p.C0);
         const int Cs = from0 ? p.C0 : p.C1;
-        for (int r = row0 + rl; r < row1; r += rows_par) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)r * Cs);
+        for (int r = row0 + rl; r < row1; r += 4 * rows_par) {
+            bf16x8 v[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float f = (float)v[e];
-                ls[e] += f; lq[e] += f * f;
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * rows_par;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[u][e] = (bf16)0.f;
+                if (rr < row1) v[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)rr * Cs);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[u][e];
+                    ls[e] += f; lq[e] += f * f;
+                }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -267,16 +276,28 @@ __global__ __launch_bounds__(256) void gn_gen_apply_kernel(GnGenArgs p) {
     bf16* dst = p.out + (size_t)n * p.HW * C + c;
     const int row0 = chunk * p.rows_per_chunk;
     const int row1 = min(row0 + p.rows_per_chunk, p.HW);
-    for (int r = row0 + rl; r < row1; r += rows_par) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)r * Cs);
-        bf16x8 o;
+    // four rows per trip: the loads are issued together so each thread keeps 64 bytes in flight
+    for (int r = row0 + rl; r < row1; r += 4 * rows_par) {
+        bf16x8 v[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float y = (float)v[e] * A[e] + Bv[e];
-            if (p.silu) y = y / (1.f + __expf(-y));
-            o[e] = (bf16)y;
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * rows_par;
+            if (rr < row1) v[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)rr * Cs);
         }
-        *reinterpret_cast<bf16x8*>(dst + (size_t)r * C) = o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * rows_par;
+            if (rr < row1) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float y = (float)v[u][e] * A[e] + Bv[e];
+                    if (p.silu) y = y / (1.f + __expf(-y));
+                    o[e] = (bf16)y;
+                }
+                *reinterpret_cast<bf16x8*>(dst + (size_t)rr * C) = o;
+            }
+        }
     }
 }
 
