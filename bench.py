@@ -45,7 +45,9 @@ def kernel_name(kid):
     if kid >= 10000:
         nb, ks = (kid // 100) % 100, kid // 10000
         aq = (8 if nb == 2 else (4 if nb == 4 else 1)) if ks == 3 else 1   # queue depth chosen in conv_pipe.hip
-        return f"conv_pipe_kernel<{nb}, {kid % 100}, {ks}, 0, {aq}>"
+        pmax = kid % 100
+        sd = 2 if (ks == 3 and pmax == 4) else 1   # staging distance chosen in conv_pipe.hip
+        return f"conv_pipe_kernel<{nb}, {pmax}, {ks}, 0, {aq}, {sd}>"
     return f"conv_igemm_kernel<{kid // 1000}, {(kid // 100) % 10}, 32, {kid % 100}>"
 
 

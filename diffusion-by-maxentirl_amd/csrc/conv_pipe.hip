@@ -126,7 +126,9 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&ac
 
 // AQ: how many steps ahead the weight fragments are requested (queue of AQ+1 fragment pairs).  Small-map layers are
 // bound by the L2 latency of those requests (4 MFMAs per step at NB=2), so they run a deeper queue.
-template <int NB, int PMAX, int KS, int DBG = 0, int AQ = 1>  // DBG: timing-only ablations (wrong results)
+// SD: chunks of staging distance (1: the next chunk is requested at this chunk's first tap; 2: the chunk after next,
+// through two register sets - the halo fetch then has 17 steps instead of 8 to come back from HBM)
+template <int NB, int PMAX, int KS, int DBG = 0, int AQ = 1, int SD = 1>  // DBG: timing-only ablations (wrong results)
 __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvArgs p) {
     constexpr int CK = 32, ROWB = CK * 2 + 16, PPP = CK / 8, TAPS = KS * KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -212,8 +214,8 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
         }
     };
 
-    bf16x8 stg[PMAX];
-    auto stage_load = [&](int c, const int (&sp)[PMAX]) {
+    bf16x8 stgs[SD][PMAX];
+    auto stage_load_set = [&](int c, const int (&sp)[PMAX], bf16x8 (&stg)[PMAX]) {
         const int cbase = c * CK;
         const bool first = cbase < p.C0;
         const bf16* src = first ? p.in0 : p.in1;
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
             if (sp[q] >= 0) stg[q] = *reinterpret_cast<const bf16x8*>(src + (size_t)sp[q] * Cs + coff);
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store_set = [&](int buf, const bf16x8 (&stg)[PMAX]) {
 #pragma unroll
         for (int q = 0; q < PMAX; ++q) {
             const int gq = geo[q];
@@ -234,6 +236,8 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
             if (gq >= 0) *reinterpret_cast<bf16x8*>(smem + buf + off) = stg[q];
         }
     };
+    auto stage_load = [&](int c, const int (&sp)[PMAX]) { stage_load_set(c, sp, stgs[0]); };
+    auto stage_store = [&](int buf) { stage_store_set(buf, stgs[0]); };
 
     f32x16 acc[1][NB];
 #pragma unroll
@@ -255,6 +259,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
     tile_srcpix(pt, srcA);
     stage_load(0, srcA);
     stage_store(0);
+    if constexpr (SD == 2) stage_load_set(1, srcA, stgs[1]);   // nchunks >= 2
     const int clast = nchunks - 1;
     // weight fragments of step f of the (chunk, tap) stream that starts at chunk c (wraps into the next tile)
     auto load_a = [&](int c, int f, bf16x8 (&dst)[2]) {
@@ -291,7 +296,16 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
                 int cc2 = c + u2 / TAPS;            // chunk of the successor step (wraps into the next tile)
                 cc2 = cc2 > clast ? 0 : cc2;
                 const int set = u & 1;
-                if (tap == 0 && !(DBG & 2)) {
+                if (SD == 2 && tap == 0) {
+                    // chunk (c + half + 2): of this tile, or - wrapped - of the next one (sources recomputed on the fly)
+                    int ct = c + half + 2;
+                    const bool wrap = ct > clast;
+                    ct = wrap ? ct - nchunks : ct;
+                    int srcT[PMAX];
+                    tile_srcpix(wrap ? (more_tiles ? pt_next : pt) : pt, srcT);
+                    stage_load_set(ct, srcT, stgs[half]);
+                }
+                if (SD == 1 && tap == 0 && !(DBG & 2)) {
                     if (half == 0) stage_load(c + 1, srcA);
                     else {
                         // the chunk after this pair: c+2 of this tile, or (last pair) chunk 0 of the next
@@ -307,7 +321,8 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
                 if (!(DBG & 1)) load_a(c, u + AQ, Aq[AQ]);
                 else { Aq[AQ][0] = Aq[0][0]; Aq[AQ][1] = Aq[0][1]; }
                 if (tap == TAPS - 1) {
-                    if (!(DBG & 2)) stage_store(half ? 0 : BUF);
+                    if (SD == 2) stage_store_set(half ? 0 : BUF, stgs[half ^ 1]);
+                    else if (!(DBG & 2)) stage_store(half ? 0 : BUF);
                     if (!(DBG & 4)) lds_barrier();
                 }
                 const char* nbase = smem + (half2 ? BUF : 0) + (tap2 / KS) * p.RP + (tap2 % KS) * ROWB;
@@ -558,9 +573,9 @@ int conv_stem_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     return DXMI_OK;
 }
 
-template <int NB, int PMAX, int KS, int DBG = 0, int AQ = 1>
+template <int NB, int PMAX, int KS, int DBG = 0, int AQ = 1, int SD = 1>
 int launch_pipe(const ConvArgs& a, int grid, hipStream_t st) {
-    auto kern = conv_pipe_kernel<NB, PMAX, KS, DBG, AQ>;
+    auto kern = conv_pipe_kernel<NB, PMAX, KS, DBG, AQ, SD>;
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -625,8 +640,9 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     b.lds_buf = SUBS * b.SP;
     if (2 * b.lds_buf + EPI_BYTES > 160 * 1024) return 1;
     const int npieces = HP * 4;
-    const int pmax = 6;                       // staging pieces per thread; larger halos go to the generic kernel
-    if (npieces > pmax * 256) return 1;
+    if (npieces > 6 * 256) return 1;          // larger halos go to the generic kernel
+    // staging pieces per thread: the small counts get the two-set (SD = 2) kernels
+    const int pmax = (a.ksize == 3 && NB == 4 && npieces <= 4 * 256) ? 4 : 6;
     const bool stream1x1 = a.ksize == 1 && a.ups == 0;
     if (kernel_id) {
         // kxxyy = conv_pipe_kernel<xx, yy, k> ; 200000 = conv1x1_stream_kernel<2, 4, 4>
@@ -647,6 +663,11 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     if (stream1x1) return launch_stream<2, 4, 4>(b, b.PT * CT, st);
     // queue depth by shape: 3x3 at NB=2 (4x4 / 8x8 maps, latency bound) 8 ahead, 3x3 at NB=4 4 ahead (register
     // budget of two workgroups per CU), 1x1 (short K loops, measured no gain) 1 ahead
-    if (a.ksize == 3) return NB == 4 ? launch_pipe<4, 6, 3, 0, 4>(b, grid, st) : launch_pipe<2, 6, 3, 0, 8>(b, grid, st);
+    // staging distance: with few enough halo pieces per thread two register sets fit, and the halo of the chunk AFTER
+    // next is requested (17 steps of cover instead of 8): -5..10 % on the K <= 2304 layers
+    if (a.ksize == 3) {
+        if (NB == 4) return pmax == 4 ? launch_pipe<4, 4, 3, 0, 4, 2>(b, grid, st) : launch_pipe<4, 6, 3, 0, 4>(b, grid, st);
+        return launch_pipe<2, 6, 3, 0, 8>(b, grid, st);   // 64-pixel tiles: the second register set measured no gain
+    }
     return NB == 4 ? launch_pipe<4, 6, 1>(b, grid, st) : launch_pipe<2, 6, 1>(b, grid, st);   // 1x1 behind an upsample (unused by the nets)
 }
