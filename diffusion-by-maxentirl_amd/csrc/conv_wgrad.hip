@@ -18,6 +18,7 @@
 // Replaces autograd's conv weight gradient for models/modules.py:71-101,142-145 and
 // models/DxMI/unet_small.py convs (reference: torch.nn.Conv2d backward).
 #include "conv_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -49,7 +50,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* row_lo, const char* row_hi
     return r;
 }
 
-template <int KS>
+// PF: the next pixel tile's dY and X pieces are fetched into registers while this tile's MFMAs run (needs <= 8 halo
+// pieces per thread, i.e. stride-1 tiles); otherwise tiles are staged synchronously.
+template <int KS, bool PF>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     constexpr int TAPS = KS * KS;
     constexpr int TP = 128;  // pixels per tile
@@ -87,11 +90,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    constexpr int DYP = TP * 8 / 256, XP = 8;
+    bf16x8 dyr[PF ? DYP : 1], xr[PF ? XP : 1];
+    const int nxp = p.SUBS * HHW * 8;   // 16-byte pieces of the X halo tile
+    auto fetch = [&](int pt) {
+        const int tx = pt % txn, ty = (pt / txn) % tyn;
+        const int n0 = (pt / (txn * tyn)) * p.SUBS;
+        const int oy0 = ty << p.THl, ox0 = tx << p.TWl;
+#pragma unroll
+        for (int q = 0; q < DYP; ++q) {
+            const int i = tid + q * 256;
+            const int pix = i >> 3, pc = i & 7;
+            const int x = pix & (TW - 1), y = (pix >> p.TWl) & (TH - 1), n = n0 + (pix >> (p.TWl + p.THl));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dyr[q][e] = (bf16)0.f;
+            if (n < p.N) dyr[q] = *reinterpret_cast<const bf16x8*>(p.dy + (((size_t)n * p.OH + oy0 + y) * p.OW + ox0 + x) * p.Cout + co0 + pc * 8);
+        }
+#pragma unroll
+        for (int q = 0; q < XP; ++q) {
+            const int i = tid + q * 256;
+            const int hp = i >> 3, pc = i & 7;
+            const int sub = hp / HHW, rem = hp - sub * HHW;
+            const int hy = rem / p.HWd, hx = rem - hy * p.HWd;
+            const int iy = oy0 * p.stride - p.pad + hy, ix = ox0 * p.stride - p.pad + hx, n = n0 + sub;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xr[q][e] = (bf16)0.f;
+            if (i < nxp && n < p.N && iy >= 0 && ix >= 0 && iy < (p.IH << p.ups) && ix < (p.IW << p.ups))
+                xr[q] = *reinterpret_cast<const bf16x8*>(xsrc + (((size_t)n * p.IH + (iy >> p.ups)) * p.IW + (ix >> p.ups)) * Cs + cis + pc * 8);
+        }
+    };
+    if constexpr (PF) fetch(split);
+
     for (int pt = split; pt < p.PT; pt += p.S) {
         const int tx = pt % txn, ty = (pt / txn) % tyn;
         const int n0 = (pt / (txn * tyn)) * p.SUBS;
         const int oy0 = ty << p.THl, ox0 = tx << p.TWl;
         __syncthreads();
+        if constexpr (PF) {
+#pragma unroll
+            for (int q = 0; q < DYP; ++q) {
+                const int i = tid + q * 256;
+                *reinterpret_cast<bf16x8*>(ydy + (i >> 3) * WG_PITCH + (i & 7) * 16) = dyr[q];
+            }
+#pragma unroll
+            for (int q = 0; q < XP; ++q) {
+                const int i = tid + q * 256;
+                if (i < nxp) *reinterpret_cast<bf16x8*>(xim + (i >> 3) * WG_PITCH + (i & 7) * 16) = xr[q];
+            }
+            __syncthreads();
+            if (pt + p.S < p.PT) fetch(pt + p.S);
+        } else {
         // ---- stage dY tile: 128 px x 64 co = 8 pieces / px
         for (int i = tid; i < TP * 8; i += 256) {
             const int pix = i >> 3, pc = i & 7;
@@ -116,6 +164,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             *reinterpret_cast<bf16x8*>(xim + hp * WG_PITCH + pc * 16) = v;
         }
         __syncthreads();
+        }
         // ---- 8 k-steps of 16 pixels
 #pragma unroll 2
         for (int kb = 0; kb < TP / 16; ++kb) {
@@ -257,15 +306,17 @@ extern "C" int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int
     DXMI_CHECK_ARG(lds <= 160 * 1024, "dxmi_conv2d_wgrad: LDS %zu too large", lds);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(S * a.CIB * a.COB), block(256);
-    if (ksize == 3) {
-        static bool attr3 = false;
-        if (!attr3) { hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr3 = true; }
-        hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, block, lds, st, a);
-    } else {
-        static bool attr1 = false;
-        if (!attr1) { hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr1 = true; }
-        hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, block, lds, st, a);
-    }
+    static const int pf_env = getenv("DXMI_WGRAD_PF") ? atoi(getenv("DXMI_WGRAD_PF")) : 1;   // tuning override
+    const bool pf = pf_env && (long)a.SUBS * a.HH * a.HWd * 8 <= 8 * 256;   // halo pieces per thread <= 8: prefetching kernel
+#define DXMI_WG_LAUNCH(KS_, PF_)                                                                                              \
+    do {                                                                                                                      \
+        static bool attr = false;                                                                                             \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KS_, PF_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((conv_wgrad_kernel<KS_, PF_>), grid, block, lds, st, a);                                            \
+    } while (0)
+    if (ksize == 3) { if (pf) DXMI_WG_LAUNCH(3, true); else DXMI_WG_LAUNCH(3, false); }
+    else { if (pf) DXMI_WG_LAUNCH(1, true); else DXMI_WG_LAUNCH(1, false); }
+#undef DXMI_WG_LAUNCH
     DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad");
     const long total = (long)ksize * ksize * Cout * Cin;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
