@@ -30,6 +30,7 @@ struct WgradArgs {
     const bf16* x1;      // second concat source or null
     const bf16* dy;      // output gradient, NHWC [N,OH,OW,Cout]
     float* partial;      // [S][taps][Cout][Cin] fp32
+    float* bpart;        // optional [S][4][Cout] fp32: column sums of dY (bias gradient), written by the ci-block-0 workgroups
     int N, IH, IW, C0, C1, OH, OW, Cout;
     int ksize, pad, ups, stride;
     int TWl, THl, SUBS, HH, HWd;  // 128-pixel tile geometry + halo
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     const int krow = 8 * (g >> 1) + q;               // + 4 for the second read
 
     f32x16 acc[TAPS];
+    float bsum = 0.f;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -165,6 +167,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         }
         __syncthreads();
         }
+        if (p.bpart && cib == 0) {   // bias gradient rides along: this workgroup's 64 couts x 128 staged pixels
+            const int col = tid & 63, part = tid >> 6;
+#pragma unroll 8
+            for (int px = part * 32; px < part * 32 + 32; ++px) bsum += (float)*reinterpret_cast<const bf16*>(ydy + px * WG_PITCH + col * 2);
+        }
         // ---- 8 k-steps of 16 pixels
 #pragma unroll 2
         for (int kb = 0; kb < TP / 16; ++kb) {
@@ -183,6 +190,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
             }
         }
     }
+    if (p.bpart && cib == 0) p.bpart[((size_t)split * 4 + (tid >> 6)) * p.Cout + co0 + (tid & 63)] = bsum;
     // ---- partial block: D[co][ci], lane: ci = lane&31, co = 8g' + 4h + {0..3}
     const int h = lane >> 5;
     float* pb = p.partial + (size_t)split * TAPS * p.Cout * Cin;
@@ -274,12 +282,12 @@ extern "C" int64_t dxmi_conv2d_wgrad_workspace_bytes(int32_t N, int32_t OH, int3
     long S = 512 / ((long)(Cin / 64) * (Cout / 64));
     if (S < 1) S = 1;
     if (S > PT) S = PT;
-    return S * ksize * ksize * (int64_t)Cout * Cin * 4;
+    return S * ksize * ksize * (int64_t)Cout * Cin * 4 + S * 4 * (int64_t)Cout * 4;   // + bias-gradient partials
 }
 
-extern "C" int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int32_t C1, const void* dy, float* dw_oihw,
-                                 void* workspace, int32_t N, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t Cout,
-                                 int32_t ksize, int32_t stride, int32_t pad, int32_t upsample, int32_t accumulate, void* stream) {
+static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, const void* dy, float* dw_oihw, float* dbias,
+                      void* workspace, int32_t N, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t Cout,
+                      int32_t ksize, int32_t stride, int32_t pad, int32_t upsample, int32_t accumulate, void* stream) {
     DXMI_CHECK_ARG(stride == 1 || stride == 2, "dxmi_conv2d_wgrad: stride %d unsupported", stride);
     DXMI_CHECK_ARG(x0 && dy && dw_oihw && workspace, "dxmi_conv2d_wgrad: null pointer");
     const int Cin = C0 + C1;
@@ -302,6 +310,7 @@ extern "C" int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int
     if (S < 1) S = 1;
     if (S > a.PT) S = a.PT;
     a.S = S;
+    a.bpart = dbias ? reinterpret_cast<float*>(workspace) + (size_t)S * ksize * ksize * Cout * Cin : nullptr;
     const size_t lds = (size_t)(128 + a.SUBS * a.HH * a.HWd) * WG_PITCH;
     DXMI_CHECK_ARG(lds <= 160 * 1024, "dxmi_conv2d_wgrad: LDS %zu too large", lds);
     hipStream_t st = (hipStream_t)stream;
@@ -322,7 +331,30 @@ extern "C" int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
                        dw_oihw, S, ksize * ksize, Cout, Cin, accumulate);
     DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad(reduce)");
+    if (dbias) {
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((Cout + 15) / 16), dim3(256), 0, st, (const float*)a.bpart, dbias, S * 4, Cout,
+                           accumulate);
+        DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad(bias reduce)");
+    }
     return DXMI_OK;
+}
+
+extern "C" int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int32_t C1, const void* dy, float* dw_oihw,
+                                 void* workspace, int32_t N, int32_t IH, int32_t IW, int32_t OH, int32_t OW, int32_t Cout,
+                                 int32_t ksize, int32_t stride, int32_t pad, int32_t upsample, int32_t accumulate, void* stream) {
+    return wgrad_impl(x0, C0, x1, C1, dy, dw_oihw, nullptr, workspace, N, IH, IW, OH, OW, Cout, ksize, stride, pad, upsample,
+                      accumulate, stream);
+}
+
+// Same, plus the bias gradient dbias[co] = sum_p dY[p][co] (fp32 [Cout]) from the dY tiles the kernel stages anyway -
+// replaces the separate column-sum pass over dY.
+extern "C" int dxmi_conv2d_wgrad_bias(const void* x0, int32_t C0, const void* x1, int32_t C1, const void* dy, float* dw_oihw,
+                                      float* dbias, void* workspace, int32_t N, int32_t IH, int32_t IW, int32_t OH, int32_t OW,
+                                      int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t upsample,
+                                      int32_t accumulate, void* stream) {
+    DXMI_CHECK_ARG(dbias, "dxmi_conv2d_wgrad_bias: dbias is NULL");
+    return wgrad_impl(x0, C0, x1, C1, dy, dw_oihw, dbias, workspace, N, IH, IW, OH, OW, Cout, ksize, stride, pad, upsample,
+                      accumulate, stream);
 }
 
 extern "C" int dxmi_colsum_bf16(const void* x, float* out, void* workspace, int64_t P, int32_t C, int32_t accumulate,

@@ -37,6 +37,7 @@ SIGNATURES = {
     "dxmi_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_conv2d_wgrad_workspace_bytes": (c_int64, [c_int] * 6),
     "dxmi_conv2d_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
+    "dxmi_conv2d_wgrad_bias": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
     "dxmi_groupnorm_silu_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 9 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dxmi_bgemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "dxmi_softmax_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

@@ -170,9 +170,10 @@ def _workspace(nbytes, device):
     return buf
 
 
-def conv2d_wgrad(x, dy, ksize, *, in1=None, pad=None, stride=1, upsample=False, out=None, accumulate=False):
-    """Weight gradient of a stride-1 conv: x [N,IH,IW,C0] (| in1), dy [N,OH,OW,Cout] NHWC bf16 ->
-    fp32 OIHW [Cout, C0+C1, k, k] (written, or added when accumulate)."""
+def conv2d_wgrad(x, dy, ksize, *, in1=None, pad=None, stride=1, upsample=False, out=None, accumulate=False, with_bias=False):
+    """Weight gradient of a conv: x [N,IH,IW,C0] (| in1), dy [N,OH,OW,Cout] NHWC bf16 ->
+    fp32 OIHW [Cout, C0+C1, k, k] (written, or added when accumulate).  with_bias: also the bias gradient
+    (column sums of dy) from the same launch -> (dw, db)."""
     _need_cuda(x, in1, dy, out)
     N, IH, IW, C0 = x.shape
     C1 = in1.shape[3] if in1 is not None else 0
@@ -186,6 +187,11 @@ def conv2d_wgrad(x, dy, ksize, *, in1=None, pad=None, stride=1, upsample=False, 
     assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (Cout, C0 + C1, ksize, ksize)
     lib = load()
     ws = _workspace(lib.dxmi_conv2d_wgrad_workspace_bytes(N, OH, OW, C0 + C1, Cout, ksize), x.device)
+    if with_bias:
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+        check(lib.dxmi_conv2d_wgrad_bias(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(out), _ptr(db), _ptr(ws), N, IH, IW, OH, OW,
+                                         Cout, ksize, stride, pad, int(upsample), 0, _stream()), "dxmi_conv2d_wgrad_bias")
+        return out, db
     check(lib.dxmi_conv2d_wgrad(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(out), _ptr(ws), N, IH, IW, OH, OW, Cout, ksize,
                                 stride, pad, int(upsample), int(accumulate), _stream()), "dxmi_conv2d_wgrad")
     return out

@@ -135,8 +135,7 @@ class _UNetFn(torch.autograd.Function):
         d_tp = torch.zeros((N, pk["tproj_bias"].numel()), dtype=torch.float32, device=dev)
 
         def conv_wb(conv, x0, gy, k, x1=None, **kw):
-            grads[conv.weight] = ops.conv2d_wgrad(x0, gy, k, in1=x1, **kw)
-            grads[conv.bias] = ops.colsum(gy)
+            grads[conv.weight], grads[conv.bias] = ops.conv2d_wgrad(x0, gy, k, in1=x1, with_bias=True, **kw)
 
         # ---- head: eps = conv_out(silu(gn(h_last)))
         H = d_eps.shape[2]

@@ -158,8 +158,8 @@ class _EDMUNetFn(torch.autograd.Function):
         emb_all = ctx.emb_all
 
         def conv_wb(conv, x0, gy, k, x1=None, **kw):
-            grads[conv.weight] = ops.conv2d_wgrad(x0, gy, k, in1=x1, **kw).reshape(conv.weight.shape)
-            grads[conv.bias] = ops.colsum(gy)
+            dw, grads[conv.bias] = ops.conv2d_wgrad(x0, gy, k, in1=x1, with_bias=True, **kw)
+            grads[conv.weight] = dw.reshape(conv.weight.shape)
 
         def gn_bwd(norm, xin, dy, *, in1=None, add0=None, add1=None, silu=True, scale_shift=None):
             dx0, dx1, dg, db, d_ss = ops.groupnorm_generic_bwd(xin, dy, norm.weight, norm.bias, in1=in1, add0=add0, add1=add1,

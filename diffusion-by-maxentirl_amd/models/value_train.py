@@ -6,7 +6,7 @@ inference and keeps the (bf16 NHWC) activations; backward walks the blocks in re
   * data gradients  = the forward MFMA conv kernel on transpose-flipped weight fragments, with the
     LeakyReLU derivative (mask of the saved activation) and the skip-path gradient fused into its
     epilogue,
-  * weight gradients = the MFMA pixel-GEMM (dxmi_conv2d_wgrad), bias gradients = column sums,
+  * weight gradients = the MFMA pixel-GEMM (dxmi_conv2d_wgrad), bias gradients = column sums of dY from the same launch,
   * avg-pool / LeakyReLU / head backward = small fused elementwise kernels.
 Parameter gradients come back as fp32 tensors in the reference's parameter order, so optimizers,
 clip_grad_norm_ and DDP-style flat-gradient all-reduce see ordinary `.grad`s.
@@ -73,11 +73,9 @@ class _ValueNetFn(torch.autograd.Function):
             inp, h1, out = saved[i]
             # gradient w.r.t. conv2 output + skip (before pool / LeakyReLU)
             d_c2 = ops.pool_act_bwd(g_out, out, b.downsample, SLOPE)
-            grads[b.conv2.weight] = ops.conv2d_wgrad(h1, d_c2, 3)
-            grads[b.conv2.bias] = ops.colsum(d_c2)
+            grads[b.conv2.weight], grads[b.conv2.bias] = ops.conv2d_wgrad(h1, d_c2, 3, with_bias=True)
             d_h1 = ops.conv2d(d_c2, pk_t[i, "conv2"], mask_src=h1, mask_slope=SLOPE)  # * LeakyReLU'(h1)
-            grads[b.conv1.weight] = ops.conv2d_wgrad(inp, d_h1, 3)
-            grads[b.conv1.bias] = ops.colsum(d_h1)
+            grads[b.conv1.weight], grads[b.conv1.bias] = ops.conv2d_wgrad(inp, d_h1, 3, with_bias=True)
             if b.skip is not None:
                 grads[b.skip[0].weight] = ops.conv2d_wgrad(inp, d_c2, 1)
                 d_skip = ops.conv2d(d_c2, pk_t[i, "skip"])

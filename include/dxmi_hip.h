@@ -113,6 +113,12 @@ int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int32_t C1, co
                       float* dw_oihw, void* workspace, int32_t N, int32_t IH, int32_t IW, int32_t OH,
                       int32_t OW, int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t upsample,
                       int32_t accumulate, void* stream);
+/* Same plus the bias gradient dbias[co] = sum_p dY[p][co] (fp32 [Cout]), summed from the dY tiles the kernel stages
+ * anyway (replaces a separate column-sum pass over dY; trainer.py's loss.backward() for nn.Conv2d.bias). */
+int dxmi_conv2d_wgrad_bias(const void* x0, int32_t C0, const void* x1, int32_t C1, const void* dy, float* dw_oihw,
+                           float* dbias, void* workspace, int32_t N, int32_t IH, int32_t IW, int32_t OH, int32_t OW,
+                           int32_t Cout, int32_t ksize, int32_t stride, int32_t pad, int32_t upsample,
+                           int32_t accumulate, void* stream);
 /* workspace: ceil(P/512) * C floats */
 int dxmi_colsum_bf16(const void* x, float* out, void* workspace, int64_t P, int32_t C,
                      int32_t accumulate, void* stream);
