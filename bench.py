@@ -44,7 +44,7 @@ def kernel_name(kid):
         return "conv1x1_stream_kernel<2, 4, 4>"
     if kid >= 10000:
         nb, ks = (kid // 100) % 100, kid // 10000
-        aq = (8 if nb == 2 else (4 if nb == 4 else 1)) if ks == 3 else 1   # queue depth chosen in conv_pipe.hip
+        aq = (8 if nb == 2 else ((3 if kid % 100 == 4 else 4) if nb == 4 else 1)) if ks == 3 else 1   # queue depth chosen in conv_pipe.hip
         pmax = kid % 100
         sd = 2 if (ks == 3 and pmax == 4) else 1   # staging distance chosen in conv_pipe.hip
         return f"conv_pipe_kernel<{nb}, {pmax}, {ks}, 0, {aq}, {sd}>"

@@ -661,12 +661,12 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     static const int stagger = getenv("DXMI_CONV_STAGGER") ? atoi(getenv("DXMI_CONV_STAGGER")) : 2;   // measured: 0 -> 2 = -2 % conv time
     b.stagger = (grid > 256 && b.PT / nstreams >= 2) ? stagger : 0;
     if (stream1x1) return launch_stream<2, 4, 4>(b, b.PT * CT, st);
-    // queue depth by shape: 3x3 at NB=2 (4x4 / 8x8 maps, latency bound) 8 ahead, 3x3 at NB=4 4 ahead (register
-    // budget of two workgroups per CU), 1x1 (short K loops, measured no gain) 1 ahead
+    // queue depth by shape: 3x3 at NB=2 (4x4 / 8x8 maps, latency bound) 8 ahead, 3x3 at NB=4 3 ahead with the two staging sets (4 ahead spills
+    // at two workgroups per CU: measured 4.74 -> 4.63 ms of conv time per forward going from 4 to 3), 1x1 (short K loops, measured no gain) 1 ahead
     // staging distance: with few enough halo pieces per thread two register sets fit, and the halo of the chunk AFTER
     // next is requested (17 steps of cover instead of 8): -5..10 % on the K <= 2304 layers
     if (a.ksize == 3) {
-        if (NB == 4) return pmax == 4 ? launch_pipe<4, 4, 3, 0, 4, 2>(b, grid, st) : launch_pipe<4, 6, 3, 0, 4>(b, grid, st);
+        if (NB == 4) return pmax == 4 ? launch_pipe<4, 4, 3, 0, 3, 2>(b, grid, st) : launch_pipe<4, 6, 3, 0, 4>(b, grid, st);
         return launch_pipe<2, 6, 3, 0, 8>(b, grid, st);   // 64-pixel tiles: the second register set measured no gain
     }
     return NB == 4 ? launch_pipe<4, 6, 1>(b, grid, st) : launch_pipe<2, 6, 1>(b, grid, st);   // 1x1 behind an upsample (unused by the nets)
