@@ -11,6 +11,7 @@
 // Reference: Normalize()/nonlinearity, models/DxMI/unet_small.py:30-36,119-126,169,329-330;
 // GroupNorm32, models/cm/nn.py:19-21.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -167,6 +168,15 @@ __global__ __launch_bounds__(512) void gn_silu_kernel(GnArgs p) {
 // in a fixed order, then normalises its rows (second read mostly served by L2 / Infinity Cache).
 // Optional per-image scale/shift (ADM "scale-shift norm", models/cm/unet.py:252-256):
 //   y = (xh*gamma + beta) * (1 + scale[n,c]) + shift[n,c]   then SiLU.
+// row chunks per image of the generic kernels: ~256 pixel rows per workgroup, more (down to 64 rows) while the launch
+// would otherwise have fewer than ~1024 workgroups
+static inline int gn_gen_chunks(int HW, int N) {
+    if (HW < 256) return 1;
+    int c = HW / 256;
+    while ((long)N * c < 1024 && c < HW / 64) c *= 2;
+    return c > 64 ? 64 : c;
+}
+
 struct GnGenArgs {
     const bf16* in0;
     const bf16* in1;
@@ -580,7 +590,7 @@ extern "C" int dxmi_groupnorm_silu_bwd(const void* in0, int32_t C0, const void* 
 }
 
 extern "C" int64_t dxmi_groupnorm_generic_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
-    const int chunks = HW >= 1024 ? 16 : (HW >= 256 ? 4 : 1);
+    const int chunks = gn_gen_chunks(HW, N);
     (void)C;
     return (int64_t)N * chunks * 32 * 2 * 4;
 }
@@ -597,7 +607,7 @@ extern "C" int dxmi_groupnorm_generic_fwd(const void* in0, int32_t C0, const voi
     GnGenArgs a;
     a.in0 = (const bf16*)in0; a.in1 = (const bf16*)in1; a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.ss_ld = ss_ld;
     a.out = (bf16*)out; a.part = (float*)workspace; a.C0 = C0; a.C1 = C1; a.HW = HW; a.groups = groups; a.cpg = C / groups;
-    a.chunks = HW >= 1024 ? 16 : (HW >= 256 ? 4 : 1);
+    a.chunks = gn_gen_chunks(HW, N);
     a.rows_per_chunk = (HW + a.chunks - 1) / a.chunks;
     a.eps = eps; a.silu = apply_silu;
     hipStream_t st = (hipStream_t)stream;
@@ -849,7 +859,7 @@ extern "C" int dxmi_groupnorm_silu_fwd(const void* in0, int32_t C0, const void* 
 }
 
 extern "C" int64_t dxmi_groupnorm_generic_bwd_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
-    const int chunks = HW >= 1024 ? 16 : (HW >= 256 ? 4 : 1);
+    const int chunks = gn_gen_chunks(HW, N);
     return (int64_t)N * chunks * 32 * 2 * 4 + (int64_t)N * chunks * C * 2 * 4;
 }
 
@@ -863,7 +873,7 @@ extern "C" int dxmi_groupnorm_generic_bwd(const void* in0, int32_t C0, const voi
     const int C = C0 + C1;
     DXMI_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0 && C0 % 8 == 0 && C1 % 8 == 0 && (C1 == 0 || (in1 && dx1)) && C <= 2048,
                    "dxmi_groupnorm_generic_bwd: C0=%d C1=%d groups=%d", C0, C1, groups);
-    const int chunks = HW >= 1024 ? 16 : (HW >= 256 ? 4 : 1);
+    const int chunks = gn_gen_chunks(HW, N);
     float* part = (float*)workspace;
     GnGenArgs f;
     f.in0 = (const bf16*)in0; f.in1 = (const bf16*)in1; f.gamma = gamma; f.beta = beta; f.ss = scale_shift; f.ss_ld = ss_ld;
