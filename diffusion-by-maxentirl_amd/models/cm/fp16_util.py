@@ -51,9 +51,13 @@ def unflatten_master_params(param_group, master_param):
 
 
 def master_params_to_model_params(param_groups_and_shapes, master_params):
+    """One multi-tensor copy per group (the reference loops `param.detach().copy_()` over ~600 tensors per step)."""
     for master_param, (param_group, _) in zip(master_params, param_groups_and_shapes):
-        for (_, param), unflat in zip(param_group, unflatten_master_params(param_group, master_param.view(-1))):
-            param.detach().copy_(unflat)
+        if not param_group:
+            continue
+        dst = [param.detach() for (_, param) in param_group]
+        src = list(unflatten_master_params(param_group, master_param.detach().view(-1)))
+        torch._foreach_copy_(dst, src)
 
 
 def zero_master_grads(master_params):
@@ -62,10 +66,11 @@ def zero_master_grads(master_params):
 
 
 def zero_grad(model_params):
+    """Drop the gradients instead of zero-filling them (the reference fills ~600 tensors, then autograd ADDS the new
+    gradient into each): every backward here is preceded by a zero_grad, so assigning is the same value with neither
+    the fill nor the add kernels; param_grad_or_zeros() covers parameters that received no gradient."""
     for param in model_params:
-        if param.grad is not None:
-            param.grad.detach_()
-            param.grad.zero_()
+        param.grad = None
 
 
 def check_overflow(value):
