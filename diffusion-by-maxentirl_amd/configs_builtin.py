@@ -58,7 +58,9 @@ CONFIGS["imagenet64_T4"] = copy.deepcopy(CONFIGS["imagenet64_T10"])
 CONFIGS["imagenet64_T4"]["sampler"].update({"n_timesteps": 4, "stochastic_last": True, "rho": 4.0})
 CONFIGS["imagenet64_T4"]["trainer"].update({"n_timesteps": 4, "skip_sampler_tau": 0, "skip_running_last": 1})
 CONFIGS["lsun_bedroom_T4"] = {
-    "diffusion": dict(_EDM_COMMON, image_size=256, num_channels=256, class_cond=False),
+    # configs/lsun/T4.yaml:1-21: two res blocks per level, additive embedding (no scale-shift norm), unconditional
+    "diffusion": dict(_EDM_COMMON, image_size=256, num_channels=256, class_cond=False, num_res_blocks=2,
+                      use_scale_shift_norm=False),
     "sampler": {"sample_shape": [3, 256, 256], "n_timesteps": 4, "class_cond": False, "num_classes": 1000,
                 "trainable_beta": "fix_last", "sigma_min": 0.002, "sigma_max": 80.0, "stochastic_last": True, "rho": 4.0},
     "training": {"pretrained_path": "pretrained/lsun_bedroom_edm/edm_bedroom256_ema.pt", "batchsize": 16,

@@ -37,6 +37,13 @@ __global__ void var_gather_sched_kernel(const int64_t* __restrict__ t, const flo
     if (b >= N) return;
     long ti = t[b];
     if (ti < 0) ti += T;  // python-style wrap, as torch indexing does
+    if (ti < 0 || ti >= T) {
+        // torch indexing raises here (IndexError); a kernel cannot, and must not read out of bounds: poison the
+        // sample's scalars so everything derived from them is NaN (the host wrapper checks host-resident t eagerly)
+        const float q = __builtin_nanf("");
+        tau[b] = q; xmul[b] = q; cmul[b] = q; sigma[b] = q;
+        return;
+    }
     tau[b] = cont[ti];
     xmul[b] = xmul_tab[ti];
     cmul[b] = cmul_tab[ti];

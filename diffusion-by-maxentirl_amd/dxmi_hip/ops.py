@@ -374,10 +374,11 @@ def edm_precond(x, sigma, sigma_data=0.5):
     return x_in, t
 
 
-def edm_step(x, model_out, z, sigma, sigma_down, sigma_up, sigma_data=0.5):
+def edm_step(x, model_out, z, sigma, sigma_down, sigma_up, sigma_data=0.5, outs=None):
     _need_cuda(x, model_out, z, sigma, sigma_down, sigma_up)
     N = x.shape[0]
-    sample, mean = torch.empty_like(x), torch.empty_like(x)
+    sample, mean = (torch.empty_like(x), torch.empty_like(x)) if outs is None else outs
+    assert sample.is_contiguous() and mean.is_contiguous() and sample.shape == x.shape and mean.shape == x.shape
     check(load().dxmi_edm_step_fwd(_ptr(x), _ptr(model_out), _ptr(z), _ptr(sigma), _ptr(sigma_down), _ptr(sigma_up), _ptr(sample),
                                    _ptr(mean), N, x.numel() // N, float(sigma_data), _stream()), "dxmi_edm_step_fwd")
     return sample, mean
@@ -417,11 +418,13 @@ def linear(x, pw, bias=None, pre_act=ACT_NONE, post_act=ACT_NONE, out=None):
     return out
 
 
-def var_gather_sched(t, continuous_steps, xmul_tab, cmul_tab, log_betas_all):
-    _need_cuda(t, continuous_steps, xmul_tab, cmul_tab, log_betas_all)
+def var_gather_sched(t, continuous_steps, xmul_tab, cmul_tab, log_betas_all, sigma_out=None):
+    _need_cuda(t, continuous_steps, xmul_tab, cmul_tab, log_betas_all, sigma_out)
     assert t.dtype == torch.int64
     N, T = t.numel(), continuous_steps.numel()
-    outs = [torch.empty(N, dtype=torch.float32, device=t.device) for _ in range(4)]
+    outs = [torch.empty(N, dtype=torch.float32, device=t.device) for _ in range(3)]
+    outs.append(sigma_out if sigma_out is not None else torch.empty(N, dtype=torch.float32, device=t.device))
+    assert outs[3].is_contiguous() and outs[3].numel() == N and outs[3].dtype == torch.float32
     check(load().dxmi_var_gather_sched(_ptr(t), _ptr(continuous_steps), _ptr(xmul_tab), _ptr(cmul_tab),
                                        _ptr(log_betas_all), *[_ptr(o) for o in outs], N, T, _stream()),
           "dxmi_var_gather_sched")
@@ -497,4 +500,99 @@ def nhwc_bf16_to_nchw_f32(x, out=None):
     if out is None:
         out = torch.empty((N, C, H, W), dtype=torch.float32, device=x.device)
     check(load().dxmi_nhwc_bf16_to_nchw_f32(_ptr(x), _ptr(out), N, C, H * W, _stream()), "dxmi_nhwc_bf16_to_nchw_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ train-step tail
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _numel_array(tensors):
+    return (ctypes.c_int64 * len(tensors))(*[t.numel() for t in tensors])
+
+
+def _need_f32_dense(*lists):
+    for ts in lists:
+        for t in ts:
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                raise _lib.DxmiError("multi-tensor kernels take contiguous fp32 device tensors")
+
+
+def adam_step(params, grads, exp_avgs, exp_avg_sqs, step_sizes, beta1, beta2, eps, bc2_sqrt, grad_scale=None,
+              write_back_grad=False, cache=None):
+    """One torch.optim.Adam update of every tensor in the lists (see dxmi_adam_step).  step_sizes: python floats
+    -(lr_i / (1 - beta1^t)).  cache: dict reused across calls for the pointer arrays of params / moments (stable)."""
+    _need_f32_dense(params, grads, exp_avgs, exp_avg_sqs)
+    n = len(params)
+    if cache is None or cache.get("n") != n:
+        c = {"n": n, "p": _ptr_array(params), "m": _ptr_array(exp_avgs), "v": _ptr_array(exp_avg_sqs), "numel": _numel_array(params)}
+        if cache is not None:
+            cache.update(c)
+        cache = c
+    ss = (ctypes.c_float * n)(*step_sizes)
+    check(load().dxmi_adam_step(cache["p"], _ptr_array(grads), cache["m"], cache["v"], cache["numel"], ss, n, beta1, beta2, eps,
+                                bc2_sqrt, _ptr(grad_scale), int(write_back_grad), _stream()), "dxmi_adam_step")
+
+
+def radam_step(params, grads, exp_avgs, exp_avg_sqs, lrs, beta1, beta2, eps, bc1, bc2_sqrt, rect, grad_scale=None,
+               found_inf=None, cache=None):
+    """One torch.optim.RAdam update (see dxmi_radam_step); rect < 0 selects the un-rectified branch."""
+    _need_f32_dense(params, grads, exp_avgs, exp_avg_sqs)
+    n = len(params)
+    if cache is None or cache.get("n") != n:
+        c = {"n": n, "p": _ptr_array(params), "m": _ptr_array(exp_avgs), "v": _ptr_array(exp_avg_sqs), "numel": _numel_array(params)}
+        if cache is not None:
+            cache.update(c)
+        cache = c
+    lr = (ctypes.c_float * n)(*lrs)
+    check(load().dxmi_radam_step(cache["p"], _ptr_array(grads), cache["m"], cache["v"], cache["numel"], lr, n, beta1, beta2, eps,
+                                 bc1, bc2_sqrt, rect, _ptr(grad_scale), _ptr(found_inf), _stream()), "dxmi_radam_step")
+
+
+def gradnorm_clip(grads, max_norm, scale_in_place=True, out=None):
+    """Global L2 norm of `grads` and the clip coefficient, on the device: returns fp32 [3] = (norm, coef, non-finite flag).
+    max_norm <= 0: norm only."""
+    _need_f32_dense(grads)
+    lib = load()
+    numel = _numel_array(grads)
+    nb = lib.dxmi_mt_blocks(numel, len(grads))
+    dev = grads[0].device
+    ws = _workspace(int(nb) * 4 + 64, dev)
+    if out is None:
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+    check(lib.dxmi_gradnorm_clip(_ptr_array(grads), numel, len(grads), float(max_norm), _ptr(ws), _ptr(out),
+                                 int(scale_in_place and max_norm > 0), _stream()), "dxmi_gradnorm_clip")
+    return out
+
+
+def clip_grad_norm_(parameters, max_norm):
+    """torch.nn.utils.clip_grad_norm_ without the host round trip: returns the total norm as a DEVICE scalar."""
+    grads = [p.grad for p in parameters if p.grad is not None]
+    if not grads:
+        return None
+    return gradnorm_clip(grads, max_norm)[0]
+
+
+def dropout(x, p, seed, out=None):
+    """Counter-hash dropout of a bf16 tensor (see dxmi_dropout_bf16); call again with the same seed on the gradient."""
+    _need_cuda(x, out)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(load().dxmi_dropout_bf16(_ptr(x), _ptr(out), x.numel(), float(p), int(seed) & 0xFFFFFFFF, _stream()), "dxmi_dropout_bf16")
+    return out
+
+
+def gather_rows(src, idx, out=None):
+    """out[r] = src[idx[r]] along dim 0 (INT path of the replay buffer); idx int64 on the device."""
+    _need_cuda(src, idx, out)
+    assert src.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous() and idx.dim() == 1
+    n = idx.numel()
+    row_bytes = (src.numel() // max(src.shape[0], 1)) * src.element_size()
+    if out is None:
+        out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    assert out.is_contiguous() and out.dtype == src.dtype and out.numel() * out.element_size() == n * row_bytes
+    if n:
+        check(load().dxmi_gather_rows(_ptr(src), _ptr(idx), _ptr(out), n, src.shape[0], row_bytes, _stream()), "dxmi_gather_rows")
     return out

@@ -62,7 +62,7 @@ class OpenAIDiffusion:
         net = self.net.module if hasattr(self.net, "module") else self.net
         return net.log_betas
 
-    def sample_step(self, x, indices, noise=None, **model_kwargs):
+    def sample_step(self, x, indices, noise=None, _outs=None, **model_kwargs):
         if not x.is_cuda:
             raise DxmiError("OpenAIDiffusion.sample_step runs only on the HIP device path (no CPU fallback)")
         sig_t, down_t, up_t = self._tabs(x.device)
@@ -84,7 +84,7 @@ class OpenAIDiffusion:
         x_in, rescaled_t = ops.edm_precond(x, sigma.contiguous(), self.diffusion.sigma_data)
         model_output = self.net(x_in, rescaled_t, **model_kwargs)
         samples, mu = ops.edm_step(x, model_output, z.contiguous(), sigma.contiguous(), sigma_down.contiguous(),
-                                   sigma_up.detach().float().contiguous(), self.diffusion.sigma_data)
+                                   sigma_up.detach().float().contiguous(), self.diffusion.sigma_data, outs=_outs)
         return {"sample": samples, "mean": mu, "sigma": sigma_up.clamp(1e-4, None)}
 
     def _sample_step_grad(self, x, z, sigma, sigma_down, sigma_up, model_kwargs):
@@ -104,8 +104,11 @@ class OpenAIDiffusion:
         samples = mu + z * e(sigma_up)
         return {"sample": samples, "mean": mu, "sigma": sigma_up.clamp(1e-4, None)}
 
-    def sample(self, n_sample, device, i_class=None, enable_grad=False, x0=None, noise=None):
-        """noise: optional [T+1, n, C, H, W]; noise[0] * sigma_max is x_T, noise[1 + i] the draw of step i."""
+    def sample(self, n_sample, device, i_class=None, enable_grad=False, x0=None, noise=None, out=None):
+        """noise: optional [T+1, n, C, H, W]; noise[0] * sigma_max is x_T, noise[1 + i] the draw of step i.
+        The trajectory is ONE block [T+1, B, C, H, W] (+ [T, B, ...] mean, [T, B] sigma) written by the fused transition
+        kernel; out: a slot of a models.DxMI.replay.TransitionRing to generate in place in the replay buffer."""
+        device = torch.device(device)
         if self.class_cond:
             if i_class is None:
                 i_class = torch.randint(0, self.num_classes, (n_sample,), device=device)
@@ -114,19 +117,41 @@ class OpenAIDiffusion:
             model_kwargs = {"y": i_class}
         else:
             i_class, model_kwargs = None, {}
-        if x0 is not None:
-            x = x0.to(device)
-        elif noise is not None:
-            x = noise[0].to(device) * self.sigma_max
+        T = self.n_timesteps
+        size = (n_sample,) + tuple(self.sample_shape)
+        in_place = not enable_grad
+        if out is None:
+            f32 = dict(dtype=torch.float32, device=device)
+            traj, mean_b, sigma_b = torch.empty((T + 1,) + size, **f32), torch.empty((T,) + size, **f32), torch.empty((T, n_sample), **f32)
         else:
-            x = torch.randn(n_sample, *self.sample_shape, device=device) * self.sigma_max
+            assert in_place, "a ring slot cannot hold a differentiable trajectory"
+            traj, mean_b, sigma_b = out["traj"], out["mean"], out["sigma"]
+            assert traj.shape == (T + 1,) + size and traj.device == device, "ring slot does not match this sampler / batch"
+            if i_class is not None and out["y"] is not None:
+                out["y"].copy_(i_class)
+        if x0 is not None:
+            traj[0].copy_(x0)
+        elif noise is not None:
+            traj[0].copy_(noise[0])
+            traj[0].mul_(self.sigma_max)
+        else:
+            traj[0].normal_().mul_(self.sigma_max)
+        x = traj[0]
         l_x, l_mean, l_sigma = [x], [], []
-        for i in range(self.n_timesteps):
+        for i in range(T):
             with torch.set_grad_enabled(enable_grad):
                 d_step = self.sample_step(x, torch.full((len(x),), i, dtype=torch.long, device=device),
-                                          noise=None if noise is None else noise[1 + i].to(device), **model_kwargs)
+                                          noise=None if noise is None else noise[1 + i].to(device),
+                                          _outs=(traj[i + 1], mean_b[i]) if in_place else None, **model_kwargs)
             x = d_step["sample"]
             l_x.append(x)
             l_mean.append(d_step["mean"])
-            l_sigma.append(d_step["sigma"])
-        return {"sample": l_x[-1], "l_sample": l_x, "y": i_class, "mean": l_mean, "sigma": l_sigma}
+            if in_place:
+                sigma_b[i].copy_(d_step["sigma"])
+                l_sigma.append(sigma_b[i])
+            else:
+                l_sigma.append(d_step["sigma"])
+        d = {"sample": l_x[-1], "l_sample": l_x, "y": i_class, "mean": l_mean, "sigma": l_sigma}
+        if out is not None:
+            d["_ring_slot"] = (id(out["ring"]), out["slot"])
+        return d

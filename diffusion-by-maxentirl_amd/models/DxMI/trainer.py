@@ -6,11 +6,13 @@ velocity / entropy regularisers, adaptive velocity regulariser — including its
 (SURVEY 7): `betas_for_q` EMA before the value update, `target = V(x')` (the velocity-augmented target
 only survives on the energy branch), `randperm` drawn from torch's CPU generator, the
 len(img)==len(x0) slicing, clip-then-step.  What changes is how the work runs on the GPU:
-  * transitions are appended with ONE concatenation per field per call instead of T (the reference
-    re-copies the growing buffer T times per field: O(T^2) traffic), and the never-read `final` field
-    holds a view-expanded tensor;
-  * the TD loop gathers each step's rows once (index of an index) instead of materialising the
-    permuted T*B buffer five times per step;
+  * transitions live in a preallocated device ring (models/DxMI/replay.py) that the sampler's fused transition
+    kernel writes directly: `append_buffer` moves no data (the reference re-copies the growing buffer T times per
+    field: O(T^2) traffic).  A reference-style dict buffer is still accepted (one cat per field);
+  * the TD loop gathers each step's rows once with the INT gather kernel (dxmi_gather_rows) instead of
+    materialising the permuted T*B buffer five times per step, and finds each step's rows with ONE stable sort of
+    the permuted timesteps (same rows, same order as the reference's per-step `nonzero`, no host sync per step);
+  * gradient clipping computes the norm and the clip coefficient on the device (dxmi_gradnorm_clip: no `.item()`);
   * value targets are evaluated under no_grad (the reference builds and discards an autograd graph);
   * the logged scalars are collected on the device and synchronised ONCE per call instead of ~2T+10
     `.item()` round trips.
@@ -19,11 +21,15 @@ Networks run through their HIP autograd functions (models/value_train.py, unet_s
 import torch
 import torch.nn.functional as F
 
+from dxmi_hip import ops
 from ..diffusion import extract, make_beta_schedule
+from .replay import TransitionRing, buffer_gather, buffer_rows
 
 
-def reset_buffer(device):
-    """Empty transition buffer (reference :58-70)."""
+def reset_buffer(device, ring=None):
+    """Empty transition buffer (reference :58-70).  ring: a TransitionRing to recycle (its rows are dropped)."""
+    if ring is not None:
+        return ring.reset()
     d = {k: torch.FloatTensor().to(device) for k in ("state", "next_state", "final", "logp", "control", "entropy", "mean", "sigma")}
     d["timestep"] = torch.LongTensor().to(device)
     d["y"] = torch.LongTensor().to(device)
@@ -33,6 +39,8 @@ def reset_buffer(device):
 def append_buffer(state_buffer, d_sample):
     """Flatten a sampled trajectory into (state, next_state, timestep, ...) rows, time-major blocks of
     n_sample (reference :23-55).  Same resulting tensors; one cat per field."""
+    if isinstance(state_buffer, TransitionRing):
+        return state_buffer.append(d_sample)
     x_seq = d_sample["l_sample"]
     n_sample, n_seq = len(x_seq[0]), len(x_seq) - 1
     device = x_seq[0].device
@@ -142,24 +150,26 @@ class DxMI_Trainer:
 
         # TD value estimation over the last T*B buffered transitions
         permutation = torch.randperm(batchsize * n_steps)                     # CPU generator, as the reference
-        indices = (permutation + (state_dict["state"].shape[0] - batchsize * n_steps)).to(device)
-        ts_perm = state_dict["timestep"][indices]
+        indices = (permutation + (buffer_rows(state_dict) - batchsize * n_steps)).to(device)
+        rows_all, ts_all = self._td_rows(state_dict, indices, n_steps, batchsize)
+        need_entropy = bool(self.entropy_in_value or self.entropy_in_value == 0)
         running_cost = v_loss = None
         for i in range(n_steps):
             update_t = n_steps - i - 1
-            rows = indices[torch.nonzero(ts_perm == update_t).flatten()]     # == [indices][train_indices], gathered once
-            state = state_dict["state"][rows]
-            timestep = state_dict["timestep"][rows]
+            rows, timestep = rows_all[update_t], ts_all[update_t]             # == [indices][train_indices], gathered once
+            state = buffer_gather(state_dict, "state", rows)
+            pred_mean = pred_std = entropy = None
             if self.value_resample:
                 with torch.no_grad():
                     d_step = self.sampler.sample_step(state, timestep)
                 next_state, pred_mean, pred_std = d_step["sample"], d_step["mean"], d_step["sigma"]
             else:
-                next_state = state_dict["next_state"][rows]
-                pred_mean = state_dict["mean"][rows]
-                pred_std = state_dict["sigma"][rows]
+                next_state = buffer_gather(state_dict, "next_state", rows)
+                if need_entropy:       # mean / sigma rows are read only by the entropy term (result-neutral skip)
+                    pred_std = buffer_gather(state_dict, "sigma", rows)
             running_cost = self.get_running_cost(state, next_state, pred_mean, pred_std, timestep)
-            entropy = torch.log(pred_std.squeeze())
+            if need_entropy:
+                entropy = torch.log(pred_std.squeeze())
             self.v.eval()
             with torch.no_grad():
                 target = self.v(next_state, timestep + 1).squeeze()
@@ -177,7 +187,7 @@ class DxMI_Trainer:
             v_loss.backward()
             self.sync_v()
             if self.value_grad_clip:
-                torch.nn.utils.clip_grad_norm_(self.v.parameters(), 0.1)
+                self._clip(self.v.parameters(), 0.1)
             self.optimizer_v.step()
             self.optimizer_v.zero_grad()
             d_running_cost[f"running_cost/step_{update_t}_"] = running_cost.detach().mean()
@@ -196,15 +206,15 @@ class DxMI_Trainer:
         """reference :348-408."""
         self.v.eval()
         self.sampler.train()
-        permutation = torch.randperm(state_dict["state"].shape[0])
+        permutation = torch.randperm(buffer_rows(state_dict))
         batchsize = self.batchsize
         n_data = min(len(permutation), batchsize * n_generator)
-        device = state_dict["state"].device
+        device = state_dict.device if isinstance(state_dict, TransitionRing) else state_dict["state"].device
         for m in range(0, n_data, batchsize):
             self.optimizer.zero_grad()
             indices = permutation[m:m + batchsize].to(device)
-            state = state_dict["state"][indices]
-            t = state_dict["timestep"][indices]
+            state = buffer_gather(state_dict, "state", indices)
+            t = buffer_gather(state_dict, "timestep", indices)
             d_step = self.sampler.sample_step(state, t)
             next_state, pred_mean, pred_std = d_step["sample"], d_step["mean"], d_step["sigma"]
             running_cost = self.get_running_cost(state, next_state, pred_mean, pred_std, t)
@@ -214,7 +224,7 @@ class DxMI_Trainer:
             sampler_loss = (sampler_value_loss + (running_cost * self.tau2 - causal_entropy * self.tau1) * non_terminal).mean()
             sampler_loss.backward()
             self.sync_sampler()   # the value net's side-effect gradients of this backward are discarded, not reduced
-            torch.nn.utils.clip_grad_norm_(self.sampler.parameters(), 0.1)
+            self._clip(self.sampler.parameters(), 0.1)
             self.optimizer.step()
         logs = {"sampler/sampler_loss_": sampler_loss.detach(), "sampler/sampler_value_loss_": sampler_value_loss.detach().mean(),
                 "sampler/running_cost_": running_cost.detach().mean(), "sampler/causal_entropy_": causal_entropy.detach().mean()}
@@ -267,6 +277,27 @@ class DxMI_Trainer:
 
     def _guidance_model_kwargs(self, n_sample, device):
         return {}
+
+    @staticmethod
+    def _clip(parameters, max_norm):
+        """torch.nn.utils.clip_grad_norm_ with the norm and the coefficient kept on the device."""
+        ops.clip_grad_norm_(list(parameters), max_norm)
+
+    @staticmethod
+    def _td_rows(state_dict, indices, n_steps, batchsize):
+        """Rows (and their timesteps) of every TD step, indexed by t: the reference takes, per step,
+        `indices[nonzero(timestep[indices] == t)]` (trainer.py:278-280).
+        Ring buffer: every timestep owns exactly `batchsize` of the last T*B rows (whole trajectories of B samples), so
+        ONE stable sort of the permuted timesteps yields the same rows in the same order for all t at once, with no host
+        sync.  Reference-style dict buffer: the reference's own per-step nonzero (row counts may be ragged there)."""
+        if isinstance(state_dict, TransitionRing):
+            assert state_dict.B == batchsize and state_dict.T == n_steps, "ring geometry differs from the trainer's"
+            ts_perm = state_dict.timestep_of(indices)
+            order = torch.sort(ts_perm, stable=True).indices
+            return indices[order].view(n_steps, batchsize), ts_perm[order].view(n_steps, batchsize)
+        ts_perm = state_dict["timestep"][indices]
+        rows = [indices[torch.nonzero(ts_perm == t).flatten()] for t in range(n_steps)]
+        return rows, [state_dict["timestep"][r] for r in rows]
 
     @staticmethod
     def _to_floats(logs):
@@ -355,8 +386,10 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
         self.optimizer_v.zero_grad()
 
         permutation = torch.randperm(batchsize * n_steps)
-        indices = (permutation + (state_dict["state"].shape[0] - batchsize * n_steps)).to(device)
-        ts_perm = state_dict["timestep"][indices]
+        indices = (permutation + (buffer_rows(state_dict) - batchsize * n_steps)).to(device)
+        rows_all, ts_all = self._td_rows(state_dict, indices, n_steps, batchsize)
+        has_y = y is not None and (("y" in state_dict.has) if isinstance(state_dict, TransitionRing)
+                                   else len(state_dict["y"]) == len(state_dict["state"]))
         d_running_cost, d_value = {}, {}
         running_cost = v_loss = None
         for _ in range(self.repeat_value_update):
@@ -366,21 +399,23 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
                 update_t = int(update_order[i]) if self.value_update_order == "random" else n_steps - i - 1
                 if self.value_update_order == "shuffle":
                     rows = indices[torch.arange(batchsize, device=device) + i * batchsize]
+                    timestep = buffer_gather(state_dict, "timestep", rows)
                 else:
-                    rows = indices[torch.nonzero(ts_perm == update_t).flatten()]
-                state = state_dict["state"][rows]
-                timestep = state_dict["timestep"][rows]
-                yb = state_dict["y"][rows] if y is not None and len(state_dict["y"]) == len(state_dict["state"]) else y
+                    rows, timestep = rows_all[update_t], ts_all[update_t]
+                state = buffer_gather(state_dict, "state", rows)
+                yb = buffer_gather(state_dict, "y", rows) if has_y else y
+                pred_mean = pred_std = entropy = None
                 if self.value_resample:
                     with torch.no_grad():
                         d_step = self.sampler.sample_step(state, timestep, **({"y": yb} if yb is not None else {}))
                     next_state, pred_mean, pred_std = d_step["sample"], d_step["mean"], d_step["sigma"]
                 else:
-                    next_state = state_dict["next_state"][rows]
-                    pred_mean = state_dict["mean"][rows]
-                    pred_std = state_dict["sigma"][rows]
+                    next_state = buffer_gather(state_dict, "next_state", rows)
+                    if self.entropy_in_value is not None:    # sigma rows are read only by the entropy term
+                        pred_std = buffer_gather(state_dict, "sigma", rows)
                 running_cost = self.get_running_cost(state, next_state, pred_mean, pred_std, timestep)
-                entropy = torch.log(pred_std.squeeze() / self.sigma_scale) if self.sigma_scale is not None else torch.log(pred_std.squeeze())
+                if self.entropy_in_value is not None:
+                    entropy = torch.log(pred_std.squeeze() / self.sigma_scale) if self.sigma_scale is not None else torch.log(pred_std.squeeze())
                 self.v.eval()
                 with torch.no_grad():
                     target = self.v(next_state, timestep + 1, y=y).squeeze()
@@ -401,7 +436,7 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
                 v_loss.backward()
                 self.sync_v()
                 if self.value_grad_clip:
-                    torch.nn.utils.clip_grad_norm_(self.v.parameters(), 0.1)
+                    self._clip(self.v.parameters(), 0.1)
                 self.optimizer_v.step()
                 self.optimizer_v.zero_grad()
                 d_running_cost[f"running_cost/step_{update_t}_"] = running_cost.detach().mean()
@@ -427,15 +462,15 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
         """reference :693-746: one optimiser step per `batchsize` slice of ALL buffered transitions."""
         self.v.eval()
         self.sampler.train()
-        permutation = torch.randperm(state_dict["state"].shape[0])
+        permutation = torch.randperm(buffer_rows(state_dict))
         batchsize = self.batchsize
-        device = state_dict["state"].device
+        device = state_dict.device if isinstance(state_dict, TransitionRing) else state_dict["state"].device
         for m in range(0, len(permutation), batchsize):
             mp_trainer.zero_grad()
             indices = permutation[m:m + batchsize].to(device)
-            state = state_dict["state"][indices]
-            t = state_dict["timestep"][indices]
-            y = state_dict["y"][indices] if self.sampler.class_cond else None
+            state = buffer_gather(state_dict, "state", indices)
+            t = buffer_gather(state_dict, "timestep", indices)
+            y = buffer_gather(state_dict, "y", indices) if self.sampler.class_cond else None
             d_step = self.sampler.sample_step(state, t, **({"y": y} if y is not None else {}))
             next_state, pred_mean, pred_std = d_step["sample"], d_step["mean"], d_step["sigma"]
             running_cost = self.get_running_cost(state, next_state, pred_mean, pred_std, t)

@@ -144,6 +144,22 @@ class Model(nn.Module):
         self.conv_out = _conv(block_in, out_ch, 3, 1, 1)
         self._packed = None
         self._packed_key = None
+        self.dropout_seed = None          # base seed of the dropout hash (None: torch.initial_seed() at first use)
+        self.dropout_seeds_used = []      # seeds of the most recent training forward, in _resblocks() call order
+        self._dropout_calls = 0
+
+    def _next_dropout_seed(self):
+        """32-bit seed of the next dropout site: hash of (base seed, running call counter).  Deliberately NOT drawn from
+        torch's CPU generator, whose stream the trainer's randperm parity depends on."""
+        base = torch.initial_seed() if self.dropout_seed is None else self.dropout_seed
+        x = (base * 0x9E3779B97F4A7C15 + self._dropout_calls * 0xD1B54A32D192ED03 + 0x8CB92BA72F3D8DD7) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 32
+        x = (x * 0xD6E8FEB86659FD93) & 0xFFFFFFFFFFFFFFFF
+        x ^= x >> 32
+        self._dropout_calls += 1
+        seed = x & 0xFFFFFFFF
+        self.dropout_seeds_used.append(seed)
+        return seed
 
     # ------------------------------------------------------------------ weight fragments
     def _resblocks(self):

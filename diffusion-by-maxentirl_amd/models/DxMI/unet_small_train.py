@@ -3,13 +3,14 @@ models/DxMI/trainer.py:361-389 back-propagates the sampler loss through `sample_
 U-Net parameter; reference graph = torch autograd over models/DxMI/unet_small.py:292-332).
 
 One torch.autograd.Function wraps the network.  forward() is the inference program plus saved bf16
-NHWC activations (and dropout masks in train mode); backward() walks it in reverse:
+NHWC activations (and one dropout seed per ResnetBlock in train mode); backward() walks it in reverse:
   conv data gradients   = the forward MFMA kernels on transpose-flipped weight fragments (stride-2:
                           over the zero-stuffed gradient; upsample: full-res gradient then 2x2 sum),
                           with the skip-connection gradient fused as the epilogue residual;
   conv weight gradients = MFMA pixel-GEMM (dxmi_conv2d_wgrad, also strided / upsampled / 1x1);
   GroupNorm(+SiLU)      = dxmi_groupnorm_silu_bwd (dx split back into the two concat sources);
   attention             = five batched MFMA GEMMs + softmax backward (dxmi_bgemm_bf16);
+  dropout               = dxmi_dropout_bf16 with the forward's seed (no stored mask);
   temb MLP + temb_proj  = tiny dense layers: re-evaluated and differentiated with torch fp32 matmuls
                           (<0.05 % of the FLOPs; plain library GEMMs).
 Parameter gradients are returned in `net.parameters()` order as fp32 tensors.
@@ -53,6 +54,7 @@ class _UNetFn(torch.autograd.Function):
         pk = net.packed()
         x = x.contiguous().float()
         training, p_drop = net.training, net.dropout_p
+        net.dropout_seeds_used = []
         emb = ops.timestep_embedding(t, net.ch, order=0)
         h1 = ops.linear(emb, pk["dense0"], net.temb.dense[0].bias, post_act=ops.ACT_SILU)
         s_temb = ops.linear(h1, pk["dense1"], net.temb.dense[1].bias, post_act=ops.ACT_SILU)
@@ -66,8 +68,9 @@ class _UNetFn(torch.autograd.Function):
             a2 = ops.groupnorm_silu(h, b.norm2.weight, b.norm2.bias, eps=1e-6, silu=True)
             mask = None
             if training and p_drop > 0:
-                mask = (torch.rand(a2.shape, device=a2.device) >= p_drop).to(torch.bfloat16) * (1.0 / (1.0 - p_drop))
-                a2 = a2 * mask
+                # nn.Dropout (unet_small.py:129) as a counter-hash kernel: the backward regenerates the mask from the seed
+                mask = net._next_dropout_seed()
+                a2 = ops.dropout(a2, p_drop, mask)
             if b.in_channels != b.out_channels:
                 sc_mod = b.conv_shortcut if b.use_conv_shortcut else b.nin_shortcut
                 sc = ops.conv2d(x0, pk[id(b), "short"], in1=x1, bias=sc_mod.bias)
@@ -155,7 +158,7 @@ class _UNetFn(torch.autograd.Function):
             conv_wb(b.conv2, a2, g, 3)
             d_a2 = ops.conv2d(g, pkt[id(b), "conv2"])
             if mask is not None:
-                d_a2 = d_a2 * mask
+                d_a2 = ops.dropout(d_a2, net.dropout_p, mask, out=d_a2)
             d_h, _, dg2, db2 = ops.groupnorm_silu_bwd(h, d_a2, b.norm2.weight, b.norm2.bias, silu=True)
             grads[b.norm2.weight], grads[b.norm2.bias] = dg2, db2
             off = pk[id(b), "toff"]

@@ -208,14 +208,28 @@ class VARSampler(nn.Module):
             self._tcache = {key: tab}
         return tab[i]
 
-    def _transition(self, x, t, z, assoc):
-        """One fused transition for integer timesteps t [B] (device int64)."""
+    def _check_t(self, t):
+        """The reference's torch indexing raises on t outside [-T, T).  Host-resident t (python int, CPU tensor) is
+        checked here; for device tensors a check would be a host sync per transition, so the gather kernel poisons
+        out-of-range samples with NaN instead of reading out of bounds."""
+        if torch.is_tensor(t):
+            if t.is_cuda or t.numel() == 0:
+                return
+            lo, hi = int(t.min()), int(t.max())
+        else:
+            lo = hi = int(t)
+        if hi >= self.n_timesteps or lo < -self.n_timesteps:
+            raise IndexError(f"timestep out of range for a {self.n_timesteps}-step sampler: [{lo}, {hi}]")
+
+    def _transition(self, x, t, z, assoc, outs=None, sigma_out=None):
+        """One fused transition for integer timesteps t [B] (device int64).  outs = (x_next, mean, control, logp) and
+        sigma_out: preallocated destinations (rows of the trajectory block / replay ring)."""
         tau, xm, cm, sg = ops.var_gather_sched(t, self.continuous_steps, self.x_prev_multiplier, self.theta_multiplier,
-                                               self._log_betas_all().detach().float().contiguous())
+                                               self._log_betas_all().detach().float().contiguous(), sigma_out=sigma_out)
         eps = self.net(x, tau)
         if self.adhoc_scale1 != 1.0:
             cm = cm * self.adhoc_scale1
-        x_next, mean, control, logp = ops.var_step(x, eps, z, xm, cm, sg, assoc=assoc)
+        x_next, mean, control, logp = ops.var_step(x, eps, z, xm, cm, sg, assoc=assoc, outs=outs)
         return x_next, mean, control, logp, sg
 
     # ---- plugin API
@@ -223,6 +237,7 @@ class VARSampler(nn.Module):
         """One transition with per-sample integer t (reference :357-408)."""
         if not x.is_cuda:
             raise DxmiError("VARSampler.sample_step runs only on the HIP device path")
+        self._check_t(t)
         t = process_single_t(x, t)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
             from .var_sampler_train import sample_step_with_grad
@@ -234,35 +249,54 @@ class VARSampler(nn.Module):
         return {"sample": xn, "logp": logp, "logp_terminal": torch.zeros(len(x), device=x.device), "mean": mean,
                 "sigma": sigma, "entropy": torch.log(sigma), "control": control}
 
-    def sample(self, n_sample, device="cpu", enable_grad=False, noise=None):
-        """T-step generation (reference :411-428 -> VAR_sampling :204-297)."""
+    def sample(self, n_sample, device="cpu", enable_grad=False, noise=None, out=None):
+        """T-step generation (reference :411-428 -> VAR_sampling :204-297).  The whole trajectory lives in ONE block
+        [T+1, B, C, H, W] (+ [T, B, ...] mean / control, [T, B] logp / sigma) that the fused transition kernel writes
+        directly; the returned lists are views of it.  out: a slot of a models.DxMI.replay.TransitionRing — the
+        trajectory is then generated in place in the replay buffer."""
         device = torch.device(device)
         if device.type != "cuda":
             raise DxmiError("VARSampler.sample runs only on the HIP device path (device must be cuda:N)")
         if enable_grad:
             raise NotImplementedError("enable_grad=True (fresh_sample_grad) is not used by the DxMI configs")
-        size = (n_sample, *self.sample_shape)
+        shape = tuple(self.sample_shape)
+        size = (n_sample,) + shape
         T = self.n_timesteps
-        x = torch.randn(size, device=device) if noise is None else noise[0].to(device).float().contiguous()
-        xs, logps, controls, means, sigmas = [x], [], [], [], []
+        if out is None:
+            f32 = dict(dtype=torch.float32, device=device)
+            traj = torch.empty((T + 1,) + size, **f32)
+            mean_b, control_b = torch.empty((T,) + size, **f32), torch.empty((T,) + size, **f32)
+            logp_b, sigma_b = torch.empty((T, n_sample), **f32), torch.empty((T, n_sample), **f32)
+        else:
+            traj, mean_b, control_b, logp_b, sigma_b = (out[k] for k in ("traj", "mean", "control", "logp", "sigma"))
+            assert traj.shape == (T + 1,) + size and traj.device == device, "ring slot does not match this sampler / batch"
+        if noise is None:
+            traj[0].normal_()
+        else:
+            traj[0].copy_(noise[0])
         with torch.no_grad():
             for i in range(T):
                 z = torch.randn(size, device=device) if noise is None else noise[i + 1].to(device).float().contiguous()
-                x, mean, control, logp, sg = self._transition(x, self._t_const(n_sample, i, device), z, assoc=1)
-                xs.append(x)
-                logps.append(logp)
-                controls.append(control)
-                means.append(mean)
-                sigmas.append(sg.view(-1, 1, 1, 1))
-        return {"sample": xs[-1], "l_sample": xs, "logp": logps, "logp_terminal": torch.zeros(n_sample, device=device),
-                "mean": means, "sigma": sigmas, "control": controls}
+                self._transition(traj[i], self._t_const(n_sample, i, device), z, assoc=1,
+                                 outs=(traj[i + 1], mean_b[i], control_b[i], logp_b[i]), sigma_out=sigma_b[i])
+        d = {"sample": traj[T], "l_sample": list(traj.unbind(0)), "logp": list(logp_b.unbind(0)),
+             "logp_terminal": torch.zeros(n_sample, device=device), "mean": list(mean_b.unbind(0)),
+             "sigma": [s_.view(-1, 1, 1, 1) for s_ in sigma_b.unbind(0)], "control": list(control_b.unbind(0))}
+        if out is not None:
+            d["_ring_slot"] = (id(out["ring"]), out["slot"])
+        return d
 
     def log_prob_step(self, x_prev, x_next, t):
-        """log-prob of a stored transition under the fixed-sigma policy (reference :431-444, :189-200)."""
+        """log-prob of a stored transition under the fixed-sigma policy (reference :431-444 -> VAR_log_prob :189-200).
+        As in the reference the network call is NOT detached: under autograd the result back-propagates into the
+        U-Net parameters and x_prev through the HIP backward (unet_small_train.py); x_next is detached."""
+        if not x_prev.is_cuda:
+            raise DxmiError("VARSampler.log_prob_step runs only on the HIP device path")
+        self._check_t(t)
         t = process_single_t(x_prev, t)
-        tau = self.diffusion_steps_list[t]
-        with torch.no_grad():
-            eps = self.net(x_prev.contiguous().float(), tau)
+        if t.numel() and (int(t.max()) >= self.n_timesteps or int(t.min()) < -self.n_timesteps):   # torch gather below: no silent wrap
+            raise IndexError("timestep out of range")
+        eps = self.net(x_prev.contiguous().float(), self.diffusion_steps_list[t])
         mean = x_prev * self.x_prev_multiplier[t][:, None, None, None] + self.theta_multiplier[t][:, None, None, None] * eps
         sigma = self.std[t][:, None, None, None]
         lp = -((x_next.detach() - mean) ** 2) / (2 * sigma ** 2) - torch.log(sigma) - math.log(math.sqrt(2 * math.pi))

@@ -272,6 +272,56 @@ int dxmi_nchw_f32_to_nhwc_bf16(const float* in, void* out, int32_t N, int32_t C,
 int dxmi_nhwc_bf16_to_nchw_f32(const void* in, float* out, int32_t N, int32_t C, int32_t HW,
                                void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Train-step tail: multi-tensor optimiser steps, gradient-norm clip, dropout, replay-buffer gathers.
+ * Tensor lists are HOST arrays of device pointers / element counts (any length; the library cuts them into
+ * launches of DXMI_MT_MAX tensors passed by value in the kernel arguments — no descriptor upload).
+ * ---------------------------------------------------------------------------------------- */
+#define DXMI_MT_MAX 64
+
+/* Workgroups one multi-tensor launch series uses over `numel[0..count)` (= fp32 partials dxmi_gradnorm_clip needs). */
+int64_t dxmi_mt_blocks(const int64_t* numel, int32_t count);
+
+/* torch.optim.Adam.step() over fp32 tensors (models/DxMI/trainer.py:264, :325, :389 with the optimisers of
+ * train_cifar10.py:283-296), the arithmetic of torch's _multi_tensor_adam (no amsgrad / weight decay), every
+ * intermediate rounded to fp32 where the foreach implementation stores one:
+ *   m = m + (1-b1)(g - m);  v = v*b2 + (1-b2) g*g;  p = p + step_size[i] * m / (sqrt(v)/bc2_sqrt + eps)
+ * step_size[i] = -(lr_i / (1 - b1^t)) and bc2_sqrt = sqrt(1 - b2^t) are formed by the caller in double, as torch does;
+ * scalar hyper-parameters cross the ABI as double and are rounded to fp32 once (ATen's Scalar -> float conversion).
+ * grad_scale: optional DEVICE scalar multiplied into every gradient first (the clip coefficient of
+ * dxmi_gradnorm_clip: clip-then-step without a host round trip); write_back_grad also stores the scaled gradient. */
+int dxmi_adam_step(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                   const int64_t* numel, const float* step_size, int32_t count, double beta1, double beta2,
+                   double eps, double bc2_sqrt, const float* grad_scale, int32_t write_back_grad, void* stream);
+
+/* torch.optim.RAdam.step() (MixedPrecisionTrainer.optimize, models/cm/fp16_util.py:204-223; optimiser built at
+ * train_image_large.py:153-160), arithmetic of torch/optim/radam.py _single_tensor_radam:
+ *   p -= ((m/bc1) * lr_i) * (bc2_sqrt / (sqrt(v) + eps)) * rect      (rect < 0: p -= (m/bc1) * lr_i, rho_t <= 5)
+ * grad_scale: optional DEVICE scalar (1 / 2^lg_loss_scale); found_inf: optional DEVICE flag, non-zero skips the whole
+ * step on the device (the overflow test of fp16_util.py:208-212 without a host sync in front of the kernels). */
+int dxmi_radam_step(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                    const int64_t* numel, const float* lr, int32_t count, double beta1, double beta2, double eps,
+                    double bc1, double bc2_sqrt, double rect, const float* grad_scale, const float* found_inf,
+                    void* stream);
+
+/* torch.nn.utils.clip_grad_norm_(params, max_norm) (trainer.py:388, :666-667; also MixedPrecisionTrainer._compute_norms
+ * fp16_util.py:232-240 with max_norm <= 0 = "norm only"): out3[0] = global L2 norm, out3[1] = min(1, max_norm/(norm+1e-6)),
+ * out3[2] = 1 if the norm is inf/nan.  Fixed-order reductions (reproducible).  partials: >= dxmi_mt_blocks() floats.
+ * scale_in_place: multiply the gradients by out3[1] (otherwise hand out3+1 to dxmi_adam_step as grad_scale). */
+int dxmi_gradnorm_clip(void* const* grads, const int64_t* numel, int32_t count, float max_norm, float* partials,
+                       float* out3, int32_t scale_in_place, void* stream);
+
+/* nn.Dropout(p) of ResnetBlock (models/DxMI/unet_small.py:129), NHWC bf16: y[i] = keep(i) ? bf16(x[i]/(1-p)) : 0 with
+ * keep(i) = (mix32(i ^ seed) >> 8) >= p*2^24, mix32 = the 32-bit finaliser x^=x>>16; x*=0x7feb352d; x^=x>>15;
+ * x*=0x846ca68b; x^=x>>16.  The backward pass calls it again on the gradient with the same seed (no stored mask). */
+int dxmi_dropout_bf16(const void* x, void* y, int64_t n, float p, uint32_t seed, void* stream);
+
+/* Replay-buffer row gather (INT path; trainer.py:278-289 `state_dict[key][indices][train_indices]`, :357-359):
+ * dst[r] = src[idx[r]], rows of row_bytes (multiple of 4), idx int64 on the device, negative indices wrap; an index
+ * outside [-n_src_rows, n_src_rows) fills the row with 0xFF bytes instead of reading out of bounds. */
+int dxmi_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t n_rows, int64_t n_src_rows,
+                     int64_t row_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,11 @@ value_resample): append_buffer :23-55, update_adaptive_vel_reg :218-228, get_run
 models/diffusion.py:18-22 (extract), update_f_v :230-346, update_sampler :348-408 — over the oracle's
 functional networks with torch autograd and torch.optim.Adam, keeping the reference's literal index
 expressions (`buf[key][indices][train_indices]`) so the integer path is the reference's own.
+`value_resample=True` (configs/cifar10/T4_ddgan.yaml:39) re-draws every TD step's transition with
+`sample_step` (trainer.py:281-285); its `randn_like` comes from torch's CPU generator at the point the
+reference draws it (after that step's gather, before the value forwards).
+`record` (optional dict) receives the gradients the parity tests compare: the value net's at every
+optimizer_v step, the U-Net's (clipped) after the policy step.
 """
 import torch
 import torch.nn.functional as F
@@ -17,7 +22,7 @@ from .precision import Precision
 
 class OracleDxMI:
     def __init__(self, net_sd, value_sd, sched, B, T, prec=None, tau1=0.1, tau2=0.01, gamma=1.0, adavelreg=0.99,
-                 time_cost=0, time_cost_sig=1.0, lr=1e-7, beta_lr=1e-5, v_lr=1e-5, eta=None):
+                 time_cost=0, time_cost_sig=1.0, lr=1e-7, beta_lr=1e-5, v_lr=1e-5, eta=None, value_resample=False, record=None):
         self.prec = prec or Precision("fp32")
         self.B, self.T = B, T
         self.cfg = ounet.UNetSmallConfig()
@@ -26,6 +31,7 @@ class OracleDxMI:
         self.sched = sched
         self.tau1, self.tau2, self.gamma, self.adavelreg = tau1, tau2, gamma, adavelreg
         self.time_cost, self.time_cost_sig = time_cost, time_cost_sig
+        self.value_resample, self.record = value_resample, record
         not_beta = [v for k, v in self.net.items() if k not in ("log_betas", "std")]
         self.opt = torch.optim.Adam([{"params": [self.net["log_betas"]], "lr": beta_lr}, {"params": not_beta, "lr": lr}])
         self.opt_v = torch.optim.Adam(list(self.val.values()), lr=v_lr)
@@ -78,6 +84,7 @@ class OracleDxMI:
         reg = pos_e.pow(2).mean() + neg_e.pow(2).mean()
         d_loss = pos_e.mean() - neg_e.mean() + self.gamma * reg
         d_loss.backward()
+        self._rec_v()
         self.opt_v.step()
         self.opt_v.zero_grad()
         d_rc, d_val = {}, {}
@@ -89,7 +96,12 @@ class OracleDxMI:
             train_indices = torch.nonzero(buf["timestep"][indices] == update_t).flatten()
             state = buf["state"][indices][train_indices]
             timestep = buf["timestep"][indices][train_indices]
-            next_state = buf["next_state"][indices][train_indices]
+            if self.value_resample:
+                with torch.no_grad():
+                    next_state = ovs.sample_step(self.unet, self.sched, self.net["log_betas"].detach(), state, timestep,
+                                                 torch.randn_like(state))["sample"]
+            else:
+                next_state = buf["next_state"][indices][train_indices]
             rc = self.running_cost(state, next_state, timestep)
             with torch.no_grad():
                 target = self.v(next_state).squeeze()
@@ -99,6 +111,7 @@ class OracleDxMI:
             v_xt = self.v(state).squeeze()
             v_loss = F.mse_loss(v_xt, target.detach())
             v_loss.backward()
+            self._rec_v()
             self.opt_v.step()
             self.opt_v.zero_grad()
             d_rc[f"running_cost/step_{update_t}_"] = rc.mean().item()
@@ -110,6 +123,10 @@ class OracleDxMI:
         for t, b in enumerate(self.betas_for_q):
             logs[f"adavelreg/beta{t}_"] = b.item()
         return logs
+
+    def _rec_v(self):
+        if self.record is not None:
+            self.record.setdefault("value_grads", []).append({k: p.grad.detach().clone() for k, p in self.val.items()})
 
     # ---- trainer.py:171-216
     def sample_guidance(self, x0, noises, guidance_scale):
@@ -143,6 +160,8 @@ class OracleDxMI:
         for p in self.val.values():   # value grads are discarded by the next zero_grad (trainer.py:235)
             p.grad = None
         torch.nn.utils.clip_grad_norm_([p for k, p in self.net.items() if p.requires_grad], 0.1)
+        if self.record is not None:
+            self.record["net_grads"] = {k: p.grad.detach().clone() for k, p in self.net.items() if p.grad is not None}
         self.opt.step()
         logs = {"sampler/sampler_loss_": loss.item(), "sampler/sampler_value_loss_": sv.mean().item(),
                 "sampler/running_cost_": rc.mean().item(), "sampler/causal_entropy_": ent.mean().item()}

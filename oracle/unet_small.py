@@ -7,7 +7,10 @@ Restates models/DxMI/unet_small.py (reference root) over a flat state dict `sd`
   Downsample          :69-76                 Upsample            :50-54
   Model.forward       :292-332
 `prec` (oracle.Precision) chooses reference fp32 arithmetic or the bf16 storage model of the HIP
-pipeline.  `dropout_masks` is unused: parity fixtures run the net in eval mode / dropout 0.
+pipeline.  Dropout (nn.Dropout(p) between norm2+swish and conv2, unet_small.py:129): torch's device RNG is
+not reproducible across devices, so train-mode parity INJECTS the masks: `dropout_masks` maps a block prefix to
+a [B,C,H,W] keep-mask (0/1) and `dropout_p` scales kept values by 1/(1-p).  `dropout_keep_mask` restates the
+HIP kernel's counter hash (include/dxmi_hip.h, dxmi_dropout_bf16) in numpy integer arithmetic (bit-exact).
 """
 import math
 
@@ -42,6 +45,22 @@ def swish(x):
     return x * torch.sigmoid(x)
 
 
+def dropout_keep_mask(shape_nchw, p, seed):
+    """keep(i) = (mix32(i ^ seed) >> 8) >= p * 2^24 over the NHWC linear index i of the activation (the HIP pipeline's
+    layout), returned as a float [B,C,H,W] 0/1 tensor."""
+    import numpy as np
+    B, C, H, W = shape_nchw
+    h = np.arange(B * H * W * C, dtype=np.uint64) ^ np.uint64(seed & 0xFFFFFFFF)
+    m = np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x7feb352d)) & m
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x846ca68b)) & m
+    h ^= h >> np.uint64(16)
+    keep = (h >> np.uint64(8)) >= np.uint64(int(float(p) * 16777216.0))
+    return torch.from_numpy(keep.reshape(B, H, W, C).astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+
+
 def _conv(sd, name, x, prec, stride=1, padding=0):
     return F.conv2d(x, prec.w(sd[name + ".weight"]), sd[name + ".bias"], stride=stride, padding=padding)
 
@@ -50,7 +69,7 @@ def _gn(sd, name, x, eps=1e-6):
     return F.group_norm(x, 32, sd[name + ".weight"], sd[name + ".bias"], eps)
 
 
-def resnet_block(sd, pre, x, s_temb, cin, cout, prec):
+def resnet_block(sd, pre, x, s_temb, cin, cout, prec, keep=None, p_drop=0.0):
     """unet_small.py:117-136.  `s_temb` = swish(temb) (shared by all blocks).  x is a stored
     activation (already prec.act-rounded)."""
     h = prec.act(swish(_gn(sd, pre + ".norm1", x)))
@@ -58,6 +77,8 @@ def resnet_block(sd, pre, x, s_temb, cin, cout, prec):
     tproj = F.linear(prec.act(s_temb), prec.w(sd[pre + ".temb_proj.weight"]), sd[pre + ".temb_proj.bias"])
     h = prec.act(h + tproj[:, :, None, None])
     h = prec.act(swish(_gn(sd, pre + ".norm2", h)))
+    if keep is not None:
+        h = prec.act(h * (keep * (1.0 / (1.0 - p_drop))))
     h = _conv(sd, pre + ".conv2", h, prec, padding=1)
     if cin != cout:
         x = prec.act(_conv(sd, pre + ".nin_shortcut", x, prec))
@@ -85,11 +106,13 @@ def attn_block(sd, pre, x, prec):
     return prec.act(x + h_)
 
 
-def forward(sd, cfg, x, t, prec=None, trace=None):
+def forward(sd, cfg, x, t, prec=None, trace=None, dropout_masks=None, dropout_p=0.0):
     """Model.forward, unet_small.py:292-332.  x [B,C,H,W] fp32, t [B] float.
     trace: optional list that receives (name, NCHW tensor) after every block (debugging aid)."""
     tr = (lambda n, v: trace.append((n, v.clone()))) if trace is not None else (lambda n, v: None)
     prec = prec or Precision("fp32")
+    dm = dropout_masks or {}
+    rb = lambda pre, xx, cin, cout: resnet_block(sd, pre, xx, s_temb, cin, cout, prec, dm.get(pre), dropout_p)
     assert x.shape[2] == x.shape[3] == cfg.resolution
     nres = len(cfg.ch_mult)
     in_ch_mult = (1,) + cfg.ch_mult
@@ -108,7 +131,7 @@ def forward(sd, cfg, x, t, prec=None, trace=None):
         block_in = cfg.ch * in_ch_mult[i_level]
         block_out = cfg.ch * cfg.ch_mult[i_level]
         for i_block in range(cfg.num_res_blocks):
-            h = resnet_block(sd, f"down.{i_level}.block.{i_block}", hs[-1], s_temb, block_in, block_out, prec)
+            h = rb(f"down.{i_level}.block.{i_block}", hs[-1], block_in, block_out)
             tr(f"down.{i_level}.block.{i_block}", h)
             block_in = block_out
             if curr_res in cfg.attn_resolutions:
@@ -123,11 +146,11 @@ def forward(sd, cfg, x, t, prec=None, trace=None):
             curr_res //= 2
 
     h = hs[-1]
-    h = resnet_block(sd, "mid.block_1", h, s_temb, block_in, block_in, prec)
+    h = rb("mid.block_1", h, block_in, block_in)
     tr("mid.block_1", h)
     h = attn_block(sd, "mid.attn_1", h, prec)
     tr("mid.attn_1", h)
-    h = resnet_block(sd, "mid.block_2", h, s_temb, block_in, block_in, prec)
+    h = rb("mid.block_2", h, block_in, block_in)
     tr("mid.block_2", h)
 
     for i_level in reversed(range(nres)):
@@ -136,8 +159,7 @@ def forward(sd, cfg, x, t, prec=None, trace=None):
         for i_block in range(cfg.num_res_blocks + 1):
             if i_block == cfg.num_res_blocks:
                 skip_in = cfg.ch * in_ch_mult[i_level]
-            h = resnet_block(sd, f"up.{i_level}.block.{i_block}", torch.cat([h, hs.pop()], dim=1), s_temb,
-                             block_in + skip_in, block_out, prec)
+            h = rb(f"up.{i_level}.block.{i_block}", torch.cat([h, hs.pop()], dim=1), block_in + skip_in, block_out)
             tr(f"up.{i_level}.block.{i_block}", h)
             block_in = block_out
             if curr_res in cfg.attn_resolutions:

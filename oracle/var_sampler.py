@@ -105,3 +105,13 @@ def sample_step(net_fn, sched, log_betas, x, t, z, trainable_beta="fix_last", ad
     return {"sample": xn, "logp": gaussian_logp_mean(xn.detach(), mean, sigma),
             "logp_terminal": torch.zeros(len(x)), "mean": mean, "sigma": sigma,
             "entropy": torch.log(sigma), "control": control}
+
+
+def log_prob_step(net_fn, sched, x_prev, x_next, t):
+    """VARSampler.log_prob_step -> VAR_log_prob, var_sampler.py:431-444, :189-200: log N(x_next; mean_t(x_prev), std_t)
+    averaged over (C,H,W) under the FIXED schedule (std table with its last entry 1e-3, tau from diffusion_steps_list =
+    continuous_steps); differentiable through net_fn, x_next detached."""
+    x_mult_tab, c_tab = sched["x_prev_multiplier"], sched["theta_multiplier"]     # VAR_get_params tables (:146-186)
+    eps = net_fn(x_prev, sched["continuous_steps"][t])
+    mean = x_prev * x_mult_tab[t][:, None, None, None] + c_tab[t][:, None, None, None] * eps
+    return gaussian_logp_mean(x_next.detach(), mean, sched["std"][t][:, None, None, None])

@@ -153,12 +153,27 @@ def gen_value():
         save("value_forward_64", x=x64, out=v(x64, None))
 
 
-def gen_trainer_step():
-    """One full DxMI_Trainer step (sample -> append_buffer -> update_f_v -> update_sampler), B=4, T=10,
-    dropout 0 (parity fixtures run without dropout: SURVEY 7 RNG parity), CPU generator seeded so the
-    INT path (randperm, gathers) is reproducible."""
+# parameter tensors whose clipped gradient / update the trainer fixtures record (spread over the net's depth); big conv
+# weights are sliced to their first output channels to keep the fixtures small
+NET_PICK = [("conv_in.weight", None), ("down.0.block.0.conv1.weight", 8), ("down.1.attn.0.q.weight", 16),
+            ("down.2.block.1.conv2.weight", 8), ("mid.attn_1.proj_out.weight", 16), ("mid.block_2.temb_proj.weight", 16),
+            ("up.2.block.2.conv1.weight", 8), ("up.1.attn.1.v.weight", 16), ("up.0.block.0.nin_shortcut.weight", 16),
+            ("temb.dense.0.weight", 32), ("norm_out.weight", None), ("conv_out.weight", None), ("conv_out.bias", None)]
+VAL_PICK = [("net.conv1.weight", None), ("net.blocks.0.conv2.weight", 8), ("net.blocks.2.skip.0.weight", 16),
+            ("net.blocks.5.conv1.weight", 8), ("net.linear.weight", None), ("net.out_scale.weight", None)]
+
+
+def _cut(t, n):
+    return t.detach().clone() if n is None else t.detach()[:n].clone()
+
+
+def _trainer_step(name, T, B, seed, img_seed, **trainer_kw):
+    """One full reference DxMI_Trainer step (sample -> append_buffer -> update_f_v -> update_sampler), dropout 0
+    (parity fixtures run without dropout: SURVEY 7 RNG parity), CPU generator seeded so the INT path (randperm,
+    gathers) and the in-step randn draws are reproducible.  Besides the logs it records, for a spread of tensors:
+    the value net's gradients at the energy step and at the last TD step (captured by wrapping optimizer_v.step),
+    the U-Net's clipped gradients of the policy step (p.grad as update_sampler leaves it) and the parameter updates."""
     import models.DxMI.trainer as ref_tr
-    B, T = 4, 10
     torch.manual_seed(0)
     kw = dict(UNET_KW)
     kw["dropout"] = 0.0
@@ -169,29 +184,100 @@ def gen_trainer_step():
     params_not_beta = [p for n, p in net.named_parameters() if "log_betas" not in n]
     opt = torch.optim.Adam([{"params": net.log_betas, "lr": 1e-5}, {"params": params_not_beta, "lr": 1e-7}])
     opt_v = torch.optim.Adam(v.parameters(), lr=1e-5)
-    trainer = ref_tr.DxMI_Trainer(batchsize=B, tau1=0.1, tau2=0.01, gamma=1, use_sampler_beta=True, time_cost=0,
-                                  adavelreg=0.99, entropy_in_value=None, velocity_in_value=None, time_cost_sig=True,
-                                  n_timesteps=T)
+    vgrads = []
+    vnamed = dict(v.named_parameters())
+    orig_step = opt_v.step
+
+    def step_and_record(*a, **k):
+        vgrads.append({n: _cut(vnamed[n].grad, c) for n, c in VAL_PICK})
+        return orig_step(*a, **k)
+    opt_v.step = step_and_record
+    trainer = ref_tr.DxMI_Trainer(batchsize=B, n_timesteps=T, **trainer_kw)
     trainer.set_models(f=None, v=v, sampler=sampler, optimizer=opt, optimizer_fstar=None, optimizer_v=opt_v)
-    g = torch.Generator().manual_seed(555)
+    g = torch.Generator().manual_seed(img_seed)
     img = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
-    seed = 2468
     torch.manual_seed(seed)
     sampler.eval()
     d_sample = sampler.sample(B, device="cpu")
     buf = ref_tr.append_buffer(ref_tr.reset_buffer("cpu"), d_sample)
+    w0 = {n: p.detach().clone() for n, p in net.named_parameters()}
+    v0 = {n: p.detach().clone() for n, p in v.named_parameters()}
     d_energy = trainer.update_f_v(img, d_sample, buf)
     d_sampler = trainer.update_sampler(buf, 1)
+    assert len(vgrads) == T + 1
     vsd = v.state_dict()
     nsd = net.state_dict()
-    save("trainer_step", seed=seed, B=B, T=T, img=img,
+    named = dict(net.named_parameters())
+    extra = {}
+    for i, (n, c) in enumerate(NET_PICK):
+        extra[f"net_grad_{i}"] = _cut(named[n].grad, c)
+        extra[f"net_delta_{i}"] = _cut(named[n].detach() - w0[n], c)
+    for i, (n, c) in enumerate(VAL_PICK):
+        extra[f"val_grad_energy_{i}"] = vgrads[0][n]
+        extra[f"val_grad_lasttd_{i}"] = vgrads[-1][n]
+        extra[f"val_delta_{i}"] = _cut(vnamed[n].detach() - v0[n], c)
+    extra["log_betas_grad"] = named["log_betas"].grad.detach().clone()
+    save(name, seed=seed, B=B, T=T, img=img,
          energy_keys=np.array(list(d_energy.keys())), energy_vals=np.array(list(d_energy.values()), dtype=np.float64),
          sampler_keys=np.array(list(d_sampler.keys())), sampler_vals=np.array(list(d_sampler.values()), dtype=np.float64),
          betas_for_q=trainer.betas_for_q, buffer_timestep=buf["timestep"], buffer_state_sum=buf["state"].double().sum(),
          buffer_shapes=np.array([list(buf[k].shape) + [0] * (4 - buf[k].dim()) for k in ("state", "next_state", "mean", "sigma", "logp", "control")]),
          value_conv1_w_delta=(vsd["net.conv1.weight"] - formula_state_dict({"net.conv1.weight": vsd["net.conv1.weight"]})["net.conv1.weight"]),
          value_linear_w=vsd["net.linear.weight"], log_betas_after=nsd["log_betas"],
-         net_conv_out_w_delta=(nsd["conv_out.weight"] - formula_state_dict({"conv_out.weight": nsd["conv_out.weight"]})["conv_out.weight"]))
+         net_conv_out_w_delta=(nsd["conv_out.weight"] - formula_state_dict({"conv_out.weight": nsd["conv_out.weight"]})["conv_out.weight"]),
+         net_pick=np.array([n for n, _ in NET_PICK]), net_pick_rows=np.array([-1 if c is None else c for _, c in NET_PICK]),
+         val_pick=np.array([n for n, _ in VAL_PICK]), val_pick_rows=np.array([-1 if c is None else c for _, c in VAL_PICK]),
+         **extra)
+
+
+def gen_trainer_step():
+    """configs/cifar10/T10.yaml trainer block at B=4, T=10."""
+    _trainer_step("trainer_step", 10, 4, 2468, 555, tau1=0.1, tau2=0.01, gamma=1, use_sampler_beta=True, time_cost=0,
+                  adavelreg=0.99, entropy_in_value=None, velocity_in_value=None, time_cost_sig=True)
+
+
+def gen_trainer_step_T4_resample():
+    """configs/cifar10/T4_ddgan.yaml trainer block (value_resample: True -> sample_step inside the TD loop,
+    trainer.py:281-285) on the DDPM backbone (models.ddgan is absent from the snapshot), B=4, T=4."""
+    _trainer_step("trainer_step_T4_resample", 4, 4, 1357, 556, tau1=0.1, tau2=0.01, gamma=1, use_sampler_beta=True,
+                  time_cost=0, time_cost_sig=1, entropy_in_value=None, velocity_in_value=None, value_resample=True,
+                  adavelreg=0.99)
+
+
+def gen_log_prob_step():
+    """VARSampler.log_prob_step (var_sampler.py:431-444 -> VAR_log_prob :189-200): the reference differentiates through
+    the net here, so the fixture carries the gradient of sum(log_prob) w.r.t. x_prev and a few parameters too."""
+    net, s = build_sampler(10)
+    g = torch.Generator().manual_seed(78)
+    x_prev = torch.randn(6, 3, 32, 32, generator=g).requires_grad_(True)
+    x_next = x_prev.detach() * 0.9 + 0.3 * torch.randn(6, 3, 32, 32, generator=g)
+    t = torch.tensor([0, 9, 3, 3, 7, 1])
+    lp = s.log_prob_step(x_prev, x_next, t)
+    lp.sum().backward()
+    named = dict(net.named_parameters())
+    pick = [("conv_out.weight", None), ("mid.block_1.conv1.weight", 8), ("down.0.block.0.norm1.weight", None), ("conv_in.weight", None)]
+    save("log_prob_step_T10", x_prev=x_prev.detach(), x_next=x_next, t=t, log_prob=lp.detach(), grad_x_prev=x_prev.grad,
+         grad_keys=np.array([n for n, _ in pick]), grad_rows=np.array([-1 if c is None else c for _, c in pick]),
+         **{f"grad_{i}": _cut(named[n].grad, c) for i, (n, c) in enumerate(pick)})
+
+
+def gen_output_stage():
+    """Output stage.  The two quantisers of the reference's generate scripts, evaluated with torch on
+    the CPU exactly as written there:
+      * generate_cifar10.py:205-207 / generate_large.py:36-39: rescale -> clamp(0,1) -> torchvision.utils.save_image.
+        torchvision is NOT installed here (and the reference pins no version); save_image's published quantiser is
+        `grid.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8)` (torchvision/utils.py,
+        unchanged since 0.4) and is restated in that form - marked `png_restated` in the fixture.
+      * generate_large.py:43: ((sample + 1) * 127.5).clamp(0, 255).to(torch.uint8) (the FID / samples_N.npz path).
+    Inputs include exact half-way and out-of-range values."""
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(6, 3, 8, 8, generator=g) * 0.8
+    x[0, 0, 0, :8] = torch.tensor([-1.0, 1.0, -1.5, 1.5, 0.0, 1.0 / 255 - 1, 0.5 / 127.5 - 1, 2 * 0.5 / 255 - 1])
+    rescale = lambda t: (t + 1) / 2                                        # generate_cifar10.py: rescale = lambda x: (x + 1) / 2
+    s01 = rescale(x).clamp(0, 1)
+    png = torch.stack([s.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8) for s in s01])
+    fid = ((x + 1) * 127.5).clamp(0, 255).to(torch.uint8)
+    save("output_stage", x=x, png_restated_hwc=png, fid_uint8_nchw=fid)
 
 
 def gen_guidance():
@@ -327,7 +413,7 @@ def gen_edm_trainer():
 
 
 GENS = {"schedule": gen_schedule, "unet": gen_unet_forward, "var_sampling": gen_var_sampling,
-        "sample_step": gen_sample_step, "value": gen_value, "trainer": gen_trainer_step, "guidance": gen_guidance, "edm": gen_edm, "edm_trainer": gen_edm_trainer}
+        "sample_step": gen_sample_step, "value": gen_value, "trainer": gen_trainer_step, "trainer_T4": gen_trainer_step_T4_resample, "log_prob": gen_log_prob_step, "output": gen_output_stage, "guidance": gen_guidance, "edm": gen_edm, "edm_trainer": gen_edm_trainer}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

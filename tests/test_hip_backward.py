@@ -260,3 +260,86 @@ def test_unet_backward_vs_oracle(golden_dir):
         assert r < 2.0 * fl + 1e-2, (k, r, fl)
         worst = max(worst, r)
     assert all(p.grad is not None for n, p in net.named_parameters() if n != "log_betas")
+
+
+def _resblock_call_order():
+    """(prefix, Cout, resolution) of the 22 ResnetBlocks in forward call order (configs/cifar10/T10.yaml net)."""
+    out = []
+    res, ch = 32, (128, 256, 256, 256)
+    for lvl in range(4):
+        out += [(f"down.{lvl}.block.{b}", ch[lvl], res) for b in range(2)]
+        if lvl != 3:
+            res //= 2
+    out += [("mid.block_1", 256, res), ("mid.block_2", 256, res)]
+    for lvl in (3, 2, 1, 0):
+        out += [(f"up.{lvl}.block.{b}", ch[lvl], res) for b in range(3)]
+        if lvl != 0:
+            res *= 2
+    return out
+
+
+def test_dropout_kernel_matches_hash_restatement(ops):
+    """INT path: the kept set of dxmi_dropout_bf16 is bit-identical to the oracle's numpy restatement of the counter
+    hash; kept values are bf16(x / (1-p)); the same seed on a second tensor (the backward) reuses the mask."""
+    from oracle.unet_small import dropout_keep_mask
+    g = torch.Generator().manual_seed(4)
+    x = bf(torch.randn(3, 64, 8, 8, generator=g))
+    for p, seed in ((0.1, 12345), (0.5, 0xDEADBEEF), (0.0, 7)):
+        keep = dropout_keep_mask(x.shape, p, seed)
+        y = nchw(ops.dropout(nhwc(x), p, seed))
+        ref = bf(x * (1.0 / (1.0 - p))) * keep
+        assert torch.equal(y, ref), (p, seed)
+        assert abs(keep.mean().item() - (1 - p)) < 0.02
+        y2 = nchw(ops.dropout(nhwc(x * 2), p, seed))
+        assert torch.equal(y2 != 0, (keep != 0) & (x != 0))
+
+
+def test_unet_backward_train_mode_dropout_vs_oracle():
+    """update_sampler runs the U-Net in train mode (trainer.py:352: dropout 0.1 live).  The masks the HIP kernels draw
+    (one hash seed per ResnetBlock) are rebuilt by the oracle's restatement of the hash and INJECTED into torch autograd
+    through the pinned oracle: forward and parameter gradients must agree to the bf16 noise floor."""
+    from models.DxMI.unet_small import Model
+    from oracle import Precision
+    from oracle import unet_small as ounet
+    from oracle.weights import formula_tensor
+    net = Model(ch=128, out_ch=3, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=[16], dropout=0.1,
+                in_channels=3, resolution=32)
+    sd = {k: formula_tensor(k, v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    net = net.to(DEV).train()
+    net.dropout_seed = 20240607
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    x = torch.randn(B, 3, 32, 32, generator=g)
+    t = torch.tensor([394.076477, 66.8653336])
+    w_out = torch.randn(B, 3, 32, 32, generator=g)
+    y = net(x.to(DEV), t.to(DEV))
+    (y * w_out.to(DEV)).sum().backward()
+    order = _resblock_call_order()
+    seeds = list(net.dropout_seeds_used)
+    assert len(seeds) == len(order) == 22 and len(set(seeds)) == 22
+    masks = {pre: ounet.dropout_keep_mask((B, c, r, r), 0.1, s) for (pre, c, r), s in zip(order, seeds)}
+    cfg = ounet.UNetSmallConfig()
+    names = ["conv_in.weight", "down.0.block.0.conv2.weight", "down.0.block.0.norm2.weight", "down.1.attn.0.q.weight",
+             "mid.block_1.conv2.weight", "up.1.block.2.nin_shortcut.weight", "up.0.block.2.conv1.weight", "conv_out.weight",
+             "temb.dense.0.weight"]
+    ref, yo = {}, {}
+    for mode in ("fp32", "bf16"):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        yo[mode] = ounet.forward(leaves, cfg, x, t, Precision(mode), dropout_masks=masks, dropout_p=0.1)
+        (yo[mode] * w_out).sum().backward()
+        ref[mode] = {k: leaves[k].grad for k in names}
+    # forward: with the right masks the train-mode output sits at the bf16 floor; with no masks it does not
+    r_fwd = rel_l2(y.detach().cpu(), yo["fp32"].detach())
+    with torch.no_grad():
+        y_nomask = ounet.forward(sd, cfg, x, t)
+    assert r_fwd < 1.5e-2 and rel_l2(y.detach().cpu(), y_nomask) > 5 * r_fwd, (r_fwd, rel_l2(y.detach().cpu(), y_nomask))
+    P = dict(net.named_parameters())
+    for k in names:
+        r = rel_l2(P[k].grad.cpu(), ref["fp32"][k])
+        fl = rel_l2(ref["bf16"][k], ref["fp32"][k])
+        print(f"  dropout {k}: HIP vs oracle fp32 {r:.2e}   (oracle bf16-model vs fp32 {fl:.2e})")
+        assert r < 2.0 * fl + 1e-2, (k, r, fl)
+    # a second forward draws fresh seeds; eval mode draws none
+    net(x.to(DEV), t.to(DEV))
+    assert set(net.dropout_seeds_used).isdisjoint(seeds)

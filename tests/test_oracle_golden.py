@@ -161,3 +161,27 @@ def test_value_forward_and_grads_match_reference(golden_dir):
     with torch.no_grad():
         out64 = ovalue.forward(sd, torch.from_numpy(g64["x"]))
     np.testing.assert_allclose(out64.numpy(), g64["out"], rtol=2e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------- log_prob_step (a4)
+def test_log_prob_step_matches_reference(golden_dir):
+    """VARSampler.log_prob_step (var_sampler.py:431-444): value, and the gradient THROUGH the net that the reference's
+    un-detached call builds (w.r.t. x_prev and a spread of parameters)."""
+    torch.set_num_threads(8)
+    g = load(golden_dir, "log_prob_step_T10")
+    keys = load(golden_dir, "schedule")["T10_state_dict_keys"]
+    sd = {k: v.clone().requires_grad_(k not in ("std", "log_betas")) for k, v in unet_state_dict(keys, 10).items()}
+    s = osched.var_schedule(10)
+    sched = {k: torch.from_numpy(v) for k, v in s.items() if k != "user_defined_eta"}
+    x_prev = torch.from_numpy(g["x_prev"]).requires_grad_(True)
+    lp = ovs.log_prob_step(lambda x, t: ounet.forward(sd, ounet.UNetSmallConfig(), x, t), sched, x_prev,
+                           torch.from_numpy(g["x_next"]), torch.from_numpy(g["t"]))
+    np.testing.assert_allclose(lp.detach().numpy(), g["log_prob"], rtol=2e-5)
+    lp.sum().backward()
+    ref = g["grad_x_prev"]
+    assert np.linalg.norm(x_prev.grad.numpy() - ref) <= 2e-4 * np.linalg.norm(ref)
+    for i, (k, rows) in enumerate(zip(g["grad_keys"], g["grad_rows"])):
+        got = sd[str(k)].grad.numpy()
+        got = got if rows < 0 else got[:rows]
+        ref = g[f"grad_{i}"]
+        assert np.linalg.norm(got - ref) <= 3e-4 * np.linalg.norm(ref), k
