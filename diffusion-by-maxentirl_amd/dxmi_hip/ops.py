@@ -113,21 +113,30 @@ def conv2d(x, pw, *, in1=None, bias=None, addvec=None, residual=None, stride=1, 
         assert mask_src.dtype == torch.bfloat16 and mask_src.is_contiguous() and tuple(mask_src.shape) == (N, OH, OW, Cout)
     d.mask_src = mask_src.data_ptr() if mask_src is not None else None
     d.mask_slope = float(mask_slope)
-    if CONV_PROFILER is not None:
-        CONV_PROFILER.launch(d)
+    if PROFILER is not None:
+        PROFILER.launch_conv(d)
     else:
         check(load().dxmi_conv2d_fwd(ctypes.byref(d), _stream()), "dxmi_conv2d_fwd")
     return out
 
 
-class ConvProfiler:
-    """Brackets every conv launch with HIP events on the launch stream (bench.py roofline leg):
-    records (kernel_id, algorithmic FLOPs, algorithmic bytes, start, end)."""
+class OpProfiler:
+    """Brackets kernel launches with HIP events on the launch stream (bench.py roofline leg) and records, per launch,
+    (class, kernel name, algorithmic FLOPs, algorithmic bytes, start, end).  Classes: "conv3x3" / "conv1x1" / "conv_stem" /
+    "conv_other" (by dxmi_conv2d_kernel_id), "groupnorm", "attention", "sampler_step", "wgrad", "groupnorm_bwd", "optimizer"."""
 
     def __init__(self):
         self.records = []
 
-    def launch(self, d):
+    def bracket(self, cls, name, flops, nbytes, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.records.append((cls, name, float(flops), float(nbytes), e0, e1))
+        return out
+
+    def launch_conv(self, d):
         lib = load()
         kid = lib.dxmi_conv2d_kernel_id(ctypes.byref(d))
         cin = 27 if d.in_mode == IN_NCHW_F32_K27 else (d.C0 + d.C1) * d.ksize * d.ksize
@@ -136,17 +145,15 @@ class ConvProfiler:
         out_b = d.N * d.OH * d.OW * d.Cout * (4 if d.out_mode == OUT_NCHW_F32 else 2)
         res_b = out_b if d.residual else 0
         w_b = d.Cout * cin * 2
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib.dxmi_conv2d_fwd(ctypes.byref(d), _stream()), "dxmi_conv2d_fwd")
-        e1.record()
-        self.records.append((kid, flops, float(in_b + out_b + res_b + w_b), e0, e1))
+        cls = "conv_stem" if kid >= 300000 else ("conv1x1" if kid >= 200000 else ("conv3x3" if kid >= 30000 else "conv_other"))
+        self.bracket(cls, kid, flops, in_b + out_b + res_b + w_b,
+                     lambda: check(lib.dxmi_conv2d_fwd(ctypes.byref(d), _stream()), "dxmi_conv2d_fwd"))
 
     def summary(self):
-        """kernel_id -> dict(launches, ms, flops, bytes); call after torch.cuda.synchronize()."""
+        """(class, name) -> dict(launches, ms, flops, bytes); call after torch.cuda.synchronize()."""
         out = {}
-        for kid, fl, by, e0, e1 in self.records:
-            s = out.setdefault(kid, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for cls, name, fl, by, e0, e1 in self.records:
+            s = out.setdefault((cls, name), {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             s["launches"] += 1
             s["ms"] += e0.elapsed_time(e1)
             s["flops"] += fl
@@ -154,7 +161,11 @@ class ConvProfiler:
         return out
 
 
-CONV_PROFILER = None
+PROFILER = None
+
+
+def _prof(cls, name, flops, nbytes, fn):
+    return fn() if PROFILER is None else PROFILER.bracket(cls, name, flops, nbytes, fn)
 
 
 _WS = {}
@@ -187,13 +198,17 @@ def conv2d_wgrad(x, dy, ksize, *, in1=None, pad=None, stride=1, upsample=False, 
     assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (Cout, C0 + C1, ksize, ksize)
     lib = load()
     ws = _workspace(lib.dxmi_conv2d_wgrad_workspace_bytes(N, OH, OW, C0 + C1, Cout, ksize), x.device)
+    fl = 2.0 * N * OH * OW * Cout * (C0 + C1) * ksize * ksize
+    by = 2.0 * (x.numel() + (in1.numel() if in1 is not None else 0) + dy.numel()) + 4.0 * out.numel()
     if with_bias:
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
-        check(lib.dxmi_conv2d_wgrad_bias(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(out), _ptr(db), _ptr(ws), N, IH, IW, OH, OW,
-                                         Cout, ksize, stride, pad, int(upsample), 0, _stream()), "dxmi_conv2d_wgrad_bias")
+        _prof("wgrad", f"k{ksize}", fl, by, lambda: check(
+            lib.dxmi_conv2d_wgrad_bias(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(out), _ptr(db), _ptr(ws), N, IH, IW, OH, OW,
+                                       Cout, ksize, stride, pad, int(upsample), 0, _stream()), "dxmi_conv2d_wgrad_bias"))
         return out, db
-    check(lib.dxmi_conv2d_wgrad(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(out), _ptr(ws), N, IH, IW, OH, OW, Cout, ksize,
-                                stride, pad, int(upsample), int(accumulate), _stream()), "dxmi_conv2d_wgrad")
+    _prof("wgrad", f"k{ksize}", fl, by, lambda: check(
+        lib.dxmi_conv2d_wgrad(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(out), _ptr(ws), N, IH, IW, OH, OW, Cout, ksize,
+                              stride, pad, int(upsample), int(accumulate), _stream()), "dxmi_conv2d_wgrad"))
     return out
 
 
@@ -254,9 +269,11 @@ def groupnorm_silu_bwd(x, dy, gamma, beta, *, in1=None, add0=None, add1=None, gr
     dx0 = torch.empty_like(x)
     dx1 = torch.empty_like(in1) if in1 is not None else None
     part = torch.empty((2, N, C), dtype=torch.float32, device=x.device)
-    check(load().dxmi_groupnorm_silu_bwd(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(add0), _ptr(add1), _ptr(gamma), _ptr(beta),
-                                         _ptr(dx0), _ptr(dx1), _ptr(part[0]), _ptr(part[1]), N, H * W, groups, float(eps),
-                                         int(silu), _stream()), "dxmi_groupnorm_silu_bwd")
+    nb = 2.0 * N * H * W * C * (3 + (add0 is not None))     # x, dy (+ add) in, dx out
+    _prof("groupnorm_bwd", "resident", 0.0, nb, lambda: check(
+        load().dxmi_groupnorm_silu_bwd(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(add0), _ptr(add1), _ptr(gamma), _ptr(beta),
+                                       _ptr(dx0), _ptr(dx1), _ptr(part[0]), _ptr(part[1]), N, H * W, groups, float(eps),
+                                       int(silu), _stream()), "dxmi_groupnorm_silu_bwd"))
     red = part.sum(1)  # [2, C]: tiny fixed-order reduction over images
     return dx0, dx1, red[0], red[1]
 
@@ -306,8 +323,9 @@ def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, 
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C0 + C1
     if out is None:
         out = torch.empty((N, H, W, C0 + C1), dtype=torch.bfloat16, device=x.device)
-    check(load().dxmi_groupnorm_silu_fwd(_ptr(x), C0, _ptr(in1), C1, _ptr(gamma), _ptr(beta), _ptr(out), N, H * W,
-                                         groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_silu_fwd")
+    _prof("groupnorm", "resident", 0.0, 4.0 * N * H * W * (C0 + C1), lambda: check(
+        load().dxmi_groupnorm_silu_fwd(_ptr(x), C0, _ptr(in1), C1, _ptr(gamma), _ptr(beta), _ptr(out), N, H * W,
+                                       groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_silu_fwd"))
     return out
 
 
@@ -325,8 +343,9 @@ def groupnorm_generic(x, gamma, beta, *, in1=None, groups=32, eps=1e-5, silu=Tru
         ss_ld = scale_shift.stride(0)
     lib = load()
     ws = _workspace(lib.dxmi_groupnorm_generic_workspace_bytes(N, H * W, C), x.device)
-    check(lib.dxmi_groupnorm_generic_fwd(_ptr(x), C0, _ptr(in1), C1, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld, _ptr(out),
-                                         _ptr(ws), N, H * W, groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_generic_fwd")
+    _prof("groupnorm", "generic", 0.0, 4.0 * N * H * W * C, lambda: check(
+        lib.dxmi_groupnorm_generic_fwd(_ptr(x), C0, _ptr(in1), C1, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld, _ptr(out),
+                                       _ptr(ws), N, H * W, groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_generic_fwd"))
     return out
 
 
@@ -392,7 +411,8 @@ def attention(qkv, heads, scale, out=None):
     assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
     if out is None:
         out = torch.empty((N, T, C), dtype=torch.bfloat16, device=qkv.device)
-    check(load().dxmi_attention_fwd(_ptr(qkv), _ptr(out), N, T, C, heads, float(scale), _stream()), "dxmi_attention_fwd")
+    _prof("attention", f"T{T}_D{C // heads}", 4.0 * N * T * T * C, 2.0 * N * T * 4 * C, lambda: check(
+        load().dxmi_attention_fwd(_ptr(qkv), _ptr(out), N, T, C, heads, float(scale), _stream()), "dxmi_attention_fwd"))
     return out
 
 
@@ -445,8 +465,10 @@ def var_step(x, eps, z, xmul, cmul, sigma, want_mean=True, want_control=True, ou
         logp = torch.empty(N, dtype=torch.float32, device=x.device)
     else:
         x_next, mean, control, logp = outs
-    check(load().dxmi_var_step_fwd(_ptr(x), _ptr(eps), _ptr(z), _ptr(xmul), _ptr(cmul), _ptr(sigma), _ptr(x_next),
-                                   _ptr(mean), _ptr(control), _ptr(logp), N, CHW, assoc, _stream()), "dxmi_var_step_fwd")
+    nb = 4.0 * N * CHW * (3 + 1 + (mean is not None) + (control is not None))
+    _prof("sampler_step", "var_step", 0.0, nb, lambda: check(
+        load().dxmi_var_step_fwd(_ptr(x), _ptr(eps), _ptr(z), _ptr(xmul), _ptr(cmul), _ptr(sigma), _ptr(x_next),
+                                 _ptr(mean), _ptr(control), _ptr(logp), N, CHW, assoc, _stream()), "dxmi_var_step_fwd"))
     return x_next, mean, control, logp
 
 
@@ -531,8 +553,12 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, step_sizes, beta1, beta2, ep
             cache.update(c)
         cache = c
     ss = (ctypes.c_float * n)(*step_sizes)
-    check(load().dxmi_adam_step(cache["p"], _ptr_array(grads), cache["m"], cache["v"], cache["numel"], ss, n, beta1, beta2, eps,
-                                bc2_sqrt, _ptr(grad_scale), int(write_back_grad), _stream()), "dxmi_adam_step")
+    if "elems" not in cache:
+        cache["elems"] = sum(p.numel() for p in params)
+    garr = _ptr_array(grads)
+    _prof("optimizer", "adam", 0.0, 28.0 * cache["elems"], lambda: check(
+        load().dxmi_adam_step(cache["p"], garr, cache["m"], cache["v"], cache["numel"], ss, n, beta1, beta2, eps,
+                              bc2_sqrt, _ptr(grad_scale), int(write_back_grad), _stream()), "dxmi_adam_step"))
 
 
 def radam_step(params, grads, exp_avgs, exp_avg_sqs, lrs, beta1, beta2, eps, bc1, bc2_sqrt, rect, grad_scale=None,
@@ -594,5 +620,6 @@ def gather_rows(src, idx, out=None):
         out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
     assert out.is_contiguous() and out.dtype == src.dtype and out.numel() * out.element_size() == n * row_bytes
     if n:
-        check(load().dxmi_gather_rows(_ptr(src), _ptr(idx), _ptr(out), n, src.shape[0], row_bytes, _stream()), "dxmi_gather_rows")
+        _prof("replay_gather", f"row{row_bytes}", 0.0, 2.0 * n * row_bytes, lambda: check(
+            load().dxmi_gather_rows(_ptr(src), _ptr(idx), _ptr(out), n, src.shape[0], row_bytes, _stream()), "dxmi_gather_rows"))
     return out

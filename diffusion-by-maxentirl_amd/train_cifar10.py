@@ -23,6 +23,8 @@ import torch
 import cmd_utils as cmd
 import dxmi_config
 from dxmi_hip.dist import broadcast_parameters
+from dxmi_hip.optim import Adam          # torch.optim.Adam subclass: step() is one multi-tensor HIP kernel series
+from models.DxMI.replay import TransitionRing
 from models.DxMI.trainer import append_buffer, reset_buffer
 from utils import fix_legacy_dict, mkdir_p, print0
 
@@ -44,16 +46,18 @@ def synthetic_loader(batchsize, n_batches, device, seed):
 
 def train_one_epoch(trainer, sampler, dataloader, n_critic, n_generator, device, log_every, state):
     """reference train_one_epoch (:141-205) without the FID / logging side paths."""
-    buf = reset_buffer(device)
+    # device-resident replay ring: n_critic trajectories of T transitions each, generated in place by the sampler
+    buf = TransitionRing(n_critic, trainer.n_timesteps, trainer.batchsize, sampler.sample_shape, device)
     for step, (images, _) in enumerate(dataloader):
         sampler.eval()
         images = (2 * images - 1).to(device)
-        d_sample = sampler.sample(len(images), device=device)
+        in_ring = len(images) == trainer.batchsize
+        d_sample = sampler.sample(len(images), device=device, out=buf.next_slot() if in_ring else None)
         append_buffer(buf, d_sample)
         d_energy = trainer.update_f_v(images, d_sample, buf)
         if (step + 1) % n_critic == 0:
             d_sampler = trainer.update_sampler(buf, n_generator)
-            buf = reset_buffer(device)
+            buf = reset_buffer(device, ring=buf)
             if (step + 1) % log_every == 0:
                 print0(f"iter {state['i_iter']}: d_loss {d_energy['ebm/d_loss_']:.4f} v_loss {d_energy['ebm/v_loss_']:.4f} "
                        f"sampler_loss {d_sampler['sampler/sampler_loss_']:.4f}")
@@ -107,11 +111,11 @@ def main():
     tune_beta = bool(sampler.trainable_beta) and cfg.training.get("beta_lr") is not None
     if tune_beta:
         not_beta = [p for n, p in net.named_parameters() if "log_betas" not in n]
-        optimizer = torch.optim.Adam([{"params": net.log_betas, "lr": cfg.training.beta_lr},
+        optimizer = Adam([{"params": net.log_betas, "lr": cfg.training.beta_lr},
                                       {"params": not_beta, "lr": cfg.training.lr}])
     else:
-        optimizer = torch.optim.Adam(net.parameters(), lr=cfg.training.lr)
-    optimizer_v = torch.optim.Adam(v.parameters(), lr=cfg.training.v_lr)
+        optimizer = Adam(net.parameters(), lr=cfg.training.lr)
+    optimizer_v = Adam(v.parameters(), lr=cfg.training.v_lr)
 
     batchsize = cfg.training.batchsize // world     # the reference divides by the visible device count (:298-301)
     trainer = dxmi_config.instantiate(cfg.trainer, batchsize=batchsize)

@@ -20,7 +20,7 @@ import random
 
 import numpy as np
 import torch
-from torch.optim import Adam, RAdam
+from dxmi_hip.optim import Adam, RAdam   # torch.optim subclasses: step() is one multi-tensor HIP kernel series
 
 import cmd_utils as cmd
 import dxmi_config
@@ -129,7 +129,9 @@ def main():
     trainer.set_models(v=v, sampler=sampler, optimizer=opt, optimizer_v=opt_v)
 
     n_iter = cfg.training.n_iter if args.max_iters is None else min(cfg.training.n_iter, args.max_iters)
-    state_dict = reset_buffer(device)
+    # device-resident replay ring (one trajectory per iteration, generated in place by the sampler; sigma is 1-D here)
+    from models.DxMI.replay import TransitionRing
+    state_dict = TransitionRing(1, trainer.n_timesteps, batchsize, sampler.sample_shape, device, with_y=class_cond, sigma_dims=1)
     i_iter = -1
     for i_iter in range(n_iter):
         data, cond = next(loader)
@@ -137,11 +139,11 @@ def main():
         y = cond.get("y", None)
         y = y.to(device) if y is not None else None
         sampler.eval()
-        d_sample = sampler.sample(len(data), device=device, i_class=y)
+        d_sample = sampler.sample(len(data), device=device, i_class=y, out=state_dict.next_slot() if len(data) == batchsize else None)
         append_buffer(state_dict, d_sample)
         d_energy = trainer.update_f_v(data, d_sample, state_dict, y=y)
         d_sampler = trainer.update_sampler_mixed_precision(state_dict, mp_trainer=mp_trainer, d_sample=d_sample)
-        state_dict = reset_buffer(device)
+        state_dict = reset_buffer(device, ring=state_dict)
         if (i_iter + 1) % cfg.training.log_every == 0:
             print0(f"iter {i_iter}: d_loss {d_energy['ebm/d_loss_']:.4f} v_loss {d_energy['ebm/v_loss_']:.4f} "
                    f"sampler_loss {d_sampler['sampler/sampler_loss_']:.4f} lg_loss_scale {mp_trainer.lg_loss_scale:.3f}")

@@ -30,12 +30,12 @@ with torch.no_grad():
 print(f"{name}: B={B} T={s.n_timesteps}: {dt*1e3:.1f} ms/batch, {B/dt:.1f} img/s, finite={bool(torch.isfinite(d['sample']).all())}")
 if len(sys.argv) > 3:
     ops_mod = ops
-    prof = ops.ConvProfiler()
-    ops_mod.CONV_PROFILER = prof
+    prof = ops.OpProfiler()
+    ops_mod.PROFILER = prof
     with torch.no_grad():
         s.sample(B, device="cuda:0")
     torch.cuda.synchronize()
-    ops_mod.CONV_PROFILER = None
+    ops_mod.PROFILER = None
     tot = 0
     for kid, v in sorted(prof.summary().items(), key=lambda kv: -kv[1]["ms"]):
         print(f"  conv kid {kid}: {v['launches']} launches {v['ms']:.1f} ms {v['flops']/v['ms']/1e9:.0f} TFLOP/s {v['bytes']/v['ms']/1e6:.0f} GB/s")
