@@ -135,18 +135,33 @@ def oracle_sampler(device, T):
     return lambda noise: ovs.sample(lambda x, t: ounet.forward(sd, cfg, x, t).float(), sched, sched["log_betas"], noise)
 
 
-def cpu_baseline(T, batch, threads):
-    """Oracle (oracle/, torch-CPU fp32) generating `batch` images with T steps once, on `threads` host threads."""
+def usable_cores():
+    """Host cores this process may actually use: scheduler affinity, capped by the cgroup CPU quota when one is set
+    (a 256-thread pool on a quota of a few cores measures oversubscription, not the CPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 8)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(T, batch, threads, steps=None):
+    """Oracle (oracle/, torch-CPU fp32) generating `batch` images on `threads` host threads: `steps` of the T sampler
+    steps are run (every step costs the same: one U-Net forward + the transition) and the rate is scaled to T steps."""
     import torch
+    steps = T if steps is None else steps
     torch.set_num_threads(threads)
-    fn = oracle_sampler("cpu", T)
+    fn = oracle_sampler("cpu", steps)
     g = torch.Generator().manual_seed(0)
-    noise = [torch.randn(batch, 3, 32, 32, generator=g) for _ in range(T + 1)]
+    noise = [torch.randn(batch, 3, 32, 32, generator=g) for _ in range(steps + 1)]
     with torch.no_grad():
         t0 = time.perf_counter()
         fn(noise)
         dt = time.perf_counter() - t0
-    return batch / dt
+    return batch / (dt * T / steps)
 
 
 def eager_reference_gpu(device, T, batch):
@@ -154,10 +169,10 @@ def eager_reference_gpu(device, T, batch):
     torch.nn.functional ops the reference executes through MIOpen and rocBLAS), fp32 and under bf16 autocast."""
     import torch
     out = {}
+    fn = oracle_sampler(device, T)       # formula weights are generated on the CPU, then moved
     prev = torch.get_default_device()
     torch.set_default_device(device)     # the oracle builds its small helper tensors on the default device
     try:
-        fn = oracle_sampler(device, T)
         g = torch.Generator(device=device).manual_seed(1)
         noise = [torch.randn(batch, 3, 32, 32, device=device, generator=g) for _ in range(T + 1)]
         for name, ctx in (("fp32", torch.autocast("cuda", enabled=False)), ("bf16_autocast", torch.autocast("cuda", dtype=torch.bfloat16))):
@@ -378,14 +393,22 @@ def main():
                     f"on the same GPU, {B} images x T={T}, 2 timed repetitions after 1 warm-up; fp32 is the reference's precision"}
     if world == 1 and not args.no_cpu_baseline:
         cb = 16
-        ncores = os.cpu_count() or 8
-        v8 = cpu_baseline(T, cb, 8)
-        vall = cpu_baseline(T, cb, ncores)
-        best, cores = (v8, 8) if v8 >= vall else (vall, ncores)
+        ncores = usable_cores()
+        v8 = cpu_baseline(T, cb, 8)                      # the full configs[0] sample: 16 images x T steps
+        # all usable cores: 1 of the T steps, scaled, in a child process with a 45 s limit (a 256-thread pool has been seen
+        # to take 80 s per step on this pool's hosts: oversubscribed BLAS)
+        try:
+            r = subprocess.run([sys.executable, "-c", f"import bench; print(bench.cpu_baseline({T}, {cb}, {ncores}, steps=1))"],
+                               cwd=ROOT, capture_output=True, text=True, timeout=45)
+            vall = float(r.stdout.strip().splitlines()[-1])
+        except (subprocess.TimeoutExpired, ValueError, IndexError):
+            vall = None
+        best, cores = (v8, 8) if (vall is None or v8 >= vall) else (vall, ncores)
         line["cpu_baseline"] = {"value": best, "unit": "images/s", "cores": cores, "kind": "port",
-                                "at_8_threads": v8, "at_all_cores": vall, "all_cores": ncores,
-                                "sample": f"oracle (torch-CPU fp32 restatement), {cb} images x T={T}, one repetition each at 8 threads "
-                                          f"and at {ncores} threads (BASELINE configs[0] shape); the better one is `value`"}
+                                "at_8_threads": v8, "at_all_cores": vall, "all_cores": ncores, "logical_cpus": os.cpu_count(),
+                                "sample": f"oracle (torch-CPU fp32 restatement), BASELINE configs[0] shape: {cb} images x T={T} at 8 threads "
+                                          f"(whole sample) and at the {ncores} usable cores (1 of the {T} steps, rate scaled to T, null = "
+                                          "not finished within 45 s); one repetition each; the better one is `value`"}
     print(json.dumps(line))
 
 
