@@ -42,6 +42,12 @@ __device__ __forceinline__ float dxmi_act(float v, int act) {
     }
 }
 
+// Branch-free form for the epilogues of the conv kernels: `act` is uniform, but a switch per element costs a ladder of
+// scalar branches per value (measured: the tile epilogue of conv_pipe_kernel spent thousands of cycles in them).
+// slope = 1 (none), 0.2 (leaky), 0 (relu): v > 0 ? v : slope * v.  SiLU keeps its own (hoisted) path.
+__device__ __forceinline__ float dxmi_act_slope(int act) { return act == DXMI_ACT_LEAKY02 ? 0.2f : (act == DXMI_ACT_RELU ? 0.f : 1.f); }
+__device__ __forceinline__ float dxmi_act_lin(float v, float slope) { return fmaxf(v, 0.f) + slope * fminf(v, 0.f); }
+
 // Workgroup barrier for LDS hand-offs that does NOT drain the vector-memory queue: __syncthreads()
 // makes hipcc emit s_waitcnt vmcnt(0) first, which stalls on every prefetched global load and on every
 // outstanding global store (CDNA4's vmcnt counts stores too).  LDS traffic of this wave is complete

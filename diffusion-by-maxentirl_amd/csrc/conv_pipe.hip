@@ -21,6 +21,22 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
+#ifdef DXMI_CONV_STAMPS
+// timing-only build (make STAMPS=1): per-workgroup cycle stamps of wave 0 (s_memtime), read back with
+// dxmi_debug_read_stamps() by tools/conv_stamps.py: [0] start, [1] HW_ID | XCC_ID << 32, then per tile
+// (K loop start, K loop end, epilogue end)
+__device__ unsigned long long g_stamps[2048][24];
+#define DXMI_STAMP(i)                                                                                        \
+    do {                                                                                                     \
+        if (threadIdx.x == 0 && (i) < 24) g_stamps[blockIdx.x & 2047][(i)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+extern "C" int dxmi_debug_read_stamps(void* dst, int bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define DXMI_STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 // Epilogue through LDS: the accumulators hold D[co][pixel] with only 4 consecutive couts per lane, so
@@ -43,6 +59,8 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&ac
     const int co_l = wave * 32 + 4 * h;  // + 8g
     const int pc = tid & 15;
     const bool pc_ok = cot * 128 + pc * 8 < p.Cout;
+    const float slope = dxmi_act_slope(p.act);      // uniform: one select, not a branch ladder per value
+    const bool silu = p.act == DXMI_ACT_SILU;
     // output offset of this thread's k-th 16-byte piece of a pass (-1: outside the batch / cout range)
     auto out_off = [&](int pass, int k) -> long {
         const int lp = (tid >> 4) + 16 * k;
@@ -114,8 +132,13 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&ac
                     for (int e = 0; e < 8; ++e) v[e] *= ((float)mv[e] > 0.f ? 1.f : p.mask_slope);
                 }
                 bf16x8 ov;
+                if (silu) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ov[e] = (bf16)dxmi_act(v[e], p.act);
+                    for (int e = 0; e < 8; ++e) ov[e] = (bf16)(v[e] / (1.f + __expf(-v[e])));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ov[e] = (bf16)dxmi_act_lin(v[e], slope);
+                }
                 *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + o) = ov;
             }
         }
@@ -278,7 +301,16 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) B[0][ks][nb] = *reinterpret_cast<const bf16x8*>(smem + hoff[nb] + ks * 32);
 
+    int stamp_i = 2;
+#ifdef DXMI_CONV_STAMPS
+    if (threadIdx.x == 0) {
+        g_stamps[blockIdx.x & 2047][0] = __builtin_amdgcn_s_memtime();
+        g_stamps[blockIdx.x & 2047][1] = __builtin_amdgcn_s_getreg(((4 - 1) << 11) | (8 << 6) | 4) |
+                                         ((unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) << 32);
+    }
+#endif
     for (;;) {
+        DXMI_STAMP(stamp_i); ++stamp_i;
         const int pt_next = pt + nstreams;
         const bool more_tiles = pt_next < p.PT;
         // ---- K loop of this tile: two chunks (2*TAPS steps) of straight-line code per iteration.
@@ -342,12 +374,19 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
             }
         }
         // ---- tile done: the next tile's first operands are already in flight
+        DXMI_STAMP(stamp_i); ++stamp_i;
         {
             int n0, oy0, ox0;
             tile_origin(pt, n0, oy0, ox0);
             if (!(DBG & 32)) conv_epilogue_lds<NB>(p, acc, smem + 2 * BUF, n0, oy0, ox0, cot, wave, lane, tid);
-            else if (acc[0][0][0] == 12345.f) reinterpret_cast<float*>(p.out)[0] = acc[0][NB - 1][3];  // keep acc live
+            else {
+                // timing-only ablation: keep EVERY accumulator live (a use of one element lets hipcc delete the MFMAs that
+                // feed the others: the "K loop alone" numbers of round 1 were taken that way and read 2x too fast)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(acc[0][nb]));
+            }
         }
+        DXMI_STAMP(stamp_i); ++stamp_i;
         if (!more_tiles) break;
         pt = pt_next;
 #pragma unroll
