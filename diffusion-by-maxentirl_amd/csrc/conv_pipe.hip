@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) B[0][ks][nb] = *reinterpret_cast<const bf16x8*>(smem + hoff[nb] + ks * 32);
 
-    int stamp_i = 2;
+    [[maybe_unused]] int stamp_i = 2;
 #ifdef DXMI_CONV_STAMPS
     if (threadIdx.x == 0) {
         g_stamps[blockIdx.x & 2047][0] = __builtin_amdgcn_s_memtime();
@@ -382,8 +382,12 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
             else {
                 // timing-only ablation: keep EVERY accumulator live (a use of one element lets hipcc delete the MFMAs that
                 // feed the others: the "K loop alone" numbers of round 1 were taken that way and read 2x too fast)
+                float keep = 0.f;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(acc[0][nb]));
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) keep += acc[0][nb][r];
+                if (keep == 12345.f) reinterpret_cast<float*>(p.out)[0] = keep;
             }
         }
         DXMI_STAMP(stamp_i); ++stamp_i;
