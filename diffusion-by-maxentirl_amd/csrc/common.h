@@ -42,6 +42,12 @@ __device__ __forceinline__ float dxmi_act(float v, int act) {
     }
 }
 
+// x * sigmoid(x) with the hardware reciprocal: v_exp_f32 + v_rcp_f32 + 2 VALU per value.  `v / (1 + expf(-v))` compiles
+// to the IEEE division sequence (div_scale / rcp / 4 fma / div_fmas / div_fixup: ~10 more instructions), which made the
+// GroupNorm+SiLU kernel VALU-bound: ~17 us of arithmetic per 24 us of HBM time at 128 ch x 32x32 x 256 images, none of
+// it overlapped (one round of workgroups).  v_rcp_f32 is accurate to 1 ulp; the result is rounded to bf16 (2^-9).
+__device__ __forceinline__ float dxmi_silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+
 // Branch-free form for the epilogues of the conv kernels: `act` is uniform, but a switch per element costs a ladder of
 // scalar branches per value (measured: the tile epilogue of conv_pipe_kernel spent thousands of cycles in them).
 // slope = 1 (none), 0.2 (leaky), 0 (relu): v > 0 ? v : slope * v.  SiLU keeps its own (hoisted) path.

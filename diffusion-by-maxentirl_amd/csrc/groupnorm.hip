@@ -150,8 +150,8 @@ __global__ __launch_bounds__(512) void gn_silu_kernel(GnArgs p) {
                 float y0 = GN_LO(v[q][e]) * ga[2 * e] + be[2 * e];
                 float y1 = GN_HI(v[q][e]) * ga[2 * e + 1] + be[2 * e + 1];
                 if (p.silu) {
-                    y0 = y0 / (1.f + __expf(-y0));
-                    y1 = y1 / (1.f + __expf(-y1));
+                    y0 = dxmi_silu_fast(y0);
+                    y1 = dxmi_silu_fast(y1);
                 }
                 o[2 * e] = (bf16)y0;
                 o[2 * e + 1] = (bf16)y1;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void gn_gen_apply_kernel(GnGenArgs p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float y = (float)v[u][e] * A[e] + Bv[e];
-                    if (p.silu) y = y / (1.f + __expf(-y));
+                    if (p.silu) y = dxmi_silu_fast(y);
                     o[e] = (bf16)y;
                 }
                 *reinterpret_cast<bf16x8*>(dst + (size_t)rr * C) = o;
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512) void gn_silu_bwd_kernel(GnBwdArgs p) {
     auto dyy_of = [&](float xh, float g, float gam, float bet) -> float {
         if (!p.silu) return g;
         const float y = xh * gam + bet;
-        const float sg = 1.f / (1.f + __expf(-y));
+        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-y));
         return g * (sg * (1.f + y * (1.f - sg)));
     };
     float dgs[VEC], dbs[VEC], s1 = 0.f, s2 = 0.f;
@@ -663,7 +663,7 @@ __device__ __forceinline__ void gn_gen_group_stats(const GnGenBwdArgs& p, int n,
 }
 
 __device__ __forceinline__ float gn_dsilu(float y) {
-    const float sg = 1.f / (1.f + __expf(-y));
+    const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-y));
     return sg * (1.f + y * (1.f - sg));
 }
 

@@ -222,7 +222,8 @@ def test_hip_trainer_step_vs_reference(golden_dir, fixture):
         assert c > 0.97, (g["val_pick"][i], c)
     # whole-tensor checks the fixture has carried since round 1
     assert _cos((nnamed["conv_out.weight"].detach() - w0["conv_out.weight"]).cpu().numpy(), g["net_conv_out_w_delta"]) > 0.95
-    np.testing.assert_allclose(vnamed["net.linear.weight"].detach().cpu().numpy(), g["value_linear_w"], rtol=0, atol=3e-5)
+    # T+1 Adam steps of lr 1e-5 each: an element whose tiny gradient flips sign under bf16 noise moves 2e-5 per step the other way
+    np.testing.assert_allclose(vnamed["net.linear.weight"].detach().cpu().numpy(), g["value_linear_w"], rtol=0, atol=1.2e-4)
     lb = net.log_betas.detach().cpu().numpy()
     assert np.allclose(lb, g["log_betas_after"], atol=3e-5), (lb, g["log_betas_after"])
     print(f"{fixture}:", ", ".join(f"{r[0]}={r[1]:.4f}" for r in report))
