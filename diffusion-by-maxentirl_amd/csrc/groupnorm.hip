@@ -820,6 +820,17 @@ extern "C" int dxmi_groupnorm_silu_supported(int32_t C0, int32_t C1, int32_t HW,
     }
 }
 
+// 1 when dxmi_groupnorm_silu_bwd can slice the shape (its plan is stricter than the forward's: x AND dy stay resident),
+// else 0: callers then use dxmi_groupnorm_generic_bwd.
+extern "C" int dxmi_groupnorm_silu_bwd_supported(int32_t C0, int32_t C1, int32_t HW, int32_t groups) {
+    const int C = C0 + C1;
+    if (groups <= 0 || groups > 32 || C % groups != 0) return 0;
+    const int cpg = C / groups;
+    if (cpg % 4 != 0 || C0 % 4 != 0) return 0;
+    int VEC, slices, threads, pieces, ppp;
+    return gn_plan(C, C0, HW, groups, 8, 16, &VEC, &slices, &threads, &pieces, &ppp) == 0 && pieces <= 16;
+}
+
 extern "C" int dxmi_groupnorm_silu_fwd(const void* in0, int32_t C0, const void* in1, int32_t C1, const float* gamma,
                                        const float* beta, void* out, int32_t N, int32_t HW, int32_t groups, float eps,
                                        int32_t apply_silu, void* stream) {

@@ -55,6 +55,7 @@ SIGNATURES = {
     "dxmi_pool_act": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_value_head": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dxmi_groupnorm_silu_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "dxmi_groupnorm_silu_bwd_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "dxmi_groupnorm_generic_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "dxmi_groupnorm_generic_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dxmi_groupnorm_generic_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),

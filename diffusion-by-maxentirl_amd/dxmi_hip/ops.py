@@ -172,10 +172,15 @@ _WS = {}
 
 
 def _workspace(nbytes, device):
-    """Grow-only scratch buffer per device (split-K partials); safe because all launches are stream-ordered."""
-    key = str(device)
+    """Grow-only scratch buffer per (device, stream): split-K partials, column sums, generic-GroupNorm partials.  Keyed by
+    the launch stream so that work overlapped on a second stream never shares it; a buffer captured into a hipGraph is
+    never re-allocated (growth during capture raises: size it with one eager call first)."""
+    stream = torch.cuda.current_stream(device)
+    key = (str(device), stream.cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None and torch.cuda.is_current_stream_capturing():
+            raise _lib.DxmiError("dxmi_hip workspace would have to grow during hipGraph capture: run the step once eagerly first")
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
@@ -266,6 +271,10 @@ def groupnorm_silu_bwd(x, dy, gamma, beta, *, in1=None, add0=None, add1=None, gr
     C1 = in1.shape[3] if in1 is not None else 0
     C = C0 + C1
     assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and tuple(dy.shape) == (N, H, W, C)
+    if not load().dxmi_groupnorm_silu_bwd_supported(C0, C1, H * W, groups):
+        # shapes the register-resident backward cannot slice (the forward falls back the same way): generic three-launch path
+        dx0, dx1, dg, db, _ = groupnorm_generic_bwd(x, dy, gamma, beta, in1=in1, add0=add0, add1=add1, groups=groups, eps=eps, silu=silu)
+        return dx0, dx1, dg, db
     dx0 = torch.empty_like(x)
     dx1 = torch.empty_like(in1) if in1 is not None else None
     part = torch.empty((2, N, C), dtype=torch.float32, device=x.device)

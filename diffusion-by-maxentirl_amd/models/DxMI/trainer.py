@@ -219,7 +219,8 @@ class DxMI_Trainer:
             next_state, pred_mean, pred_std = d_step["sample"], d_step["mean"], d_step["sigma"]
             running_cost = self.get_running_cost(state, next_state, pred_mean, pred_std, t)
             causal_entropy = torch.log(pred_std.squeeze())
-            sampler_value_loss = self.v(next_state, t + 1).squeeze()
+            with self._frozen(self.v):
+                sampler_value_loss = self.v(next_state, t + 1).squeeze()
             non_terminal = (t < self.n_timesteps - self.skip_sampler_tau).float()
             sampler_loss = (sampler_value_loss + (running_cost * self.tau2 - causal_entropy * self.tau1) * non_terminal).mean()
             sampler_loss.backward()
@@ -277,6 +278,21 @@ class DxMI_Trainer:
 
     def _guidance_model_kwargs(self, n_sample, device):
         return {}
+
+    class _frozen:
+        """Context: the module's parameters do not ask for gradients (the value net inside the policy step: the reference
+        accumulates and then discards them, trainer.py:235 / :387 — skipping the weight-gradient kernels changes nothing)."""
+
+        def __init__(self, module):
+            self.ps = [p for p in module.parameters() if p.requires_grad]
+
+        def __enter__(self):
+            for p in self.ps:
+                p.requires_grad_(False)
+
+        def __exit__(self, *exc):
+            for p in self.ps:
+                p.requires_grad_(True)
 
     @staticmethod
     def _clip(parameters, max_norm):
@@ -475,7 +491,8 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
             next_state, pred_mean, pred_std = d_step["sample"], d_step["mean"], d_step["sigma"]
             running_cost = self.get_running_cost(state, next_state, pred_mean, pred_std, t)
             causal_entropy = torch.log(pred_std.squeeze())
-            sampler_value_loss = self.v(next_state, t + 1, y=y).squeeze()
+            with self._frozen(self.v):
+                sampler_value_loss = self.v(next_state, t + 1, y=y).squeeze()
             non_terminal = (t < self.n_timesteps - self.skip_sampler_tau).float()
             sampler_loss = (sampler_value_loss + (running_cost * self.tau2 - causal_entropy * self.tau1) * non_terminal).mean()
             mp_trainer.backward(sampler_loss)

@@ -173,10 +173,15 @@ class _UNetFn(torch.autograd.Function):
                                                               add1=add1, silu=True)
                 C0 = x0.shape[3]
                 w = pkt[id(b), "short"]
-                d_x0 = ops.conv2d(g, ops.pack_conv_weight(w[:, :C0].contiguous(), transpose_flip=True), residual=dxg0)
+                # transposed fragments of the shortcut, split per concat source; cached with the other packs
+                if (id(b), "short_t", C0) not in pkt:
+                    pkt[id(b), "short_t", C0] = (ops.pack_conv_weight(w[:, :C0].contiguous(), transpose_flip=True),
+                                                 ops.pack_conv_weight(w[:, C0:].contiguous(), transpose_flip=True) if x1 is not None else None)
+                w0t, w1t = pkt[id(b), "short_t", C0]
+                d_x0 = ops.conv2d(g, w0t, residual=dxg0)
                 d_x1 = None
                 if x1 is not None:
-                    d_x1 = ops.conv2d(g, ops.pack_conv_weight(w[:, C0:].contiguous(), transpose_flip=True), residual=dxg1)
+                    d_x1 = ops.conv2d(g, w1t, residual=dxg1)
             else:
                 assert x1 is None
                 addin = g if add0 is None else g + add0
@@ -243,7 +248,9 @@ class _UNetFn(torch.autograd.Function):
         grads[net.conv_in.weight] = ops.stem_conv_wgrad(ctx.x, g)
         dx = None
         if ctx.needs_input_grad[1]:
-            dx = ops.conv2d(g, ops.pack_conv_weight(net.conv_in.weight, transpose_flip=True), out_nchw_f32=True)
+            if "conv_in_t" not in pkt:
+                pkt["conv_in_t"] = ops.pack_conv_weight(net.conv_in.weight, transpose_flip=True)
+            dx = ops.conv2d(g, pkt["conv_in_t"], out_nchw_f32=True)
 
         # ---- temb MLP + all temb_proj layers: tiny dense graph, re-evaluated in fp32 with torch autograd
         blocks = list(net._resblocks())

@@ -204,10 +204,14 @@ class _EDMUNetFn(torch.autograd.Function):
                 dxg0, dxg1, _ = gn_bwd(gn1, x0, d_a1, in1=x1)
                 C0 = x0.shape[3]
                 w = sk.weight
-                d_x0 = ops.conv2d(g, ops.pack_conv_weight(w[:, :C0].contiguous(), transpose_flip=True), residual=dxg0)
+                if (id(b), "skip_t", C0) not in pkt:     # transposed fragments per concat source, cached with the other packs
+                    pkt[id(b), "skip_t", C0] = (ops.pack_conv_weight(w[:, :C0].contiguous(), transpose_flip=True),
+                                                ops.pack_conv_weight(w[:, C0:].contiguous(), transpose_flip=True) if x1 is not None else None)
+                w0t, w1t = pkt[id(b), "skip_t", C0]
+                d_x0 = ops.conv2d(g, w0t, residual=dxg0)
                 d_x1 = None
                 if x1 is not None:
-                    d_x1 = ops.conv2d(g, ops.pack_conv_weight(w[:, C0:].contiguous(), transpose_flip=True), residual=dxg1)
+                    d_x1 = ops.conv2d(g, w1t, residual=dxg1)
                 return d_x0, d_x1
             assert x1 is None
             g_id = _up_sum(g) if b.up else (_pool_t(g) if b.down else g)
@@ -267,7 +271,9 @@ class _EDMUNetFn(torch.autograd.Function):
         grads[conv_in.weight] = ops.stem_conv_wgrad(ctx.x, g)
         dx = None
         if ctx.needs_input_grad[1]:
-            dx = ops.conv2d(g, ops.pack_conv_weight(conv_in.weight, transpose_flip=True), out_nchw_f32=True)
+            if "conv_in_t" not in pkt:
+                pkt["conv_in_t"] = ops.pack_conv_weight(conv_in.weight, transpose_flip=True)
+            dx = ops.conv2d(g, pkt["conv_in_t"], out_nchw_f32=True)
 
         # ---- embedding graph: time_embed MLP, label embedding, every emb_layers Linear (tiny; torch fp32 autograd)
         blocks = [m for m in net.modules() if isinstance(m, ResBlock)]

@@ -42,6 +42,9 @@ class _ValueNetFn(torch.autograd.Function):
         res = ops.value_head(inp, net.linear.weight, net.linear.bias, ow, ob)
         ctx.net, ctx.saved, ctx.a0, ctx.x, ctx.x_nhwc = net, saved, a0, x, x_nhwc
         ctx.need_dx = x.requires_grad or ctx.needs_input_grad[1]
+        # parameter gradients are skipped when no parameter asks for one (the policy step only needs d/dx: its value
+        # gradients are discarded by the next zero_grad, reference trainer.py:235, :387)
+        ctx.need_dw = any(prm.requires_grad for prm in params)
         return res
 
     @staticmethod
@@ -60,9 +63,11 @@ class _ValueNetFn(torch.autograd.Function):
         else:
             dy_pre = dy
         dfeat, s = ops.value_head_bwd(feat, w.contiguous(), dy_pre.contiguous())
-        grads[net.linear.weight] = (dy_pre[:, None] * s).sum(0, keepdim=True)
-        grads[net.linear.bias] = dy_pre.sum().reshape(1)
-        if net.learn_out_scale:
+        dw = ctx.need_dw
+        if dw:
+            grads[net.linear.weight] = (dy_pre[:, None] * s).sum(0, keepdim=True)
+            grads[net.linear.bias] = dy_pre.sum().reshape(1)
+        if dw and net.learn_out_scale:
             y_pre = s @ w + net.linear.bias
             grads[net.out_scale.weight] = (dy * y_pre).sum().reshape(1, 1)
             grads[net.out_scale.bias] = dy.sum().reshape(1)
@@ -73,11 +78,14 @@ class _ValueNetFn(torch.autograd.Function):
             inp, h1, out = saved[i]
             # gradient w.r.t. conv2 output + skip (before pool / LeakyReLU)
             d_c2 = ops.pool_act_bwd(g_out, out, b.downsample, SLOPE)
-            grads[b.conv2.weight], grads[b.conv2.bias] = ops.conv2d_wgrad(h1, d_c2, 3, with_bias=True)
+            if dw:
+                grads[b.conv2.weight], grads[b.conv2.bias] = ops.conv2d_wgrad(h1, d_c2, 3, with_bias=True)
             d_h1 = ops.conv2d(d_c2, pk_t[i, "conv2"], mask_src=h1, mask_slope=SLOPE)  # * LeakyReLU'(h1)
-            grads[b.conv1.weight], grads[b.conv1.bias] = ops.conv2d_wgrad(inp, d_h1, 3, with_bias=True)
+            if dw:
+                grads[b.conv1.weight], grads[b.conv1.bias] = ops.conv2d_wgrad(inp, d_h1, 3, with_bias=True)
             if b.skip is not None:
-                grads[b.skip[0].weight] = ops.conv2d_wgrad(inp, d_c2, 1)
+                if dw:
+                    grads[b.skip[0].weight] = ops.conv2d_wgrad(inp, d_c2, 1)
                 d_skip = ops.conv2d(d_c2, pk_t[i, "skip"])
             else:
                 d_skip = d_c2
@@ -85,9 +93,10 @@ class _ValueNetFn(torch.autograd.Function):
             g_out = ops.conv2d(d_h1, pk_t[i, "conv1"], residual=d_skip)
         # ---- stem conv: a0 = LeakyReLU(conv1(x))
         d_a0 = ops.pool_act_bwd(g_out, a0, False, SLOPE)
-        grads[net.conv1.bias] = ops.colsum(d_a0)
         assert net.in_chan == 3, "stem backward is written for 3-channel images"
-        grads[net.conv1.weight] = ops.stem_conv_wgrad(ctx.x, d_a0)
+        if dw:
+            grads[net.conv1.bias] = ops.colsum(d_a0)
+            grads[net.conv1.weight] = ops.stem_conv_wgrad(ctx.x, d_a0)
         dx = None
         if ctx.need_dx:
             # data gradient of the stem: 128 -> 3 channel conv on flipped weights, fp32 NCHW out

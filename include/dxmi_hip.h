@@ -135,6 +135,9 @@ int dxmi_groupnorm_silu_bwd(const void* in0, int32_t C0, const void* in1, int32_
                             const void* add0, const void* add1, const float* gamma, const float* beta,
                             void* dx0, void* dx1, float* dgamma_part, float* dbeta_part, int32_t N,
                             int32_t HW, int32_t groups, float eps, int32_t apply_silu, void* stream);
+/* 1 when dxmi_groupnorm_silu_bwd can serve the shape (x and dy both stay resident, so its limits are tighter than the
+ * forward's), else 0 — use dxmi_groupnorm_generic_bwd then. */
+int dxmi_groupnorm_silu_bwd_supported(int32_t C0, int32_t C1, int32_t HW, int32_t groups);
 
 /* Batched bf16 GEMM on MFMA for attention backward: C[b] = alpha * A[b] (MxK) * B[b] (KxN), batch
  * b = (outer, inner) with element strides *_b0 / *_b1.  *_kcontig != 0: element (row,k) of that operand
