@@ -84,6 +84,8 @@ def spawn_ranks(n):
 # ----------------------------------------------------------------------------------------------- pieces
 def kernel_name(kid):
     """dxmi_conv2d_kernel_id -> the template instantiation name rocprofv3 prints."""
+    if kid >= 400000:
+        return "conv_ws_kernel"
     if kid >= 300000:
         return "conv_stem_kernel"
     if kid >= 200000:

@@ -1,0 +1,412 @@
+// Wave-specialised 3x3 convolution for gfx950: the MFMA waves never touch global memory.
+//
+// Why (measured on MI355X): in conv_pipe_kernel every wave both computes and moves data.  vmcnt retires
+// in order, so a wave that has stores or residual loads in flight stalls at its next wait on a *younger* weight-fragment
+// load until they are acknowledged; the tile end (residual in, output out) therefore costs more cycles than the tile's
+// MFMAs, and at 256 VGPRs there is no room for a third resident workgroup to cover it.  Here ONE workgroup of 8 waves owns a
+// CU and the roles are split (each SIMD hosts one wave of each kind):
+//   waves 0-3  MFMA: a 64-cout x 128-pixel accumulator tile each (128 co x 256 px per workgroup).  Operands come from LDS
+//              only — weight fragments from a 4-slot ring, input pixels from a double-buffered halo image — with a
+//              half-step software pipeline (the reads of one 16-deep k-step fly under the 8 MFMAs of the previous one).
+//              No vector-memory instruction is ever issued, so nothing a loader does can stall them; the only waits are
+//              lgkmcnt for LDS reads and one barrier per (chunk, tap) step.
+//   waves 4,5  weight loaders: stream the pre-packed MFMA A fragments of step g+3 into the ring by LDS DMA
+//              (`global_load_lds_dwordx4`: one 1-KiB fragment per instruction, no staging registers), wait with a counted
+//              vmcnt that leaves two steps in flight.
+//   waves 6,7  bulk movers: the next 32-channel chunk's halo image (DMA, XOR-swizzled 16-byte slots instead of padding: a
+//              DMA writes 1 KiB linearly), the residual tile and the bias / temb table of the CURRENT tile (DMA into the
+//              output tile's own LDS buffer), and the drain of the PREVIOUS tile's output (LDS -> 256-byte NHWC rows).
+//              Their long-latency traffic only ever delays themselves.
+// Tile end: the MFMA waves add bias + temb + residual to the accumulators in the accumulator layout (LDS reads of their
+// own cout columns), apply the activation, round ONCE to bf16 and write the output tile in place in LDS; two barriers.
+//
+// Scope: 3x3 / stride 1 / pad 1 (optionally behind a nearest x2 upsample), NHWC bf16 in (virtual concat) and out,
+// Cout % 128 == 0, Cin % 32 == 0, maps >= 16x16 (one image per 256-pixel tile).  Everything else stays on conv_pipe.hip.
+#include "conv_common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int WS_A_SLOT = 8192;              // one (chunk, tap): 2 k-steps x 4 cout blocks x 1 KiB fragments
+constexpr int WS_RING = 6;                   // ring slots (steps): five steps of weight prefetch
+constexpr int WS_A_RING = WS_RING * WS_A_SLOT;
+constexpr int WS_RO = 256 * 256;             // output / residual tile: 256 px x 128 co bf16
+constexpr int WS_TB = 1024;                  // bias[128] | temb[128] fp32
+constexpr int WS_HALO_BLOCKS = 23;           // 1-KiB blocks of a halo image (34x10 or 20x18 pixels x 64 B)
+constexpr int WS_HALO = WS_HALO_BLOCKS * 1024;
+
+__device__ uint4 ws_zero16 = {0u, 0u, 0u, 0u};   // source of zero-padding pixels
+
+#define WS_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define WS_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// one MFMA, then one LDS read, six times, then the last two MFMAs: with a single MFMA wave per SIMD the operand reads of
+// the next half-step must issue in the shadow of this half-step's MFMAs
+#define WS_INTERLEAVE()                                         \
+    do {                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  \
+        }                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      \
+    } while (0)
+
+struct WsTile {
+    int cot, n0, oy0, ox0;
+};
+
+// Halo image: pixel (hy, hx) of the (TH+2) x (TW+2) halo at row pitch HP pixels, 64 B (32 channels) per pixel in four
+// 16-byte slots; channel piece j sits in slot j ^ ((hx >> 2) & 3).  With HP = 34 (TW 32) / 20 (TW 16) the ds_read_b128
+// lane groups of every (tap, k-step) are bank-conflict free (brute-forced), and because the swizzle depends on hx only, a
+// lane's B-operand address is one of six precomputed bases (kx x k-step) plus a compile-time offset: no address arithmetic
+// in the MFMA loop.
+template <int TW>
+__global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
+    constexpr int TH = 256 / TW, HP = TW == 32 ? 34 : 20, HH = TH + 2, RPB = 32 / TW, TWl = TW == 32 ? 5 : 4;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const halo0 = smem;
+    char* const aring = smem + 2 * WS_HALO;
+    char* const ro = aring + WS_A_RING;
+    float* const tb = reinterpret_cast<float*>(ro + WS_RO);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int txn = p.OW / TW, tyn = p.OH / TH;
+    const int nchunks = (p.C0 + p.C1) / 32;
+    const int S = 9 * nchunks;                       // steps per tile
+    const int ntiles = p.PT * p.CT;                  // (pixel tile, cout tile) pairs, cout fastest
+    const int ups = p.ups ? 1 : 0;
+
+    auto tile_of = [&](int q, WsTile& t) {
+        t.cot = q % p.CT;
+        const int pt = q / p.CT;
+        const int tx = pt % txn, ty = (pt / txn) % tyn;
+        t.n0 = pt / (txn * tyn);
+        t.oy0 = ty * TH;
+        t.ox0 = tx * TW;
+    };
+
+    int q = blockIdx.x;
+    if (q >= ntiles) return;
+    const int qstride = gridDim.x;
+
+    if (wave < 4) {
+        // ================================================================ MFMA waves
+        const int ch = wave & 1, ph = wave >> 1, h = lane >> 5;
+        const int x = lane & (TW - 1), yl = (lane & 31) >> TWl;
+        // B-operand bases [kx][ks] (relative to a halo image, tap row 0, this wave's first pixel block)
+        int bbase[3][2];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                bbase[kx][ks] = (((ph * 4 * RPB + yl) * HP + x + kx) * 64) + (((ks * 2 + h) ^ (((x + kx) >> 2) & 3)) * 16);
+        const char* const abase = aring + ch * 2048 + lane * 16;      // + slot*8192 + ks*4096 + cb*1024
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][nb][r] = 0.f;
+        bf16x8 Ax[2], Bx[4], Ay[2], By[4];
+        // operands of k-step ks of step u of a chunk PAIR (u = 0..17: chunk parity u / 9, tap u % 9; u = 18 is the first
+        // step of the next pair / the next tile): ring slot, halo image and tap offset are compile-time constants
+        auto read_ops = [&](int u, int ks, bf16x8 (&A)[2], bf16x8 (&B)[4]) {
+            const int t = u % 9, ky = t / 3, kx = t % 3;
+            const char* hb = halo0 + ((u / 9) & 1) * WS_HALO + bbase[kx][ks];
+            const char* as = abase + (u % WS_RING) * WS_A_SLOT + ks * 4096;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) A[cb] = *reinterpret_cast<const bf16x8*>(as + cb * 1024);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) B[nb] = *reinterpret_cast<const bf16x8*>(hb + (RPB * nb + ky) * HP * 64);
+        };
+        auto mfma8 = [&](const bf16x8 (&A)[2], const bf16x8 (&B)[4]) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) acc[cb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cb], B[nb], acc[cb][nb], 0, 0, 0);
+        };
+        const float slope = dxmi_act_slope(p.act);
+        const bool has_res = p.residual != nullptr;
+
+        __builtin_amdgcn_s_setprio(3);                  // the MFMA stream outranks the loaders that share its SIMD
+        ws_barrier();                                   // P0: tap 0 and the first halo chunk have landed
+        read_ops(0, 0, Ax, Bx);
+        for (;;) {
+            const bool more = q + qstride < ntiles;
+            // K loop: two chunks (18 steps) of straight-line code per iteration, no branches inside (a branch makes hipcc wait
+            // lgkmcnt(0) at the join, which exposes the latency of the operand reads just issued).  The first operands of
+            // the step after the last one — the next tile's first step, whose weights and halo image are already in LDS
+            // when the last barrier of this tile opens — are requested unconditionally.
+            for (int c = 0; c < nchunks; c += 2) {
+#pragma unroll
+                for (int u = 0; u < 18; ++u) {
+                    read_ops(u, 1, Ay, By);
+                    mfma8(Ax, Bx);
+                    WS_INTERLEAVE();
+                    ws_barrier();                       // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
+                    read_ops(u + 1, 0, Ax, Bx);
+                    mfma8(Ay, By);
+                    WS_INTERLEAVE();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            ws_barrier();                               // E1: residual tile + bias / temb table of this tile landed
+            {
+                // acc + bias + temb (+ residual) -> activation -> bf16 -> output tile, in place, accumulator layout
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    f32x4 bv[4];
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int co = ch * 64 + cb * 32 + 8 * g4 + 4 * h;
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb + co), t0 = *reinterpret_cast<const f32x4*>(tb + 128 + co);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bv[g4][e] = b0[e] + t0[e];
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb) {
+                        const int lp = (ph * 4 + nb) * 32 + (lane & 31);
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const int c8 = ch * 8 + cb * 4 + g4;
+                            char* a = ro + (lp * 16 + (c8 ^ (lp & 15))) * 16 + 8 * h;
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[cb][nb][4 * g4 + e] + bv[g4][e];
+                            if (has_res) {
+                                const bf16x4 r = *reinterpret_cast<const bf16x4*>(a);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+                            }
+                            bf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (bf16)dxmi_act_lin(v[e], slope);
+                            *reinterpret_cast<bf16x4*>(a) = o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[cb][nb][4 * g4 + e] = 0.f;
+                        }
+                    }
+                }
+            }
+            ws_barrier();                               // E2: output tile complete, the bulk movers may drain it
+            if (!more) break;
+            q += qstride;
+        }
+        return;
+    }
+
+    if (wave < 6) {
+        // ================================================================ weight loaders (waves 4, 5)
+        const int lw = wave - 4;
+        const char* const wb = reinterpret_cast<const char*>(p.w) + (size_t)lane * 16;
+        WsTile cur;
+        tile_of(q, cur);
+        // fragments lw*4 .. lw*4+3 of (chunk c, tap t) for cout tile cot -> ring slot
+        auto issue_tap = [&](int cot, int g) {
+            if (p.stagger & 1) return;                  // timing-only ablation (DXMI_CONV_WS_DBG): no weight stream
+            const int c = g / 9, t = g - c * 9;
+            char* dst = aring + (g % WS_RING) * WS_A_SLOT + lw * 4096;
+            // fragments (ks = lw, cbg = 0..3): contiguous 4 KiB of the packed weights
+            const char* src = wb + ((size_t)(t * p.KST + c * 2 + lw) * p.CB + cot * 4) * 1024;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                __builtin_amdgcn_global_load_lds(WS_GPTR(src + f * 1024), WS_LPTR(dst + f * 1024), 16, 0, 0);
+        };
+#pragma unroll 1
+        for (int g = 0; g < WS_RING - 1; ++g) issue_tap(cur.cot, g);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tap 0 landed (4 younger taps may be outstanding)
+        ws_barrier();                                       // P0
+        for (;;) {
+            const bool more = q + qstride < ntiles;
+            WsTile nxt = cur;
+            if (more) tile_of(q + qstride, nxt);
+            for (int g = 0; g < S; ++g) {
+                const int g3 = g + WS_RING - 1;
+                bool issued = true;
+                if (g3 < S) issue_tap(cur.cot, g3);
+                else if (more) issue_tap(nxt.cot, g3 - S);      // ring slot (g3 - S) % RING == g3 % RING: S % RING == 0 (host-checked)
+                else issued = false;
+                // at most taps g+2 .. g+5 (16 DMAs) outstanding -> tap g+1 landed; without a new issue (last steps of the last
+                // tile) the count of younger DMAs shrinks, so everything is awaited
+                if (issued) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ws_barrier();                                    // B_g
+            }
+            ws_barrier();                                        // E1
+            ws_barrier();                                        // E2
+            if (!more) break;
+            q += qstride;
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ==================================================================== bulk movers (waves 6, 7)
+    {
+        const int bw = wave - 6;
+        const int t2 = bw * 64 + lane;                     // 0..127 over the two waves
+        constexpr int HB2 = (WS_HALO_BLOCKS + 1) / 2;      // halo blocks per wave
+        // halo block k of this wave = block bw + 2k: lane -> (halo pixel, 16-byte slot); slot s of pixel (hy, hx) holds
+        // channel piece s ^ ((hx >> 2) & 3).  Source pixel of every block lane, recomputed per tile only.
+        int hsrc[HB2], hj8;
+        {
+            const int hpix = lane >> 2;
+            (void)hpix;
+        }
+        auto halo_plan = [&](const WsTile& t) {
+#pragma unroll
+            for (int k = 0; k < HB2; ++k) {
+                const int hp = (bw + 2 * k) * 16 + (lane >> 2);
+                const int hy = hp / HP, hx = hp - hy * HP;
+                const int iy = t.oy0 - 1 + hy, ix = t.ox0 - 1 + hx;
+                const bool ok = hy < HH && hx < TW + 2 && iy >= 0 && ix >= 0 && iy < (p.IH << ups) && ix < (p.IW << ups);
+                hsrc[k] = ok ? (t.n0 * p.IH + (iy >> ups)) * p.IW + (ix >> ups) : -1;
+            }
+        };
+        auto halo_issue = [&](int c, char* buf) {
+            if (p.stagger & 2) return;                  // timing-only ablation: no halo stream
+            const int cbase = c * 32;
+            const bool first = cbase < p.C0;
+            const bf16* src = first ? p.in0 : p.in1;
+            const int Cs = first ? p.C0 : p.C1;
+            const int coff = first ? cbase : cbase - p.C0;
+#pragma unroll
+            for (int k = 0; k < HB2; ++k) {
+                const int blk = bw + 2 * k;
+                const int hx = ((blk * 16 + (lane >> 2)) % HP);
+                const int j8 = ((lane & 3) ^ ((hx >> 2) & 3)) * 8;
+                const void* g = hsrc[k] >= 0 ? (const void*)(src + (size_t)hsrc[k] * Cs + coff + j8) : (const void*)&ws_zero16;
+                if (blk < WS_HALO_BLOCKS)
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(g), WS_LPTR(buf + blk * 1024), 16, 0, 0);
+            }
+        };
+        // output-tile pieces of this thread: L = k*128 + t2 (k = 0..31): pixel lp = k*8 + (t2 >> 4), cout piece (t2 & 15) ^ (lp & 15)
+        auto piece_off = [&](const WsTile& t, int k) -> long {
+            const int lp = k * 8 + (t2 >> 4);
+            const int c8 = (t2 & 15) ^ (lp & 15);
+            const int px = lp & (TW - 1), py = lp >> TWl;
+            return (long)((((size_t)t.n0 * p.OH + t.oy0 + py) * p.OW + t.ox0 + px) * p.Cout + t.cot * 128 + c8 * 8);
+        };
+        auto drain = [&](const WsTile& t) {
+            if (p.stagger & 4) return;                  // timing-only ablation: no output drain
+#pragma unroll 1
+            for (int k = 0; k < 32; k += 4) {
+                bf16x8 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(ro + ((k + u) * 128 + t2) * 16);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + piece_off(t, k + u)) = v[u];
+            }
+        };
+        auto fetch_tile_inputs = [&](const WsTile& t) {      // residual tile + bias / temb table
+            if (p.stagger & 8) return;                  // timing-only ablation: no residual / table fetch
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the drain's reads of these slots are complete
+            if (p.residual) {
+#pragma unroll 1
+                for (int k = 0; k < 32; ++k)
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.residual + piece_off(t, k)), WS_LPTR(ro + (k * 128 + bw * 64) * 16), 16, 0, 0);
+            }
+            if (bw == 0) {
+                // bias[128] (2 x 64 floats) and this image's temb row: 4-byte DMA, 256 B per instruction
+                if (p.bias) {
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + t.cot * 128 + lane), WS_LPTR(tb), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + t.cot * 128 + 64 + lane), WS_LPTR(tb + 64), 4, 0, 0);
+                }
+                if (p.addvec) {
+                    const float* av = p.addvec + (size_t)t.n0 * p.addvec_ld + t.cot * 128;
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + lane), WS_LPTR(tb + 128), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + 64 + lane), WS_LPTR(tb + 192), 4, 0, 0);
+                }
+            }
+        };
+        (void)hj8;
+
+        WsTile cur;
+        tile_of(q, cur);
+        // table rows that no DMA fills stay zero
+        if (bw == 0) {
+            if (!p.bias) { tb[lane] = 0.f; tb[64 + lane] = 0.f; }
+            if (!p.addvec) { tb[128 + lane] = 0.f; tb[192 + lane] = 0.f; }
+        }
+        halo_plan(cur);
+        halo_issue(0, halo0);
+        fetch_tile_inputs(cur);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ws_barrier();                                           // P0
+        bool have_prev = false;
+        WsTile prev = cur;
+        for (;;) {
+            const bool more = q + qstride < ntiles;
+            WsTile nxt = cur;
+            if (more) tile_of(q + qstride, nxt);
+            for (int c = 0; c < nchunks; ++c) {
+                // next halo image first (it must be complete at this chunk's last barrier), bulk traffic behind it
+                const bool wrap = c + 1 == nchunks;
+                if (wrap && more) halo_plan(nxt);
+                if (!wrap || more) halo_issue(wrap ? 0 : c + 1, halo0 + ((c + 1) & 1) * WS_HALO);
+                if (c == 0 && have_prev) {
+                    drain(prev);                                 // previous tile out ...
+                    fetch_tile_inputs(cur);                      // ... this tile's residual / table in (same LDS slots)
+                }
+                for (int t = 0; t < 9; ++t) {
+                    if (t == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // halo image (and everything older) landed
+                    ws_barrier();                                // B_g
+                }
+            }
+            ws_barrier();                                        // E1 (vmcnt(0) above covers the residual tile and the table)
+            ws_barrier();                                        // E2
+            prev = cur;
+            have_prev = true;
+            if (!more) break;
+            q += qstride;
+            cur = nxt;
+        }
+        drain(prev);
+    }
+}
+
+}  // namespace
+
+// Launches the wave-specialised kernel when the shape is in its scope; returns 1 otherwise (caller falls back).
+int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
+    static const int enabled = getenv("DXMI_CONV_WS") ? atoi(getenv("DXMI_CONV_WS")) : 0;
+    if (!enabled) return 1;
+    if (a.in_mode != DXMI_IN_NHWC_BF16 || a.out_mode != DXMI_OUT_NHWC_BF16) return 1;
+    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups == 2 || a.mask_src || a.act == DXMI_ACT_SILU) return 1;
+    if (a.Cout % 128 != 0 || (a.C0 + a.C1) % 32 != 0 || a.C0 % 32 != 0) return 1;
+    const int TW = a.OW >= 32 ? 32 : a.OW;
+    if (TW != 32 && TW != 16) return 1;
+    const int TH = 256 / TW;
+    if (a.OH % TH != 0 || a.OW % TW != 0) return 1;
+    const int nchunks = (a.C0 + a.C1) / 32;
+    if ((9 * nchunks) % WS_RING != 0 || nchunks % 2 != 0) return 1;   // ring slot / halo image of a step must not depend on the tile
+    if (kernel_id) {
+        *kernel_id = 400000;
+        return DXMI_OK;
+    }
+    ConvArgs b = a;
+    b.SUBS = 1;
+    b.PT = a.N * (a.OH / TH) * (a.OW / TW);
+    b.CT = a.Cout / 128;
+    b.tile_px = 256;
+    static const int dbg = getenv("DXMI_CONV_WS_DBG") ? atoi(getenv("DXMI_CONV_WS_DBG")) : 0;
+    b.stagger = dbg;
+    const size_t lds = 2 * WS_HALO + WS_A_RING + WS_RO + WS_TB;
+    int grid = b.PT * b.CT;
+    if (grid > 256) grid = 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ws_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ws_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    if (TW == 32) hipLaunchKernelGGL(conv_ws_kernel<32>, dim3(grid), dim3(512), lds, st, b);
+    else hipLaunchKernelGGL(conv_ws_kernel<16>, dim3(grid), dim3(512), lds, st, b);
+    DXMI_CHECK_LAUNCH("dxmi_conv2d_fwd(ws)");
+    return DXMI_OK;
+}
