@@ -147,7 +147,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                     read_ops(u, 1, Ay, By);
                     mfma8(Ax, Bx);
                     WS_INTERLEAVE();
-                    ws_barrier();                       // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
+                    if (!(p.stagger & 16)) ws_barrier();                       // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
                     read_ops(u + 1, 0, Ax, Bx);
                     mfma8(Ay, By);
                     WS_INTERLEAVE();
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 // tile) the count of younger DMAs shrinks, so everything is awaited
                 if (issued) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                ws_barrier();                                    // B_g
+                if (!(p.stagger & 16)) ws_barrier();                                    // B_g
             }
             ws_barrier();                                        // E1
             ws_barrier();                                        // E2
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 }
                 for (int t = 0; t < 9; ++t) {
                     if (t == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // halo image (and everything older) landed
-                    ws_barrier();                                // B_g
+                    if (!(p.stagger & 16)) ws_barrier();                                // B_g
                 }
             }
             ws_barrier();                                        // E1 (vmcnt(0) above covers the residual tile and the table)
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
 
 // Launches the wave-specialised kernel when the shape is in its scope; returns 1 otherwise (caller falls back).
 int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
-    static const int enabled = getenv("DXMI_CONV_WS") ? atoi(getenv("DXMI_CONV_WS")) : 0;
+    static const int enabled = getenv("DXMI_CONV_WS") ? atoi(getenv("DXMI_CONV_WS")) : 1;   // DXMI_CONV_WS=0: conv_pipe_kernel for every shape
     if (!enabled) return 1;
     if (a.in_mode != DXMI_IN_NHWC_BF16 || a.out_mode != DXMI_OUT_NHWC_BF16) return 1;
     if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups == 2 || a.mask_src || a.act == DXMI_ACT_SILU) return 1;
