@@ -84,6 +84,8 @@ def spawn_ranks(n):
 # ----------------------------------------------------------------------------------------------- pieces
 def kernel_name(kid):
     """dxmi_conv2d_kernel_id -> the template instantiation name rocprofv3 prints."""
+    if kid >= 500000:
+        return "conv1x1_rw_kernel"
     if kid >= 400000:
         return "conv_ws_kernel"
     if kid >= 300000:
