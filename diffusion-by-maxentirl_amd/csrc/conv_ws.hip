@@ -32,7 +32,7 @@ constexpr int WS_RING = 6;                   // ring slots (steps): five steps o
 constexpr int WS_A_RING = WS_RING * WS_A_SLOT;
 constexpr int WS_RO = 256 * 256;             // output / residual tile: 256 px x 128 co bf16
 constexpr int WS_TB = 1024;                  // bias[128] | temb[128] fp32
-constexpr int WS_HALO_BLOCKS = 23;           // 1-KiB blocks of a halo image (34x10 or 20x18 pixels x 64 B)
+constexpr int WS_HALO_BLOCKS = 22;           // 1-KiB blocks of a halo image (34x10 or 18x18 pixels x 64 B)
 constexpr int WS_HALO = WS_HALO_BLOCKS * 1024;
 
 __device__ uint4 ws_zero16 = {0u, 0u, 0u, 0u};   // source of zero-padding pixels
@@ -53,18 +53,41 @@ __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      \
     } while (0)
 
+// 16 MFMAs (16 cycles each) with 4 / 8 operand reads spread between them
+#define WS_INTERLEAVE_4()                                       \
+    do {                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  \
+        }                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      \
+    } while (0)
+#define WS_INTERLEAVE_8()                                       \
+    do {                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  \
+        }                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      \
+    } while (0)
+
 struct WsTile {
     int cot, n0, oy0, ox0;
 };
 
 // Halo image: pixel (hy, hx) of the (TH+2) x (TW+2) halo at row pitch HP pixels, 64 B (32 channels) per pixel in four
-// 16-byte slots; channel piece j sits in slot j ^ ((hx >> 2) & 3).  With HP = 34 (TW 32) / 20 (TW 16) the ds_read_b128
-// lane groups of every (tap, k-step) are bank-conflict free (brute-forced), and because the swizzle depends on hx only, a
-// lane's B-operand address is one of six precomputed bases (kx x k-step) plus a compile-time offset: no address arithmetic
-// in the MFMA loop.
+// 16-byte slots; channel piece j sits in slot j ^ (2 * ((hx >> 2) & 1)).  The MFMA shape is 16x16x32 (on random data the chip
+// holds a higher clock on it than on 32x32x16 at equal cycles per FLOP: MI355X_MICROARCH.md, DVFS give-back item 7): a B
+// fragment is 16 consecutive pixels x the whole 64-byte row (lane = pixel + 16 * channel piece), one MFMA consumes a whole
+// 32-channel chunk of one tap.  With that swizzle the ds_read_b128 lane groups of every tap are bank-conflict free at
+// HP = 34 (TW 32) and HP = 18 (TW 16) (brute-forced), and because it depends on hx only, a lane's B-operand address is one
+// of three precomputed bases (kx) plus a compile-time offset: no address arithmetic in the MFMA loop.
+// The weight ring keeps the 32x32x16 fragment packing of pack_conv_weight (shared with conv_pipe): the 16x16x32 A fragment
+// (16 couts x 32 channels) of cout block cb16 is lanes (cb16 & 1) * 16 .. + 15 of both lane halves of the two k-step
+// fragments of cout block cb16 >> 1 — a per-lane base plus a compile-time offset as well, bank-conflict free as it lies.
 template <int TW>
 __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
-    constexpr int TH = 256 / TW, HP = TW == 32 ? 34 : 20, HH = TH + 2, RPB = 32 / TW, TWl = TW == 32 ? 5 : 4;
+    constexpr int TH = 256 / TW, HP = TW == 32 ? 34 : 18, HH = TH + 2, TWl = TW == 32 ? 5 : 4;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const halo0 = smem;
     char* const aring = smem + 2 * WS_HALO;
@@ -93,102 +116,106 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
     const int qstride = gridDim.x;
 
     if (wave < 4) {
-        // ================================================================ MFMA waves
-        const int ch = wave & 1, ph = wave >> 1, h = lane >> 5;
-        const int x = lane & (TW - 1), yl = (lane & 31) >> TWl;
-        // B-operand bases [kx][ks] (relative to a halo image, tap row 0, this wave's first pixel block)
-        int bbase[3][2];
+        // ================================================================ MFMA waves: 64 couts (ch) x 128 pixels (ph)
+        const int ch = wave & 1, ph = wave >> 1;
+        const int px = lane & 15, kg = lane >> 4;      // B: pixel / channel piece; A: cout / 8-channel group; D: pixel / 4-cout group
+        // 16-pixel block nb (0..7) of this wave is tile pixels (ph*8 + nb)*16 ..: row (ph*8 + nb) >> (TW / 32), column ((nb & 1) * 16 at TW 32)
+        constexpr int BROW = TW == 32 ? 2 : 1;         // blocks per tile row
+        int bbase[3];
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
+            bbase[kx] = ((ph * (8 / BROW) * HP + px + kx) * 64) + ((kg ^ (2 * (((px + kx) >> 2) & 1))) << 4);
+        const char* const abase = aring + ch * 2048 + ((kg >> 1) * 4096) + ((px + 32 * (kg & 1)) << 4);   // + slot*8192 + (cb16>>1)*1024 + (cb16&1)*256
+        f32x4 acc[4][8];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                bbase[kx][ks] = (((ph * 4 * RPB + yl) * HP + x + kx) * 64) + (((ks * 2 + h) ^ (((x + kx) >> 2) & 3)) * 16);
-        const char* const abase = aring + ch * 2048 + lane * 16;      // + slot*8192 + ks*4096 + cb*1024
-        f32x16 acc[2][4];
+        for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+            for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb)
+                for (int r = 0; r < 4; ++r) acc[cb][nb][r] = 0.f;
+        bf16x8 A0[4], A1[4], Bx[4], By[4];
+        // operands of step u of a chunk PAIR (u = 0..17: chunk parity u / 9, tap u % 9; u = 18 is the first step of the next
+        // pair / the next tile): ring slot, halo image and tap offset are compile-time constants
+        auto read_a = [&](int u, bf16x8 (&A)[4]) {
+            const char* as = abase + (u % WS_RING) * WS_A_SLOT;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[cb][nb][r] = 0.f;
-        bf16x8 Ax[2], Bx[4], Ay[2], By[4];
-        // operands of k-step ks of step u of a chunk PAIR (u = 0..17: chunk parity u / 9, tap u % 9; u = 18 is the first
-        // step of the next pair / the next tile): ring slot, halo image and tap offset are compile-time constants
-        auto read_ops = [&](int u, int ks, bf16x8 (&A)[2], bf16x8 (&B)[4]) {
-            const int t = u % 9, ky = t / 3, kx = t % 3;
-            const char* hb = halo0 + ((u / 9) & 1) * WS_HALO + bbase[kx][ks];
-            const char* as = abase + (u % WS_RING) * WS_A_SLOT + ks * 4096;
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) A[cb] = *reinterpret_cast<const bf16x8*>(as + cb * 1024);
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) B[nb] = *reinterpret_cast<const bf16x8*>(hb + (RPB * nb + ky) * HP * 64);
+            for (int cb = 0; cb < 4; ++cb) A[cb] = *reinterpret_cast<const bf16x8*>(as + (cb >> 1) * 1024 + (cb & 1) * 256);
         };
-        auto mfma8 = [&](const bf16x8 (&A)[2], const bf16x8 (&B)[4]) {
+        auto read_b = [&](int u, int half, bf16x8 (&B)[4]) {
+            const int t = u % 9, ky = t / 3, kx = t % 3;
+            const char* hb = halo0 + ((u / 9) & 1) * WS_HALO + bbase[kx];
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
+            for (int i = 0; i < 4; ++i) {
+                const int nb = half * 4 + i;
+                B[i] = *reinterpret_cast<const bf16x8*>(hb + ((nb / BROW + ky) * HP + (nb % BROW) * 16) * 64);
+            }
+        };
+        auto mfma16 = [&](const bf16x8 (&A)[4], const bf16x8 (&B)[4], int half) {
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) acc[cb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[cb], B[nb], acc[cb][nb], 0, 0, 0);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[cb][half * 4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[cb], B[i], acc[cb][half * 4 + i], 0, 0, 0);
         };
         const float slope = dxmi_act_slope(p.act);
         const bool has_res = p.residual != nullptr;
 
         __builtin_amdgcn_s_setprio(3);                  // the MFMA stream outranks the loaders that share its SIMD
         ws_barrier();                                   // P0: tap 0 and the first halo chunk have landed
-        read_ops(0, 0, Ax, Bx);
+        read_a(0, A0);
+        read_b(0, 0, Bx);
         for (;;) {
             const bool more = q + qstride < ntiles;
             // K loop: two chunks (18 steps) of straight-line code per iteration, no branches inside (a branch makes hipcc wait
-            // lgkmcnt(0) at the join, which exposes the latency of the operand reads just issued).  The first operands of
-            // the step after the last one — the next tile's first step, whose weights and halo image are already in LDS
-            // when the last barrier of this tile opens — are requested unconditionally.
+            // lgkmcnt(0) at the join, which exposes the latency of the operand reads just issued).  Every half step (16 MFMAs)
+            // requests the operands of the next one: the other 4 pixel blocks of this step, then — behind the barrier that
+            // says they landed — the weights and first 4 blocks of the next step.  The first operands of the step after the
+            // last one (the next tile's first step, already in LDS when the last barrier of this tile opens) are requested
+            // unconditionally.
             for (int c = 0; c < nchunks; c += 2) {
 #pragma unroll
                 for (int u = 0; u < 18; ++u) {
-                    read_ops(u, 1, Ay, By);
-                    mfma8(Ax, Bx);
-                    WS_INTERLEAVE();
-                    if (!(p.stagger & 16)) ws_barrier();                       // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
-                    read_ops(u + 1, 0, Ax, Bx);
-                    mfma8(Ay, By);
-                    WS_INTERLEAVE();
+                    read_b(u, 1, By);
+                    if (u & 1) mfma16(A1, Bx, 0); else mfma16(A0, Bx, 0);
+                    WS_INTERLEAVE_4();
+                    if (!(p.stagger & 16)) ws_barrier();   // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
+                    if (u & 1) read_a(u + 1, A0); else read_a(u + 1, A1);
+                    read_b(u + 1, 0, Bx);
+                    if (u & 1) mfma16(A1, By, 1); else mfma16(A0, By, 1);
+                    WS_INTERLEAVE_8();
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             ws_barrier();                               // E1: residual tile + bias / temb table of this tile landed
             {
-                // acc + bias + temb (+ residual) -> activation -> bf16 -> output tile, in place, accumulator layout
+                // acc + bias + temb (+ residual) -> activation -> bf16 -> output tile, in place, accumulator layout:
+                // lane = pixel (lane & 15) of a 16-pixel block, couts 4 * (lane >> 4) .. + 3 of a 16-cout block
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    f32x4 bv[4];
+                for (int cb = 0; cb < 4; ++cb) {
+                    const int co = ch * 64 + cb * 16 + 4 * kg;
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb + co), t0 = *reinterpret_cast<const f32x4*>(tb + 128 + co);
+                    f32x4 bv;
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int co = ch * 64 + cb * 32 + 8 * g4 + 4 * h;
-                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb + co), t0 = *reinterpret_cast<const f32x4*>(tb + 128 + co);
+                    for (int e = 0; e < 4; ++e) bv[e] = b0[e] + t0[e];
+                    const int c8 = ch * 8 + cb * 2 + (kg >> 1);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) bv[g4][e] = b0[e] + t0[e];
-                    }
+                    for (int nb = 0; nb < 8; ++nb) {
+                        const int lp = (ph * 8 + nb) * 16 + px;
+                        char* a = ro + (lp * 16 + (c8 ^ (lp & 15))) * 16 + 8 * (kg & 1);
+                        f32x4 v;
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) {
-                        const int lp = (ph * 4 + nb) * 32 + (lane & 31);
+                        for (int e = 0; e < 4; ++e) v[e] = acc[cb][nb][e] + bv[e];
+                        if (has_res) {
+                            const bf16x4 r = *reinterpret_cast<const bf16x4*>(a);
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const int c8 = ch * 8 + cb * 4 + g4;
-                            char* a = ro + (lp * 16 + (c8 ^ (lp & 15))) * 16 + 8 * h;
-                            f32x4 v;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = acc[cb][nb][4 * g4 + e] + bv[g4][e];
-                            if (has_res) {
-                                const bf16x4 r = *reinterpret_cast<const bf16x4*>(a);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
-                            }
-                            bf16x4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (bf16)dxmi_act_lin(v[e], slope);
-                            *reinterpret_cast<bf16x4*>(a) = o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[cb][nb][4 * g4 + e] = 0.f;
+                            for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
                         }
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)dxmi_act_lin(v[e], slope);
+                        *reinterpret_cast<bf16x4*>(a) = o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[cb][nb][e] = 0.f;
                     }
                 }
             }
@@ -252,7 +279,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         const int t2 = bw * 64 + lane;                     // 0..127 over the two waves
         constexpr int HB2 = (WS_HALO_BLOCKS + 1) / 2;      // halo blocks per wave
         // halo block k of this wave = block bw + 2k: lane -> (halo pixel, 16-byte slot); slot s of pixel (hy, hx) holds
-        // channel piece s ^ ((hx >> 2) & 3).  Source pixel of every block lane, recomputed per tile only.
+        // channel piece s ^ (2 * ((hx >> 2) & 1)).  Source pixel of every block lane, recomputed per tile only.
         int hsrc[HB2], hj8;
         {
             const int hpix = lane >> 2;
@@ -279,7 +306,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             for (int k = 0; k < HB2; ++k) {
                 const int blk = bw + 2 * k;
                 const int hx = ((blk * 16 + (lane >> 2)) % HP);
-                const int j8 = ((lane & 3) ^ ((hx >> 2) & 3)) * 8;
+                const int j8 = ((lane & 3) ^ (2 * ((hx >> 2) & 1))) * 8;
                 const void* g = hsrc[k] >= 0 ? (const void*)(src + (size_t)hsrc[k] * Cs + coff + j8) : (const void*)&ws_zero16;
                 if (blk < WS_HALO_BLOCKS)
                     __builtin_amdgcn_global_load_lds(WS_GPTR(g), WS_LPTR(buf + blk * 1024), 16, 0, 0);
