@@ -25,6 +25,23 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
+#ifdef DXMI_CONV_STAMPS
+// timing-only build (make STAMPS=1): cycles MFMA wave 0 of every workgroup spends in each step barrier (tools/ws_stamps.py)
+__device__ unsigned g_ws_wait[256][160];
+extern "C" int dxmi_debug_read_ws_stamps(void* dst, int bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws_wait), bytes, 0, hipMemcpyDeviceToHost);
+}
+#define WS_STAMPED_BARRIER(idx)                                                                     \
+    do {                                                                                            \
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime();                                \
+        ws_barrier();                                                                               \
+        const unsigned long long t1_ = __builtin_amdgcn_s_memtime();                                \
+        if (wave == 0 && lane == 0 && (idx) < 160 && blockIdx.x < 256) g_ws_wait[blockIdx.x][(idx)] = (unsigned)(t1_ - t0_); \
+    } while (0)
+#else
+#define WS_STAMPED_BARRIER(idx) ws_barrier()
+#endif
+
 namespace {
 
 constexpr int WS_A_SLOT = 8192;              // one (chunk, tap): 2 k-steps x 4 cout blocks x 1 KiB fragments
@@ -70,6 +87,25 @@ __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0
         }                                                       \
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      \
     } while (0)
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate): n is rounded DOWN to an even
+// count, which only waits for more
+__device__ __forceinline__ void ws_wait_vm(int n) {
+    switch (n >> 1) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); break;
+    }
+}
 
 struct WsTile {
     int cot, n0, oy0, ox0;
@@ -164,6 +200,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         ws_barrier();                                   // P0: tap 0 and the first halo chunk have landed
         read_a(0, A0);
         read_b(0, 0, Bx);
+        int stamp_i = 0;                                // stamp build: index of the tile's first step
         for (;;) {
             const bool more = q + qstride < ntiles;
             // K loop: two chunks (18 steps) of straight-line code per iteration, no branches inside (a branch makes hipcc wait
@@ -178,7 +215,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                     read_b(u, 1, By);
                     if (u & 1) mfma16(A1, Bx, 0); else mfma16(A0, Bx, 0);
                     WS_INTERLEAVE_4();
-                    if (!(p.stagger & 16)) ws_barrier();   // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
+                    if (!(p.stagger & 16)) WS_STAMPED_BARRIER(stamp_i + c * 9 + u);   // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
                     if (u & 1) read_a(u + 1, A0); else read_a(u + 1, A1);
                     read_b(u + 1, 0, Bx);
                     if (u & 1) mfma16(A1, By, 1); else mfma16(A0, By, 1);
@@ -222,6 +259,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             ws_barrier();                               // E2: output tile complete, the bulk movers may drain it
             if (!more) break;
             q += qstride;
+            stamp_i += S;
         }
         return;
     }
@@ -295,7 +333,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 hsrc[k] = ok ? (t.n0 * p.IH + (iy >> ups)) * p.IW + (ix >> ups) : -1;
             }
         };
-        auto halo_issue = [&](int c, char* buf) {
+        auto halo_issue = [&](int c, char* buf, int ka, int kb) {     // blocks ka .. kb-1 of this wave's share (compile-time range)
             if (p.stagger & 2) return;                  // timing-only ablation: no halo stream
             const int cbase = c * 32;
             const bool first = cbase < p.C0;
@@ -304,6 +342,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             const int coff = first ? cbase : cbase - p.C0;
 #pragma unroll
             for (int k = 0; k < HB2; ++k) {
+                if (k < ka || k >= kb) continue;
                 const int blk = bw + 2 * k;
                 const int hx = ((blk * 16 + (lane >> 2)) % HP);
                 const int j8 = ((lane & 3) ^ (2 * ((hx >> 2) & 1))) * 8;
@@ -330,26 +369,45 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 for (int u = 0; u < 4; ++u) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + piece_off(t, k + u)) = v[u];
             }
         };
-        auto fetch_tile_inputs = [&](const WsTile& t) {      // residual tile + bias / temb table
-            if (p.stagger & 8) return;                  // timing-only ablation: no residual / table fetch
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the drain's reads of these slots are complete
-            if (p.residual) {
+        auto fetch_table = [&](const WsTile& t) {            // bias[128] (2 x 64 floats) and this image's temb row: 4-byte DMA, 256 B per instruction
+            if (bw != 0 || (p.stagger & 8)) return;
+            if (p.bias) {
+                __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + t.cot * 128 + lane), WS_LPTR(tb), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + t.cot * 128 + 64 + lane), WS_LPTR(tb + 64), 4, 0, 0);
+            }
+            if (p.addvec) {
+                const float* av = p.addvec + (size_t)t.n0 * p.addvec_ld + t.cot * 128;
+                __builtin_amdgcn_global_load_lds(WS_GPTR(av + lane), WS_LPTR(tb + 128), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(WS_GPTR(av + 64 + lane), WS_LPTR(tb + 192), 4, 0, 0);
+            }
+        };
+        const bool do_res = p.residual != nullptr && !(p.stagger & 8);
+        auto fetch_residual = [&](const WsTile& t, int k0, int k1) {
+            if (!do_res) return;
 #pragma unroll 1
-                for (int k = 0; k < 32; ++k)
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.residual + piece_off(t, k)), WS_LPTR(ro + (k * 128 + bw * 64) * 16), 16, 0, 0);
-            }
-            if (bw == 0) {
-                // bias[128] (2 x 64 floats) and this image's temb row: 4-byte DMA, 256 B per instruction
-                if (p.bias) {
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + t.cot * 128 + lane), WS_LPTR(tb), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + t.cot * 128 + 64 + lane), WS_LPTR(tb + 64), 4, 0, 0);
+            for (int k = k0; k < k1; ++k)
+                __builtin_amdgcn_global_load_lds(WS_GPTR(p.residual + piece_off(t, k)), WS_LPTR(ro + (k * 128 + bw * 64) * 16), 16, 0, 0);
+        };
+        // pieces k0 .. k1-1 of this wave's share of the tile switch: previous tile's output pieces out, this tile's residual
+        // pieces into the same LDS rows (a wave refills exactly the rows it drained; its reads are complete when the stores
+        // that consume them have issued).  Returns the number of vector-memory operations it issued.
+        const bool do_drain = !(p.stagger & 4);
+        auto tile_switch = [&](const WsTile& pt, const WsTile& ct, int k0, int k1) -> int {
+#pragma unroll 1
+            for (int k = k0; k < k1; k += 4) {
+                const int n = k1 - k < 4 ? k1 - k : 4;
+                if (do_drain) {
+                    bf16x8 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u < n) v[u] = *reinterpret_cast<const bf16x8*>(ro + ((k + u) * 128 + t2) * 16);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (u < n) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + piece_off(pt, k + u)) = v[u];
                 }
-                if (p.addvec) {
-                    const float* av = p.addvec + (size_t)t.n0 * p.addvec_ld + t.cot * 128;
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + lane), WS_LPTR(tb + 128), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + 64 + lane), WS_LPTR(tb + 192), 4, 0, 0);
-                }
+                fetch_residual(ct, k, k + n);
             }
+            return (k1 - k0) * ((do_drain ? 1 : 0) + (do_res ? 1 : 0));
         };
         (void)hj8;
 
@@ -361,31 +419,57 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             if (!p.addvec) { tb[128 + lane] = 0.f; tb[192 + lane] = 0.f; }
         }
         halo_plan(cur);
-        halo_issue(0, halo0);
-        fetch_tile_inputs(cur);
+        halo_issue(0, halo0, 0, HB2);
+        fetch_table(cur);
+        fetch_residual(cur, 0, 32);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ws_barrier();                                           // P0
         bool have_prev = false;
         WsTile prev = cur;
+        // Neither the halo image of the next chunk (11 DMAs per wave) nor the tile switch (64 KB out + 64 KB residual in per
+        // CU) is issued in one burst: a DMA costs its wave ~100+ cycles of issue, and a mover that arrives late at a step
+        // barrier stalls the MFMA waves (stamp build: 1.5k cycles per chunk for the halo burst, up to 6.6k with the tile
+        // switch behind it).  Per step a mover issues two halo blocks (steps 0-5) and its share of the tile switch's pieces
+        // (spread over the first nchunks-1 chunks, steps 0-7).  vmcnt retires in order: the wait for the halo image at a
+        // chunk's last step leaves in flight exactly the tile-switch operations issued after the last halo block.
+        const int kpc = (32 + nchunks - 2) / (nchunks - 1);      // tile-switch pieces per chunk
+        const int pps = (kpc + 7) >> 3;                          // ... per step
         for (;;) {
             const bool more = q + qstride < ntiles;
             WsTile nxt = cur;
             if (more) tile_of(q + qstride, nxt);
             for (int c = 0; c < nchunks; ++c) {
-                // next halo image first (it must be complete at this chunk's last barrier), bulk traffic behind it
                 const bool wrap = c + 1 == nchunks;
+                if (c == 0 && have_prev) fetch_table(cur);       // older than this chunk's halo DMAs: complete at its last barrier
                 if (wrap && more) halo_plan(nxt);
-                if (!wrap || more) halo_issue(wrap ? 0 : c + 1, halo0 + ((c + 1) & 1) * WS_HALO);
-                if (c == 0 && have_prev) {
-                    drain(prev);                                 // previous tile out ...
-                    fetch_tile_inputs(cur);                      // ... this tile's residual / table in (same LDS slots)
+                const bool do_halo = !wrap || more;
+                char* const hbuf = halo0 + ((c + 1) & 1) * WS_HALO;
+                const int hc = wrap ? 0 : c + 1;
+                int k0 = 32, k1 = 32;
+                if (have_prev && !wrap) {
+                    k0 = c * kpc < 32 ? c * kpc : 32;
+                    k1 = k0 + kpc < 32 ? k0 + kpc : 32;
                 }
+                int young = 0;
+#pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    if (t == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // halo image (and everything older) landed
+                    if (t < 6 && do_halo) halo_issue(hc, hbuf, 2 * t, 2 * t + 2);
+                    if (t < 8) {
+                        const int ka = k0 + t * pps < k1 ? k0 + t * pps : k1, kb = ka + pps < k1 ? ka + pps : k1;
+                        if (ka < kb) {
+                            const int n = tile_switch(prev, cur, ka, kb);
+                            if (t >= 5) young += n;
+                        }
+                    }
+                    if (t == 8) {
+                        // halo image (and everything older) landed; at the last chunk E1 needs the whole residual tile
+                        if (wrap) ws_wait_vm(0);
+                        else ws_wait_vm(young);
+                    }
                     if (!(p.stagger & 16)) ws_barrier();                                // B_g
                 }
             }
-            ws_barrier();                                        // E1 (vmcnt(0) above covers the residual tile and the table)
+            ws_barrier();                                        // E1
             ws_barrier();                                        // E2
             prev = cur;
             have_prev = true;

@@ -1,0 +1,31 @@
+"""GPU box, stamp build (make -C diffusion-by-maxentirl_amd/csrc STAMPS=1): cycles MFMA wave 0 of every conv_ws workgroup waits in
+each step barrier (s_memtime ticks), for one layer: python tools/ws_stamps.py CIN COUT H RES"""
+import ctypes, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "diffusion-by-maxentirl_amd"))
+from dxmi_hip import ops, _lib
+dev = "cuda:0"
+cin, cout, h, res = [int(v) for v in (sys.argv[1:5] if len(sys.argv) > 4 else (128, 128, 32, 0))]
+B = 256
+x = torch.randn(B, h, h, cin, device=dev).to(torch.bfloat16)
+pw = ops.pack_conv_weight(torch.randn(cout, cin, 3, 3, device=dev) * 0.05)
+bias = torch.randn(cout, device=dev)
+r = torch.randn(B, h, h, cout, device=dev).to(torch.bfloat16) if res else None
+out = torch.empty(B, h, h, cout, device=dev, dtype=torch.bfloat16)
+for _ in range(5):
+    ops.conv2d(x, pw, bias=bias, residual=r, out=out)
+torch.cuda.synchronize()
+lib = ctypes.CDLL(_lib.LIB_PATH)
+buf = np.zeros((256, 160), dtype=np.uint32)
+lib.dxmi_debug_read_ws_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes)
+w = buf.astype(np.int64)
+np.set_printoptions(linewidth=250, suppress=True)
+S = 9 * cin // 32
+n = min(160, 2 * S)
+med = np.median(w[:, :n], axis=0)
+print(f"{cin}->{cout} @{h} res={res}: steps per tile {S}; median barrier wait per step (ticks), first {n} steps:")
+for i in range(0, n, 9):
+    print(f"  steps {i:3d}..{i+8:3d}:", " ".join(f"{v:6.0f}" for v in med[i:i + 9]))
+print("sum over a tile (median wg):", med[:S].sum(), " second tile:", med[S:2 * S].sum() if n >= 2 * S else "-")
