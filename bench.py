@@ -85,9 +85,9 @@ def spawn_ranks(n):
 def kernel_name(kid):
     """dxmi_conv2d_kernel_id -> the template instantiation name rocprofv3 prints."""
     if kid >= 500000:
-        return "conv1x1_rw_kernel"
+        return f"conv1x1_rw_kernel<{(kid // 1000) % 10}, {(kid // 10) % 100}, {'true' if kid % 10 else 'false'}>"
     if kid >= 400000:
-        return "conv_ws_kernel"
+        return f"conv_ws_kernel<{kid - 400000}>"
     if kid >= 300000:
         return "conv_stem_kernel"
     if kid >= 200000:

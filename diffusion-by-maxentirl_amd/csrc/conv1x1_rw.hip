@@ -223,7 +223,8 @@ int conv1x1_rw_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     const long px = (long)a.N * a.OH * a.OW;
     if (px % 64 != 0 || px / 64 < 512) return 1;          // small maps: the per-tile kernel fills the chip better
     if (kernel_id) {
-        *kernel_id = 500000;
+        const int nch = K / 128;
+        *kernel_id = 500000 + nch * 1000 + (nch > 3 ? 6 : 3) * 10 + (a.residual ? 1 : 0);   // conv1x1_rw_kernel<NCH, R, RES>
         return DXMI_OK;
     }
     ConvArgs b = a;

@@ -497,7 +497,7 @@ int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     const int nchunks = (a.C0 + a.C1) / 32;
     if ((9 * nchunks) % WS_RING != 0 || nchunks % 2 != 0) return 1;   // ring slot / halo image of a step must not depend on the tile
     if (kernel_id) {
-        *kernel_id = 400000;
+        *kernel_id = 400000 + TW;    // conv_ws_kernel<TW>
         return DXMI_OK;
     }
     ConvArgs b = a;
