@@ -2,10 +2,10 @@
 
 The reference wraps `sampler.net` and `v` in torch DDP (train_cifar10.py:298-309): NCCL all-reduce of
 25 MB buckets during every backward, parameters broadcast from rank 0 at construction.  Here the
-exchange is explicit and flat: after a backward, all gradients of a module are packed by ONE multi-tensor
-copy into a PERSISTENT contiguous fp32 buffer (143 MB U-Net / 20.5 MB value net, allocated once), averaged by
-ONE RCCL all-reduce (xGMI is point-to-point: one large message per link beats many small ones) and unpacked by
-one multi-tensor copy.  Backend "nccl" == RCCL on ROCm (ReduceOp.AVG: the division happens inside the
+exchange is explicit and flat: the gradients of a module live in ONE PERSISTENT contiguous buffer (143 MB U-Net /
+20.5 MB value net, allocated once) cut into ~32 MB buckets (xGMI is point-to-point: few large messages per link beat
+many small ones); a bucket's all-reduce is launched as soon as autograd has produced its gradients, so the exchange
+overlaps the rest of the backward, and the means are scattered back by one multi-tensor copy.  Backend "nccl" == RCCL on ROCm (ReduceOp.AVG: the division happens inside the
 collective); "gloo" for the CPU tests (SUM, then one division).
 The reduced set is the module's FIXED list of trainable parameters — a parameter that received no gradient on
 this rank contributes zeros — so every rank always issues the same collective with the same element count
@@ -40,37 +40,131 @@ def broadcast_parameters(module, src=0):
 
 
 class FlatGradSync:
-    """All-reduce(mean) of a module's gradients through one persistent flat buffer."""
+    """All-reduce(mean) of a module's gradients through one persistent flat buffer, overlapped with the backward pass.
 
-    def __init__(self, module, wire_dtype=torch.float32, force=False):
+    The flat buffer is laid out in REVERSE parameter order (gradients arrive roughly last layer first) and cut into buckets
+    of ~`bucket_mb`.  A post-accumulate-grad hook packs each gradient into its slice the moment autograd has produced it; when
+    the next bucket in order is complete its all-reduce is launched asynchronously (RCCL: on the collective's own stream,
+    behind an event on the compute stream), so the exchange of the deep layers runs under the backward of the shallow ones
+    (train_cifar10.py:298-309 gets the same from DDP's 25 MB buckets).  Buckets are always launched in index order, so every
+    rank issues the same sequence of collectives.  `sync()` (== `__call__`) after the backward: packs whatever the hooks did not
+    see (a parameter without gradient contributes zeros), launches the remaining buckets, waits, and scatters the means back
+    into the `.grad` tensors with one multi-tensor copy.  Two backward passes without a `sync()` in between fall back to
+    one blocking all-reduce of the accumulated gradients."""
+
+    def __init__(self, module, wire_dtype=torch.float32, force=False, bucket_mb=32, overlap=True):
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.wire_dtype = wire_dtype
         self.force = force            # run the collective even on a 1-rank group (tests of the RCCL path)
         self.flat = None
         self.views = None
+        # flat layout: reversed parameter order, buckets = contiguous slices
+        self.order = list(reversed(range(len(self.params))))
+        itemsize = torch.empty((), dtype=wire_dtype).element_size()
+        limit = max(1, int(bucket_mb * (1 << 20) / itemsize))
+        self.offset = [0] * len(self.params)
+        self.bucket_of = [0] * len(self.params)
+        self.buckets = []             # (start, end, n_params)
+        pos, start, count = 0, 0, 0
+        for i in self.order:
+            self.offset[i] = pos
+            self.bucket_of[i] = len(self.buckets)
+            pos += self.params[i].numel()
+            count += 1
+            if pos - start >= limit:
+                self.buckets.append((start, pos, count))
+                start, count = pos, 0
+        if count:
+            self.buckets.append((start, pos, count))
+        self.numel = pos
+        self._reset()
+        self.hooks = []
+        self.overlap = overlap
+        if overlap and self.params and hasattr(self.params[0], "register_post_accumulate_grad_hook"):
+            self.index = {id(p): i for i, p in enumerate(self.params)}
+            for p in self.params:
+                self.hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # ------------------------------------------------------------------ state of one backward
+    def _reset(self):
+        self.ready = [False] * len(self.params)
+        self.pending = [b[2] for b in self.buckets]
+        self.next = 0                 # next bucket to launch
+        self.handles = []
+        self.dirty = False
+
+    def _active(self):
+        return bool(self.params) and (is_distributed() or (self.force and dist.is_initialized()))
 
     def _buffers(self, device):
         if self.flat is None or self.flat.device != device:
-            n = sum(p.numel() for p in self.params)
-            self.flat = torch.empty(n, dtype=self.wire_dtype, device=device)
-            self.views = [c.view_as(p) for c, p in zip(self.flat.split([p.numel() for p in self.params]), self.params)]
+            self.flat = torch.empty(self.numel, dtype=self.wire_dtype, device=device)
+            self.views = [self.flat[self.offset[i]:self.offset[i] + p.numel()].view_as(p) for i, p in enumerate(self.params)]
         return self.flat, self.views
 
-    def __call__(self):
-        if not (is_distributed() or (self.force and dist.is_initialized())):
+    def _on_grad(self, p):
+        if not self._active():
             return
-        if not self.params:
+        i = self.index[id(p)]
+        if self.ready[i]:             # second backward before sync(): the launched buckets hold stale sums
+            self.dirty = True
+            return
+        _, views = self._buffers(p.grad.device)
+        views[i].copy_(p.grad)
+        self._mark(i)
+
+    def _mark(self, i):
+        self.ready[i] = True
+        self.pending[self.bucket_of[i]] -= 1
+        while self.next < len(self.buckets) and self.pending[self.next] == 0:
+            self._launch(self.next)
+            self.next += 1
+
+    def _launch(self, b):
+        start, end, _ = self.buckets[b]
+        buf = self.flat[start:end]
+        if dist.get_backend() == "nccl":
+            # the collective runs on RCCL's stream behind the work already queued on the compute stream (c10d inserts the
+            # event); async: the compute stream is not blocked until sync() waits on the handle
+            self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.AVG, async_op=True))
+        else:
+            self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
+
+    # ------------------------------------------------------------------ after the backward
+    def sync(self):
+        if not self._active():
             return
         for p in self.params:           # fixed element count on every rank
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
         grads = [p.grad for p in self.params]
         flat, views = self._buffers(grads[0].device)
-        torch._foreach_copy_(views, grads)                    # one multi-tensor gather into the persistent buffer
         world = dist.get_world_size()
-        if dist.get_backend() == "nccl":
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG)       # RCCL: mean inside the collective
+        if self.dirty:
+            # every rank must have issued every bucket collective exactly once before the blocking one (a rank whose hooks
+            # saw fewer complete buckets would otherwise be a collective behind): flush the rest, discard the results
+            while self.next < len(self.buckets):
+                self._launch(self.next)
+                self.next += 1
+            for h in self.handles:
+                h.wait()
+            torch._foreach_copy_(views, grads)
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat.div_(world)
         else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat.div_(world)
+            late = [i for i in self.order if not self.ready[i]]
+            if late:                    # gradients the hooks did not see (no hooks, constructed after backward, unused parameters)
+                torch._foreach_copy_([views[i] for i in late], [grads[i] for i in late])
+                for i in late:
+                    self._mark(i)
+            for h in self.handles:
+                h.wait()
+            if dist.get_backend() != "nccl":
+                flat.div_(world)
         torch._foreach_copy_(grads, views)                    # one multi-tensor scatter back
+        self._reset()
+
+    __call__ = sync

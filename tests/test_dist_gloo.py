@@ -150,3 +150,80 @@ def test_fixed_parameter_set_when_a_rank_has_no_gradient_gloo():
     # second sync averages the already-averaged gradient again: (g/2 + g/2)/2 on both ranks = g/2
     assert torch.allclose(torch.from_numpy(gb0), torch.from_numpy(want)) and (gb0 == gb1).all()
     assert same0 and same1 and bumped1            # rank 0 is the source: nothing is written there
+
+
+def _overlap_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "diffusion-by-maxentirl_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dxmi_hip.dist import FlatGradSync
+    torch.manual_seed(5)
+    m = torch.nn.ModuleDict({"a": torch.nn.Linear(6, 6), "b": torch.nn.Linear(6, 6), "c": torch.nn.Linear(6, 2)})
+    sync = FlatGradSync(m, bucket_mb=4e-5)            # ~10 elements per bucket: three buckets, launched DURING backward
+    n_buckets = len(sync.buckets)
+    x = torch.full((3, 6), float(rank + 1))
+
+    def loss():
+        h = m["a"](x)
+        if rank == 0:                                 # rank 1 never uses branch b: its bucket completes only inside sync()
+            h = h + m["b"](x)
+        return m["c"](h).pow(2).sum()
+
+    out = {}
+    # (1) hooks + buckets
+    loss().backward()
+    launched_in_backward = sync.next
+    local = {k: (None if p.grad is None else p.grad.clone()) for k, p in m.named_parameters()}
+    sync()
+    out["round1"] = {k: p.grad.clone().numpy() for k, p in m.named_parameters()}
+    out["local1"] = {k: (None if g is None else g.numpy()) for k, g in local.items()}
+    # (2) second exchange reuses the buffer and the state machine
+    ptr = sync.flat.data_ptr()
+    for p in m.parameters():
+        p.grad = None
+    loss().backward()
+    sync()
+    out["same_buffer"] = sync.flat.data_ptr() == ptr
+    out["round2_equal"] = all(torch.equal(p.grad, torch.from_numpy(out["round1"][k])) for k, p in m.named_parameters())
+    # (3) two backward passes before one sync: blocking fallback on the ACCUMULATED gradients
+    for p in m.parameters():
+        p.grad = None
+    loss().backward()
+    loss().backward()
+    acc = {k: (None if p.grad is None else p.grad.clone().numpy()) for k, p in m.named_parameters()}
+    sync()
+    out["round3"] = {k: p.grad.clone().numpy() for k, p in m.named_parameters()}
+    out["acc3"] = acc
+    q.put((rank, n_buckets, launched_in_backward, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_sync_gloo():
+    """FlatGradSync built BEFORE the backward: gradients are packed by hooks, buckets all-reduced in index order while autograd is
+    still running; an unused branch on one rank, buffer reuse and the two-backward fallback."""
+    import socket
+    import numpy as np
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, nb0, lib0, o0), (_, nb1, lib1, o1) = res
+    assert nb0 == nb1 and nb0 >= 3
+    assert lib0 >= 1                                   # rank 0 had complete buckets before backward returned
+    zero = lambda g, like: np.zeros_like(like) if g is None else g
+    for k in o0["round1"]:
+        want = (zero(o0["local1"][k], o0["round1"][k]) + zero(o1["local1"][k], o0["round1"][k])) / 2
+        assert np.allclose(o0["round1"][k], want, atol=1e-6) and np.array_equal(o0["round1"][k], o1["round1"][k]), k
+        want3 = (zero(o0["acc3"][k], o0["round3"][k]) + zero(o1["acc3"][k], o0["round3"][k])) / 2
+        assert np.allclose(o0["round3"][k], want3, atol=1e-6) and np.array_equal(o0["round3"][k], o1["round3"][k]), k
+    assert o0["same_buffer"] and o1["same_buffer"] and o0["round2_equal"] and o1["round2_equal"]
