@@ -196,7 +196,8 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         const float slope = dxmi_act_slope(p.act);
         const bool has_res = p.residual != nullptr;
 
-        __builtin_amdgcn_s_setprio(3);                  // the MFMA stream outranks the loaders that share its SIMD
+        // (no s_setprio: giving the MFMA waves priority over the movers that share their SIMDs measured 5 % SLOWER on the
+        // residual layers — late movers cost more than contended issue slots — and equal elsewhere)
         ws_barrier();                                   // P0: tap 0 and the first halo chunk have landed
         read_a(0, A0);
         read_b(0, 0, Bx);
