@@ -84,6 +84,8 @@ def spawn_ranks(n):
 # ----------------------------------------------------------------------------------------------- pieces
 def kernel_name(kid):
     """dxmi_conv2d_kernel_id -> the template instantiation name rocprofv3 prints."""
+    if kid >= 600000:
+        return "conv_head_kernel"
     if kid >= 500000:
         return f"conv1x1_rw_kernel<{(kid // 1000) % 10}, {(kid // 10) % 100}, {'true' if kid % 10 else 'false'}>"
     if kid >= 400000:

@@ -145,7 +145,7 @@ class OpProfiler:
         out_b = d.N * d.OH * d.OW * d.Cout * (4 if d.out_mode == OUT_NCHW_F32 else 2)
         res_b = out_b if d.residual else 0
         w_b = d.Cout * cin * 2
-        cls = "conv1x1" if kid >= 500000 else "conv3x3" if kid >= 400000 else "conv_stem" if kid >= 300000 else ("conv1x1" if kid >= 200000 else ("conv3x3" if kid >= 30000 else "conv_other"))
+        cls = "conv_other" if kid >= 600000 else "conv1x1" if kid >= 500000 else "conv3x3" if kid >= 400000 else "conv_stem" if kid >= 300000 else ("conv1x1" if kid >= 200000 else ("conv3x3" if kid >= 30000 else "conv_other"))
         self.bracket(cls, kid, flops, in_b + out_b + res_b + w_b,
                      lambda: check(lib.dxmi_conv2d_fwd(ctypes.byref(d), _stream()), "dxmi_conv2d_fwd"))
 

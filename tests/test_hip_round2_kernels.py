@@ -162,3 +162,25 @@ def test_attention256(ops, N):
     # batch independence: image 0 alone
     y0 = ops.attention(qkv[:1].to(torch.bfloat16).to(DEV), 1, scale)
     assert torch.equal(y0[0], y1[0])
+
+
+@pytest.mark.parametrize("N,H,Cout", [(1, 32, 3), (7, 32, 3), (2, 64, 3), (3, 32, 6)])
+def test_conv_head(ops, N, H, Cout):
+    """conv_out (128 -> few channels, NCHW fp32 output): conv_head_kernel, borders and partial cout blocks included"""
+    g = torch.Generator().manual_seed(3 + N + H + Cout)
+    x = bf(torch.randn(N, 128, H, H, generator=g))
+    w = bf(torch.randn(Cout, 128, 3, 3, generator=g) / math.sqrt(128 * 9))
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, b, padding=1)
+    prof = ops.OpProfiler()
+    ops.PROFILER = prof
+    try:
+        y = ops.conv2d(nhwc(x), ops.pack_conv_weight(w.to(DEV)), bias=b.to(DEV), out_nchw_f32=True)
+        y2 = ops.conv2d(nhwc(x), ops.pack_conv_weight(w.to(DEV)), bias=b.to(DEV), out_nchw_f32=True)
+    finally:
+        ops.PROFILER = None
+    torch.cuda.synchronize()
+    assert prof.records[-1][1] == 600000, prof.records[-1][1]
+    assert y.dtype == torch.float32 and tuple(y.shape) == tuple(ref.shape)
+    assert torch.equal(y, y2)
+    assert rel_l2(y.cpu(), ref) < 2e-3      # fp32 output: only the bf16 operands' products, fp32 accumulation
