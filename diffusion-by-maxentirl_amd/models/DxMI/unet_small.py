@@ -234,26 +234,43 @@ class Model(nn.Module):
         return ops.conv2d(a.view(N, H, W, C), pk[id(m), "proj"], bias=m.proj_out.bias, residual=x)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, t):
+    def forward(self, x, t, temb_rows=None):
         assert x.shape[2] == x.shape[3] == self.resolution
         if not x.is_cuda:
             raise DxmiError("models.DxMI.unet_small.Model runs only on the HIP device path (no CPU fallback)")
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             from .unet_small_train import forward_with_grad  # autograd wrapper around the HIP kernels
             return forward_with_grad(self, x, t)
-        return self.forward_inference(x, t)
+        return self.forward_inference(x, t, temb_rows=temb_rows)
 
     @torch.no_grad()
-    def forward_inference(self, x, t, trace=None):
-        """trace: optional list receiving (name, NHWC bf16 tensor) after every block (debugging aid)."""
-        tr = (lambda n, v: trace.append((n, v))) if trace is not None else (lambda n, v: None)
+    def temb_table(self, t):
+        """The timestep branch of forward() — embedding, the two dense layers, every block's temb_proj (reference
+        unet_small.py:306-309 and :123) — for a vector of timesteps: [len(t), sum of block widths].  The branch depends on t
+        only, and every output row depends on its own input row only, so a generation loop whose batch shares one timestep
+        per step evaluates it on T rows once instead of on T x B identical rows (VARSampler.sample); the rows are bitwise
+        the ones forward() computes itself."""
         pk = self.packed()
-        x = x.contiguous().float()
         emb = ops.timestep_embedding(t, self.ch, order=0)
         h1 = ops.linear(emb, pk["dense0"], self.temb.dense[0].bias, post_act=ops.ACT_SILU)
         s_temb = ops.linear(h1, pk["dense1"], self.temb.dense[1].bias, post_act=ops.ACT_SILU)  # swish(temb)
-        tp = ops.linear(s_temb, pk["tproj"], pk["tproj_bias"])
-        tr("s_temb", s_temb)
+        return ops.linear(s_temb, pk["tproj"], pk["tproj_bias"])
+
+    @torch.no_grad()
+    def forward_inference(self, x, t, trace=None, temb_rows=None):
+        """trace: optional list receiving (name, NHWC bf16 tensor) after every block (debugging aid).
+        temb_rows: a row of temb_table() for this call's (batch-uniform) timestep, shape [1, W] or [B, W] with any row stride."""
+        tr = (lambda n, v: trace.append((n, v))) if trace is not None else (lambda n, v: None)
+        pk = self.packed()
+        x = x.contiguous().float()
+        if temb_rows is None:
+            emb = ops.timestep_embedding(t, self.ch, order=0)
+            h1 = ops.linear(emb, pk["dense0"], self.temb.dense[0].bias, post_act=ops.ACT_SILU)
+            s_temb = ops.linear(h1, pk["dense1"], self.temb.dense[1].bias, post_act=ops.ACT_SILU)  # swish(temb)
+            tp = ops.linear(s_temb, pk["tproj"], pk["tproj_bias"])
+            tr("s_temb", s_temb)
+        else:
+            tp = temb_rows.expand(x.shape[0], -1)      # row stride 0 when one row serves the whole batch
 
         if pk["conv_in"].k27:
             h = ops.conv2d(x, pk["conv_in"], bias=self.conv_in.bias)

@@ -159,6 +159,7 @@ class VARSampler(nn.Module):
         assert trainable_beta in {True, False, "fix_last"}
         self.net = net
         self.n_timesteps = n_timesteps
+        self.temb_table = True      # sample(): evaluate the U-Net's timestep branch once per call on the T distinct timesteps
         self.sample_shape = sample_shape
         self.adhoc_scale1, self.adhoc_scale2 = adhoc_scale1, adhoc_scale2
         self.trainable_beta = trainable_beta
@@ -221,12 +222,13 @@ class VARSampler(nn.Module):
         if hi >= self.n_timesteps or lo < -self.n_timesteps:
             raise IndexError(f"timestep out of range for a {self.n_timesteps}-step sampler: [{lo}, {hi}]")
 
-    def _transition(self, x, t, z, assoc, outs=None, sigma_out=None):
+    def _transition(self, x, t, z, assoc, outs=None, sigma_out=None, temb_rows=None):
         """One fused transition for integer timesteps t [B] (device int64).  outs = (x_next, mean, control, logp) and
-        sigma_out: preallocated destinations (rows of the trajectory block / replay ring)."""
+        sigma_out: preallocated destinations (rows of the trajectory block / replay ring).  temb_rows: this step's row of the
+        U-Net's timestep-branch table when the whole batch shares t (sample())."""
         tau, xm, cm, sg = ops.var_gather_sched(t, self.continuous_steps, self.x_prev_multiplier, self.theta_multiplier,
                                                self._log_betas_all().detach().float().contiguous(), sigma_out=sigma_out)
-        eps = self.net(x, tau)
+        eps = self.net(x, tau) if temb_rows is None else self.net(x, tau, temb_rows=temb_rows)
         if self.adhoc_scale1 != 1.0:
             cm = cm * self.adhoc_scale1
         x_next, mean, control, logp = ops.var_step(x, eps, z, xm, cm, sg, assoc=assoc, outs=outs)
@@ -275,10 +277,16 @@ class VARSampler(nn.Module):
         else:
             traj[0].copy_(noise[0])
         with torch.no_grad():
+            # every image of a generation step shares its timestep: the U-Net's timestep branch (embedding, two dense layers,
+            # all temb_proj) is evaluated once per sample() call on the T distinct timesteps instead of on T x B identical rows
+            table = None
+            if self.temb_table and hasattr(self._bare_net(), "temb_table"):
+                table = self._bare_net().temb_table(self.continuous_steps[:T].to(device).float().contiguous())
             for i in range(T):
                 z = torch.randn(size, device=device) if noise is None else noise[i + 1].to(device).float().contiguous()
                 self._transition(traj[i], self._t_const(n_sample, i, device), z, assoc=1,
-                                 outs=(traj[i + 1], mean_b[i], control_b[i], logp_b[i]), sigma_out=sigma_b[i])
+                                 outs=(traj[i + 1], mean_b[i], control_b[i], logp_b[i]), sigma_out=sigma_b[i],
+                                 temb_rows=None if table is None else table[i:i + 1])
         d = {"sample": traj[T], "l_sample": list(traj.unbind(0)), "logp": list(logp_b.unbind(0)),
              "logp_terminal": torch.zeros(n_sample, device=device), "mean": list(mean_b.unbind(0)),
              "sigma": [s_.view(-1, 1, 1, 1) for s_ in sigma_b.unbind(0)], "control": list(control_b.unbind(0))}

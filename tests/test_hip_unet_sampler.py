@@ -146,6 +146,31 @@ def test_var_sampling_vs_reference(golden_dir, T):
     assert torch.equal(d["logp_terminal"].cpu(), torch.zeros(B))
 
 
+def test_sample_timestep_branch_table_is_bitwise_neutral():
+    """sample() evaluates the U-Net's timestep branch (embedding, dense layers, every temb_proj) once on the T distinct
+    timesteps and hands each step its row (row stride 0 over the batch) instead of recomputing B identical rows per step:
+    the trajectory must be bitwise the one the per-step evaluation gives."""
+    s, _ = make_sampler(10)
+    B = 6
+    torch.manual_seed(3)
+    noise = [torch.randn(B, 3, 32, 32) for _ in range(11)]
+    assert s.temb_table
+    a = s.sample(B, device=DEV, noise=noise)
+    s.temb_table = False
+    b = s.sample(B, device=DEV, noise=noise)
+    s.temb_table = True
+    for k in ("l_sample", "mean", "control", "logp"):
+        assert torch.equal(torch.stack(a[k]), torch.stack(b[k])), k
+    # and the table rows are the rows forward() computes for a batch at that timestep
+    net = s._bare_net()
+    tau = s.continuous_steps[:10].to(DEV).float().contiguous()
+    table = net.temb_table(tau)
+    x = noise[0].to(DEV)
+    e1 = net(x, tau[3].expand(B).contiguous())
+    e2 = net(x, tau[3].expand(B).contiguous(), temb_rows=table[3:4])
+    assert torch.equal(e1, e2)
+
+
 @pytest.mark.parametrize("name,tb", [("sample_step_T10", "fix_last"), ("sample_step_T10_fixedbeta", False)])
 def test_sample_step_vs_reference(golden_dir, name, tb):
     s, sd = make_sampler(10, tb)
