@@ -88,6 +88,8 @@ def kernel_name(kid):
         return "conv_head_kernel"
     if kid >= 500000:
         return f"conv1x1_rw_kernel<{(kid // 1000) % 10}, {(kid // 10) % 100}, {'true' if kid % 10 else 'false'}>"
+    if kid == 400008:
+        return "conv_ws8_kernel"
     if kid >= 400000:
         return f"conv_ws_kernel<{kid - 400000}>"
     if kid >= 300000:

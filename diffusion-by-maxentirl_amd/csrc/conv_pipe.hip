@@ -640,6 +640,7 @@ int ilog2p(int v) {
 int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);       // conv_ws.hip
 int conv1x1_rw_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);   // conv1x1_rw.hip
 int conv_head_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);    // conv_head.hip
+int conv_ws8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);     // conv_ws8.hip
 
 int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     {
@@ -648,6 +649,8 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
         rc = conv1x1_rw_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;
         rc = conv_head_try_launch(a, st, kernel_id);
+        if (rc <= 0) return rc;
+        rc = conv_ws8_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;
     }
     if (a.in_mode == DXMI_IN_NCHW_F32_K27 && a.out_mode == DXMI_OUT_NHWC_BF16 && a.Cout % 64 == 0) return conv_stem_launch(a, st, kernel_id);

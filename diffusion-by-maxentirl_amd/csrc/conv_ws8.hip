@@ -1,0 +1,425 @@
+// conv_ws_kernel's design (conv_ws.hip: MFMA waves fed only from LDS, dedicated mover waves, 16x16x32 MFMAs) for the 8x8
+// maps of the U-Nets (level 2 of the CIFAR-10 DDPM net: 13 of its 49 convs), where a 256-pixel x 128-cout tile would leave
+// only 128 workgroups for 256 CUs.  Here a tile is FOUR whole 8x8 images x 64 couts:
+//   * 256 images x 256 couts = 256 tiles: one per CU, same 512-thread workgroup (waves 0-3 MFMA, 4-5 weights, 6-7 the rest);
+//   * MFMA wave w owns image w of the tile: 64 couts x 64 pixels (4 x 4 accumulator blocks of 16 x 16), operands by
+//     ds_read_b128 at a per-lane base + compile-time offset; a step (one tap of one 32-channel chunk) is 16 MFMAs;
+//   * halo image: 4 x (10 x 10) pixels x 64 B = 25 KB per chunk, channel piece j of halo column hx in slot j ^ (hx & 2)
+//     (bank-conflict free for every tap at row pitch 10, brute-forced); weight ring 6 x 4 KB; output / residual tile 32 KB;
+//     bias + one temb row per image;
+//   * everything else as in conv_ws.hip: one barrier per step, movers issue a few DMAs per step, exact in-order vmcnt counts.
+// Scope: 3x3 / stride 1 / pad 1 on 8x8 maps, NHWC bf16 in (virtual concat) and out, any batch, Cout % 64 == 0,
+// an even number (>= 4) of 32-channel chunks.
+#include "conv_common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int W8_HP = 10, W8_HS = 100;              // halo row pitch / pixels per image halo
+constexpr int W8_HALO_BLOCKS = 25;                  // 4 x 100 pixels x 64 B = 25 KiB exactly
+constexpr int W8_HALO = W8_HALO_BLOCKS * 1024;
+constexpr int W8_A_SLOT = 4096;                     // one (chunk, tap): 2 k-steps x 2 cout blocks x 1 KiB fragments
+constexpr int W8_RING = 6;
+constexpr int W8_A_RING = W8_RING * W8_A_SLOT;
+constexpr int W8_RO = 256 * 128;                    // 256 px x 64 co bf16
+constexpr int W8_TB = 2048;                         // bias[64] | temb[4][64] fp32
+
+__device__ uint4 w8_zero16 = {0u, 0u, 0u, 0u};
+
+#define W8_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define W8_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ void w8_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 8 MFMAs (16 cycles each) with 2 / 6 operand reads spread between them
+#define W8_INTERLEAVE_2()                                       \
+    do {                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  \
+        }                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      \
+    } while (0)
+#define W8_INTERLEAVE_6()                                       \
+    do {                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  \
+        }                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      \
+    } while (0)
+
+__device__ __forceinline__ void w8_wait_vm(int n) {      // s_waitcnt vmcnt(n), n wave-uniform, rounded DOWN to even (waits for more)
+    switch (n >> 1) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    }
+}
+
+struct W8Tile {
+    int cot, n0;
+};
+
+__global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* const halo0 = smem;
+    char* const aring = smem + 2 * W8_HALO;
+    char* const ro = aring + W8_A_RING;
+    float* const tb = reinterpret_cast<float*>(ro + W8_RO);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunks = (p.C0 + p.C1) / 32;
+    const int S = 9 * nchunks;                       // steps per tile
+    const int ntiles = p.PT * p.CT;                  // (4-image tile, 64-cout tile) pairs, cout fastest
+
+    auto tile_of = [&](int q, W8Tile& t) {
+        t.cot = q % p.CT;
+        t.n0 = (q / p.CT) * 4;
+    };
+
+    int q = blockIdx.x;
+    if (q >= ntiles) return;
+    const int qstride = gridDim.x;
+
+    if (wave < 4) {
+        // ================================================================ MFMA waves: image `wave` of the tile, 64 couts
+        const int px = lane & 15, kg = lane >> 4;      // B: pixel / channel piece; A: cout / 8-channel group; D: pixel / 4-cout group
+        int bbase[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int hx = (px & 7) + kx;
+            bbase[kx] = ((wave * W8_HS + (px >> 3) * W8_HP + hx) * 64) + ((kg ^ (hx & 2)) << 4);
+        }
+        const char* const abase = aring + ((kg >> 1) * 2048) + ((px + 32 * (kg & 1)) << 4);   // + slot*4096 + (cb16>>1)*1024 + (cb16&1)*256
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[cb][nb][r] = 0.f;
+        bf16x8 A0[4], A1[4], Bx[2], By[2];
+        // operands of step u of a chunk PAIR (u = 0..17: chunk parity u / 9, tap u % 9; u = 18 wraps)
+        auto read_a = [&](int u, bf16x8 (&A)[4]) {
+            const char* as = abase + (u % W8_RING) * W8_A_SLOT;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) A[cb] = *reinterpret_cast<const bf16x8*>(as + (cb >> 1) * 1024 + (cb & 1) * 256);
+        };
+        auto read_b = [&](int u, int half, bf16x8 (&B)[2]) {      // 16-pixel blocks 2 half, 2 half + 1: image rows 2 nb, 2 nb + 1
+            const int t = u % 9, ky = t / 3, kx = t % 3;
+            const char* hb = halo0 + ((u / 9) & 1) * W8_HALO + bbase[kx];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) B[i] = *reinterpret_cast<const bf16x8*>(hb + ((2 * (half * 2 + i) + ky) * W8_HP) * 64);
+        };
+        auto mfma8 = [&](const bf16x8 (&A)[4], const bf16x8 (&B)[2], int half) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[cb][half * 2 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[cb], B[i], acc[cb][half * 2 + i], 0, 0, 0);
+        };
+        const float slope = dxmi_act_slope(p.act);
+        const bool has_res = p.residual != nullptr;
+
+        w8_barrier();                                   // P0: tap 0 and the first halo chunk have landed
+        read_a(0, A0);
+        read_b(0, 0, Bx);
+        for (;;) {
+            const bool more = q + qstride < ntiles;
+            for (int c = 0; c < nchunks; c += 2) {
+#pragma unroll
+                for (int u = 0; u < 18; ++u) {
+                    read_b(u, 1, By);
+                    if (u & 1) mfma8(A1, Bx, 0); else mfma8(A0, Bx, 0);
+                    W8_INTERLEAVE_2();
+                    w8_barrier();                       // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
+                    if (u & 1) read_a(u + 1, A0); else read_a(u + 1, A1);
+                    read_b(u + 1, 0, Bx);
+                    if (u & 1) mfma8(A1, By, 1); else mfma8(A0, By, 1);
+                    W8_INTERLEAVE_6();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            w8_barrier();                               // E1: residual tile + bias / temb table of this tile landed
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const int co = cb * 16 + 4 * kg;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb + co), t0 = *reinterpret_cast<const f32x4*>(tb + 64 + wave * 64 + co);
+                f32x4 bv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = b0[e] + t0[e];
+                const int c8 = cb * 2 + (kg >> 1);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const int lp = wave * 64 + nb * 16 + px;
+                    char* a = ro + (lp * 8 + (c8 ^ (lp & 7))) * 16 + 8 * (kg & 1);
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[cb][nb][e] + bv[e];
+                    if (has_res) {
+                        const bf16x4 r = *reinterpret_cast<const bf16x4*>(a);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)dxmi_act_lin(v[e], slope);
+                    *reinterpret_cast<bf16x4*>(a) = o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[cb][nb][e] = 0.f;
+                }
+            }
+            w8_barrier();                               // E2: output tile complete, the bulk movers may drain it
+            if (!more) break;
+            q += qstride;
+        }
+        return;
+    }
+
+    if (wave < 6) {
+        // ================================================================ weight loaders (waves 4, 5): k-step lw of every tap
+        const int lw = wave - 4;
+        const char* const wb = reinterpret_cast<const char*>(p.w) + (size_t)lane * 16;
+        W8Tile cur;
+        tile_of(q, cur);
+        auto issue_tap = [&](int cot, int g) {
+            const int c = g / 9, t = g - c * 9;
+            char* dst = aring + (g % W8_RING) * W8_A_SLOT + lw * 2048;
+            const char* src = wb + ((size_t)(t * p.KST + c * 2 + lw) * p.CB + cot * 2) * 1024;
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+                __builtin_amdgcn_global_load_lds(W8_GPTR(src + f * 1024), W8_LPTR(dst + f * 1024), 16, 0, 0);
+        };
+#pragma unroll 1
+        for (int g = 0; g < W8_RING - 1; ++g) issue_tap(cur.cot, g);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // tap 0 landed (4 younger taps may be outstanding)
+        w8_barrier();                                       // P0
+        for (;;) {
+            const bool more = q + qstride < ntiles;
+            W8Tile nxt = cur;
+            if (more) tile_of(q + qstride, nxt);
+            for (int g = 0; g < S; ++g) {
+                const int g3 = g + W8_RING - 1;
+                bool issued = true;
+                if (g3 < S) issue_tap(cur.cot, g3);
+                else if (more) issue_tap(nxt.cot, g3 - S);      // same ring slot: S % RING == 0 (host-checked)
+                else issued = false;
+                if (issued) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // taps g+2 .. g+5 (8 DMAs) may be outstanding
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                w8_barrier();                                    // B_g
+            }
+            w8_barrier();                                        // E1
+            w8_barrier();                                        // E2
+            if (!more) break;
+            q += qstride;
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ==================================================================== bulk movers (waves 6, 7)
+    {
+        const int bw = wave - 6;
+        const int t2 = bw * 64 + lane;                     // 0..127 over the two waves
+        constexpr int HB2 = (W8_HALO_BLOCKS + 1) / 2;      // halo blocks per wave (block bw + 2k)
+        int hsrc[HB2];
+        auto halo_plan = [&](const W8Tile& t) {
+#pragma unroll
+            for (int k = 0; k < HB2; ++k) {
+                const int hp = (bw + 2 * k) * 16 + (lane >> 2);
+                const int sub = hp / W8_HS, r = hp - sub * W8_HS;
+                const int hy = r / W8_HP, hx = r - hy * W8_HP;
+                const int iy = hy - 1, ix = hx - 1;
+                const bool ok = sub < 4 && t.n0 + sub < p.N && iy >= 0 && ix >= 0 && iy < 8 && ix < 8;
+                hsrc[k] = ok ? ((t.n0 + sub) * 8 + iy) * 8 + ix : -1;
+            }
+        };
+        auto halo_issue = [&](int c, char* buf, int ka, int kb) {     // blocks ka .. kb-1 of this wave's share (compile-time range)
+            const int cbase = c * 32;
+            const bool first = cbase < p.C0;
+            const bf16* src = first ? p.in0 : p.in1;
+            const int Cs = first ? p.C0 : p.C1;
+            const int coff = first ? cbase : cbase - p.C0;
+#pragma unroll
+            for (int k = 0; k < HB2; ++k) {
+                if (k < ka || k >= kb) continue;
+                const int blk = bw + 2 * k;
+                const int hx = ((blk * 16 + (lane >> 2)) % W8_HS) % W8_HP;
+                const int j8 = ((lane & 3) ^ (hx & 2)) * 8;
+                const void* g = hsrc[k] >= 0 ? (const void*)(src + (size_t)hsrc[k] * Cs + coff + j8) : (const void*)&w8_zero16;
+                if (blk < W8_HALO_BLOCKS)
+                    __builtin_amdgcn_global_load_lds(W8_GPTR(g), W8_LPTR(buf + blk * 1024), 16, 0, 0);
+            }
+        };
+        // output-tile pieces of this thread: L = k*128 + t2 (k = 0..15): pixel lp = k*16 + (t2 >> 3), cout piece (t2 & 7) ^ (lp & 7)
+        // (-1: the piece belongs to an image past the end of the batch — the last tile of a batch that is not a multiple of 4)
+        auto piece_off = [&](const W8Tile& t, int k) -> long {
+            const int lp = k * 16 + (t2 >> 3);
+            const int c8 = (t2 & 7) ^ (lp & 7);
+            const int n = t.n0 + (lp >> 6);
+            if (n >= p.N) return -1;
+            return (long)((((size_t)n * 8 + ((lp >> 3) & 7)) * 8 + (lp & 7)) * p.Cout + t.cot * 64 + c8 * 8);
+        };
+        auto fetch_table = [&](const W8Tile& t) {            // bias[64] and the four images' temb rows: 4-byte DMA, 256 B per instruction
+            if (bw != 0) return;
+            if (p.bias) __builtin_amdgcn_global_load_lds(W8_GPTR(p.bias + t.cot * 64 + lane), W8_LPTR(tb), 4, 0, 0);
+            if (p.addvec) {
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub) {
+                    const int n = t.n0 + sub < p.N ? t.n0 + sub : p.N - 1;      // images past the batch: any valid row (results discarded)
+                    __builtin_amdgcn_global_load_lds(W8_GPTR(p.addvec + (size_t)n * p.addvec_ld + t.cot * 64 + lane),
+                                                     W8_LPTR(tb + 64 + sub * 64), 4, 0, 0);
+                }
+            }
+        };
+        const bool do_res = p.residual != nullptr;
+        auto fetch_residual = [&](const W8Tile& t, int k0, int k1) {
+            if (!do_res) return;
+#pragma unroll 1
+            for (int k = k0; k < k1; ++k) {
+                const long o = piece_off(t, k);
+                const void* g = o >= 0 ? (const void*)(p.residual + o) : (const void*)&w8_zero16;
+                __builtin_amdgcn_global_load_lds(W8_GPTR(g), W8_LPTR(ro + (k * 128 + bw * 64) * 16), 16, 0, 0);
+            }
+        };
+        // pieces k0 .. k1-1 of the tile switch: previous tile's output pieces out, this tile's residual pieces into the same
+        // LDS rows (a wave refills exactly the rows it drained).  Returns the vector-memory operations it issued.
+        auto tile_switch = [&](const W8Tile& pt, const W8Tile& ct, int k0, int k1) -> int {
+#pragma unroll 1
+            for (int k = k0; k < k1; k += 2) {
+                const int n = k1 - k < 2 ? k1 - k : 2;
+                bf16x8 v[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (u < n) v[u] = *reinterpret_cast<const bf16x8*>(ro + ((k + u) * 128 + t2) * 16);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const long o = u < n ? piece_off(pt, k + u) : -1;
+                    // predicated per lane; the store still counts once in vmcnt for the wave whenever u < n
+                    if (u < n) {
+                        if (o >= 0) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + o) = v[u];
+                    }
+                }
+                fetch_residual(ct, k, k + n);
+            }
+            // a store whose lanes all belong to images past the batch is skipped entirely: such tiles' stores are not counted
+            // (a count that is too LOW only waits for more)
+            return (k1 - k0) * ((pt.n0 + 4 <= p.N ? 1 : 0) + (do_res ? 1 : 0));
+        };
+
+        W8Tile cur;
+        tile_of(q, cur);
+        // table rows that no DMA fills stay zero
+        if (bw == 0) {
+            if (!p.bias) tb[lane] = 0.f;
+            if (!p.addvec) { tb[64 + lane] = 0.f; tb[128 + lane] = 0.f; tb[192 + lane] = 0.f; tb[256 + lane] = 0.f; }
+        }
+        halo_plan(cur);
+        halo_issue(0, halo0, 0, HB2);
+        fetch_table(cur);
+        fetch_residual(cur, 0, 16);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        w8_barrier();                                           // P0
+        bool have_prev = false;
+        W8Tile prev = cur;
+        const int kpc = (16 + nchunks - 2) / (nchunks - 1);      // tile-switch pieces per chunk (first nchunks-1 chunks)
+        const int pps = (kpc + 7) >> 3;                          // ... per step
+        for (;;) {
+            const bool more = q + qstride < ntiles;
+            W8Tile nxt = cur;
+            if (more) tile_of(q + qstride, nxt);
+            for (int c = 0; c < nchunks; ++c) {
+                const bool wrap = c + 1 == nchunks;
+                if (c == 0 && have_prev) fetch_table(cur);       // older than this chunk's halo DMAs: complete at its last barrier
+                if (wrap && more) halo_plan(nxt);
+                const bool do_halo = !wrap || more;
+                char* const hbuf = halo0 + ((c + 1) & 1) * W8_HALO;
+                const int hc = wrap ? 0 : c + 1;
+                int k0 = 16, k1 = 16;
+                if (have_prev && !wrap) {
+                    k0 = c * kpc < 16 ? c * kpc : 16;
+                    k1 = k0 + kpc < 16 ? k0 + kpc : 16;
+                }
+                int young = 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (t < 7 && do_halo) halo_issue(hc, hbuf, 2 * t, 2 * t + 2);
+                    if (t < 8) {
+                        const int ka = k0 + t * pps < k1 ? k0 + t * pps : k1, kb = ka + pps < k1 ? ka + pps : k1;
+                        if (ka < kb) {
+                            const int n = tile_switch(prev, cur, ka, kb);
+                            if (t >= 6) young += n;              // issued after the last halo block of this chunk
+                        }
+                    }
+                    if (t == 8) {
+                        // halo image (and everything older) landed; at the last chunk E1 needs the whole residual tile
+                        if (wrap) w8_wait_vm(0);
+                        else w8_wait_vm(young);
+                    }
+                    w8_barrier();                                // B_g
+                }
+            }
+            w8_barrier();                                        // E1
+            w8_barrier();                                        // E2
+            prev = cur;
+            have_prev = true;
+            if (!more) break;
+            q += qstride;
+            cur = nxt;
+        }
+        // last tile out
+#pragma unroll 1
+        for (int k = 0; k < 16; k += 4) {
+            bf16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(ro + ((k + u) * 128 + t2) * 16);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long o = piece_off(prev, k + u);
+                if (o >= 0) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + o) = v[u];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// Launches the 8x8-map wave-specialised kernel when the shape is in its scope; returns 1 otherwise (caller falls back).
+int conv_ws8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
+    static const int enabled = getenv("DXMI_CONV_WS8") ? atoi(getenv("DXMI_CONV_WS8")) : 1;   // 0: conv_pipe_kernel for the 8x8 maps
+    if (!enabled) return 1;
+    if (a.in_mode != DXMI_IN_NHWC_BF16 || a.out_mode != DXMI_OUT_NHWC_BF16) return 1;
+    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups != 0 || a.mask_src || a.act == DXMI_ACT_SILU) return 1;
+    if (a.OH != 8 || a.OW != 8 || a.IH != 8 || a.IW != 8) return 1;
+    if (a.Cout % 64 != 0 || (a.C0 + a.C1) % 32 != 0 || a.C0 % 32 != 0) return 1;
+    const int nchunks = (a.C0 + a.C1) / 32;
+    if (nchunks < 4 || nchunks % 2 != 0 || (9 * nchunks) % W8_RING != 0) return 1;
+    // no batch-size condition: an image's result must not depend on the batch it rides in (the kernels differ in summation order)
+    if (kernel_id) {
+        *kernel_id = 400008;    // conv_ws8_kernel
+        return DXMI_OK;
+    }
+    ConvArgs b = a;
+    b.SUBS = 4;
+    b.PT = (a.N + 3) / 4;      // the last tile may hold fewer than four images (masked)
+    b.CT = a.Cout / 64;
+    b.tile_px = 256;
+    const size_t lds = 2 * W8_HALO + W8_A_RING + W8_RO + W8_TB;
+    int grid = b.PT * b.CT;
+    if (grid > 256) grid = 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ws8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_ws8_kernel, dim3(grid), dim3(512), lds, st, b);
+    DXMI_CHECK_LAUNCH("dxmi_conv2d_fwd(ws8)");
+    return DXMI_OK;
+}

@@ -91,6 +91,28 @@ def test_conv_ws(ops, N, C0, C1, Cout, H, ups, fuse):
     assert rel_l2(nchw(y), ref) < 4e-3
 
 
+# (N, C0, C1, Cout, fuse): 3x3 shapes on 8x8 maps in conv_ws8_kernel's scope (tiles of four images x 64 couts)
+WS8_CASES = [
+    (128, 256, 0, 256, "bias+res+vec"),                    # 128 tiles, one per workgroup
+    (132, 256, 256, 256, "bias+vec+act"),                  # concat, 16 chunks
+    (260, 256, 0, 256, "bias+res+vec"),                    # 260 tiles over 256 workgroups: four walk two tiles (tile switch)
+    (520, 128, 0, 128, "bias+res"),                        # 4 chunks, two cout tiles, 260 tiles
+    (64, 256, 0, 512, "none"),                             # eight cout tiles
+    (1, 256, 0, 256, "bias+res+vec"),                      # one image: three quarters of the only tile masked
+    (7, 256, 0, 256, "bias+res+vec"),                      # last tile holds three images
+    (1031, 128, 0, 64, "bias+res"),                        # 258 tiles, the last one with three images, reached through a tile switch
+]
+
+
+@pytest.mark.parametrize("N,C0,C1,Cout,fuse", WS8_CASES)
+def test_conv_ws8(ops, N, C0, C1, Cout, fuse):
+    y, ref, kid = run_conv(ops, N, C0, C1, Cout, 8, 3, False, fuse)
+    assert kid == 400008, f"expected conv_ws8_kernel, got kernel id {kid}"
+    assert rel_l2(nchw(y), ref) < 4e-3
+    y2, _, _ = run_conv(ops, N, C0, C1, Cout, 8, 3, False, fuse)
+    assert torch.equal(y, y2)
+
+
 # (N, C0, C1, Cout, H, fuse): 1x1 shapes in conv1x1_rw_kernel's scope (>= 32768 pixels)
 RW_CASES = [
     (128, 256, 0, 768, 16, "bias"),                         # q|k|v: six cout tiles share a pixel stream
@@ -113,7 +135,7 @@ def test_conv1x1_rw(ops, N, C0, C1, Cout, H, fuse):
 def test_round2_kernels_out_of_scope_shapes_fall_back(ops):
     """shapes just outside the new kernels' scope still run (on the round-1 kernels) and agree with the reference"""
     for (N, C0, C1, Cout, H, k, fuse) in [(2, 128, 0, 192, 32, 3, "bias"),      # Cout % 128 != 0
-                                          (4, 256, 0, 256, 8, 3, "bias+res"),    # 8x8 map
+                                          (4, 256, 0, 256, 4, 3, "bias+res"),    # 4x4 map
                                           (2, 96, 0, 128, 32, 3, "bias"),        # odd chunk count
                                           (8, 256, 0, 256, 16, 1, "bias"),       # 1x1 with too few pixels
                                           (128, 192, 0, 384, 16, 1, "bias")]:    # 1x1 with K % 128 != 0
