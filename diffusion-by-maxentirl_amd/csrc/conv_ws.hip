@@ -4,24 +4,26 @@
 // in order, so a wave that has stores or residual loads in flight stalls at its next wait on a *younger* weight-fragment
 // load until they are acknowledged; the tile end (residual in, output out) therefore costs more cycles than the tile's
 // MFMAs, and at 256 VGPRs there is no room for a third resident workgroup to cover it.  Here ONE workgroup of 8 waves owns a
-// CU and the roles are split (each SIMD hosts one wave of each kind):
-//   waves 0-3  MFMA: a 64-cout x 128-pixel accumulator tile each (128 co x 256 px per workgroup).  Operands come from LDS
-//              only — weight fragments from a 4-slot ring, input pixels from a double-buffered halo image — with a
-//              half-step software pipeline (the reads of one 16-deep k-step fly under the 8 MFMAs of the previous one).
-//              No vector-memory instruction is ever issued, so nothing a loader does can stall them; the only waits are
-//              lgkmcnt for LDS reads and one barrier per (chunk, tap) step.
-//   waves 4,5  weight loaders: stream the pre-packed MFMA A fragments of step g+3 into the ring by LDS DMA
+// CU, persistent over (256-pixel, 128-cout) tiles, and the roles are split (each SIMD hosts one wave of each kind):
+//   waves 0-3  MFMA (v_mfma_f32_16x16x32_bf16): a 64-cout x 128-pixel accumulator tile each.  Operands come from LDS only —
+//              weight fragments from a 6-slot ring, input pixels from a double-buffered halo image — at per-lane bases plus
+//              compile-time offsets (no address arithmetic in the loop), with a half-step software pipeline: the reads of
+//              the next 16 MFMAs fly under the current 16.  No vector-memory instruction is ever issued, so nothing a mover
+//              does can stall them; the only waits are lgkmcnt for LDS reads and one barrier per (chunk, tap) step.
+//   waves 4,5  weight loaders: stream the pre-packed A fragments of step g+5 into the ring by LDS DMA
 //              (`global_load_lds_dwordx4`: one 1-KiB fragment per instruction, no staging registers), wait with a counted
-//              vmcnt that leaves two steps in flight.
+//              vmcnt that leaves four steps in flight.
 //   waves 6,7  bulk movers: the next 32-channel chunk's halo image (DMA, XOR-swizzled 16-byte slots instead of padding: a
 //              DMA writes 1 KiB linearly), the residual tile and the bias / temb table of the CURRENT tile (DMA into the
-//              output tile's own LDS buffer), and the drain of the PREVIOUS tile's output (LDS -> 256-byte NHWC rows).
-//              Their long-latency traffic only ever delays themselves.
+//              output tile's own LDS buffer), and the drain of the PREVIOUS tile's output (LDS -> 256-byte NHWC rows) —
+//              issued a few instructions per step, never in bursts (a DMA costs its wave ~100 cycles of issue and a mover
+//              that is late at a step barrier stalls the MFMA waves), every wait counting exactly the younger operations.
 // Tile end: the MFMA waves add bias + temb + residual to the accumulators in the accumulator layout (LDS reads of their
 // own cout columns), apply the activation, round ONCE to bf16 and write the output tile in place in LDS; two barriers.
 //
 // Scope: 3x3 / stride 1 / pad 1 (optionally behind a nearest x2 upsample), NHWC bf16 in (virtual concat) and out,
-// Cout % 128 == 0, Cin % 32 == 0, maps >= 16x16 (one image per 256-pixel tile).  Everything else stays on conv_pipe.hip.
+// Cout % 128 == 0, an even number of 32-channel chunks, maps >= 16x16 (one image per 256-pixel tile); 8x8 maps: conv_ws8.hip.
+// Everything else stays on conv_pipe.hip.
 #include "conv_common.h"
 #include <stdlib.h>
 
@@ -38,8 +40,12 @@ extern "C" int dxmi_debug_read_ws_stamps(void* dst, int bytes) {
         const unsigned long long t1_ = __builtin_amdgcn_s_memtime();                                \
         if (wave == 0 && lane == 0 && (idx) < 160 && blockIdx.x < 256) g_ws_wait[blockIdx.x][(idx)] = (unsigned)(t1_ - t0_); \
     } while (0)
+// timing-only ablations of the diagnostic build (DXMI_CONV_WS_DBG bits: 1 no weight stream, 2 no halo stream, 4 no drain,
+// 8 no residual / table fetch, 16 no step barriers — wrong results); compiled out of the product library
+#define WS_DBG(bit) (p.stagger & (bit))
 #else
 #define WS_STAMPED_BARRIER(idx) ws_barrier()
+#define WS_DBG(bit) 0
 #endif
 
 namespace {
@@ -58,17 +64,6 @@ __device__ uint4 ws_zero16 = {0u, 0u, 0u, 0u};   // source of zero-padding pixel
 #define WS_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// one MFMA, then one LDS read, six times, then the last two MFMAs: with a single MFMA wave per SIMD the operand reads of
-// the next half-step must issue in the shadow of this half-step's MFMAs
-#define WS_INTERLEAVE()                                         \
-    do {                                                        \
-        _Pragma("unroll") for (int i_ = 0; i_ < 6; ++i_) {      \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  \
-        }                                                       \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      \
-    } while (0)
 
 // 16 MFMAs (16 cycles each) with 4 / 8 operand reads spread between them
 #define WS_INTERLEAVE_4()                                       \
@@ -216,7 +211,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                     read_b(u, 1, By);
                     if (u & 1) mfma16(A1, Bx, 0); else mfma16(A0, Bx, 0);
                     WS_INTERLEAVE_4();
-                    if (!(p.stagger & 16)) WS_STAMPED_BARRIER(stamp_i + c * 9 + u);   // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
+                    if (!(WS_DBG(16))) WS_STAMPED_BARRIER(stamp_i + c * 9 + u);   // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
                     if (u & 1) read_a(u + 1, A0); else read_a(u + 1, A1);
                     read_b(u + 1, 0, Bx);
                     if (u & 1) mfma16(A1, By, 1); else mfma16(A0, By, 1);
@@ -273,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         tile_of(q, cur);
         // fragments lw*4 .. lw*4+3 of (chunk c, tap t) for cout tile cot -> ring slot
         auto issue_tap = [&](int cot, int g) {
-            if (p.stagger & 1) return;                  // timing-only ablation (DXMI_CONV_WS_DBG): no weight stream
+            if (WS_DBG(1)) return;                  // timing-only ablation (DXMI_CONV_WS_DBG): no weight stream
             const int c = g / 9, t = g - c * 9;
             char* dst = aring + (g % WS_RING) * WS_A_SLOT + lw * 4096;
             // fragments (ks = lw, cbg = 0..3): contiguous 4 KiB of the packed weights
@@ -300,7 +295,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 // tile) the count of younger DMAs shrinks, so everything is awaited
                 if (issued) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (!(p.stagger & 16)) ws_barrier();                                    // B_g
+                if (!(WS_DBG(16))) ws_barrier();                                    // B_g
             }
             ws_barrier();                                        // E1
             ws_barrier();                                        // E2
@@ -319,11 +314,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         constexpr int HB2 = (WS_HALO_BLOCKS + 1) / 2;      // halo blocks per wave
         // halo block k of this wave = block bw + 2k: lane -> (halo pixel, 16-byte slot); slot s of pixel (hy, hx) holds
         // channel piece s ^ (2 * ((hx >> 2) & 1)).  Source pixel of every block lane, recomputed per tile only.
-        int hsrc[HB2], hj8;
-        {
-            const int hpix = lane >> 2;
-            (void)hpix;
-        }
+        int hsrc[HB2];
         auto halo_plan = [&](const WsTile& t) {
 #pragma unroll
             for (int k = 0; k < HB2; ++k) {
@@ -335,7 +326,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             }
         };
         auto halo_issue = [&](int c, char* buf, int ka, int kb) {     // blocks ka .. kb-1 of this wave's share (compile-time range)
-            if (p.stagger & 2) return;                  // timing-only ablation: no halo stream
+            if (WS_DBG(2)) return;                  // timing-only ablation: no halo stream
             const int cbase = c * 32;
             const bool first = cbase < p.C0;
             const bf16* src = first ? p.in0 : p.in1;
@@ -360,7 +351,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             return (long)((((size_t)t.n0 * p.OH + t.oy0 + py) * p.OW + t.ox0 + px) * p.Cout + t.cot * 128 + c8 * 8);
         };
         auto drain = [&](const WsTile& t) {
-            if (p.stagger & 4) return;                  // timing-only ablation: no output drain
+            if (WS_DBG(4)) return;                  // timing-only ablation: no output drain
 #pragma unroll 1
             for (int k = 0; k < 32; k += 4) {
                 bf16x8 v[4];
@@ -371,7 +362,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             }
         };
         auto fetch_table = [&](const WsTile& t) {            // bias[128] (2 x 64 floats) and this image's temb row: 4-byte DMA, 256 B per instruction
-            if (bw != 0 || (p.stagger & 8)) return;
+            if (bw != 0 || (WS_DBG(8))) return;
             if (p.bias) {
                 __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + t.cot * 128 + lane), WS_LPTR(tb), 4, 0, 0);
                 __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + t.cot * 128 + 64 + lane), WS_LPTR(tb + 64), 4, 0, 0);
@@ -382,7 +373,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 __builtin_amdgcn_global_load_lds(WS_GPTR(av + 64 + lane), WS_LPTR(tb + 192), 4, 0, 0);
             }
         };
-        const bool do_res = p.residual != nullptr && !(p.stagger & 8);
+        const bool do_res = p.residual != nullptr && !(WS_DBG(8));
         auto fetch_residual = [&](const WsTile& t, int k0, int k1) {
             if (!do_res) return;
 #pragma unroll 1
@@ -392,7 +383,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         // pieces k0 .. k1-1 of this wave's share of the tile switch: previous tile's output pieces out, this tile's residual
         // pieces into the same LDS rows (a wave refills exactly the rows it drained; its reads are complete when the stores
         // that consume them have issued).  Returns the number of vector-memory operations it issued.
-        const bool do_drain = !(p.stagger & 4);
+        const bool do_drain = !(WS_DBG(4));
         auto tile_switch = [&](const WsTile& pt, const WsTile& ct, int k0, int k1) -> int {
 #pragma unroll 1
             for (int k = k0; k < k1; k += 4) {
@@ -410,7 +401,6 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             }
             return (k1 - k0) * ((do_drain ? 1 : 0) + (do_res ? 1 : 0));
         };
-        (void)hj8;
 
         WsTile cur;
         tile_of(q, cur);
@@ -467,7 +457,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                         if (wrap) ws_wait_vm(0);
                         else ws_wait_vm(young);
                     }
-                    if (!(p.stagger & 16)) ws_barrier();                                // B_g
+                    if (!(WS_DBG(16))) ws_barrier();                                // B_g
                 }
             }
             ws_barrier();                                        // E1
@@ -506,8 +496,12 @@ int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     b.PT = a.N * (a.OH / TH) * (a.OW / TW);
     b.CT = a.Cout / 128;
     b.tile_px = 256;
+#ifdef DXMI_CONV_STAMPS
     static const int dbg = getenv("DXMI_CONV_WS_DBG") ? atoi(getenv("DXMI_CONV_WS_DBG")) : 0;
     b.stagger = dbg;
+#else
+    b.stagger = 0;
+#endif
     const size_t lds = 2 * WS_HALO + WS_A_RING + WS_RO + WS_TB;
     int grid = b.PT * b.CT;
     if (grid > 256) grid = 256;
