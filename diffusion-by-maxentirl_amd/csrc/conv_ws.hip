@@ -313,8 +313,12 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         const int t2 = bw * 64 + lane;                     // 0..127 over the two waves
         constexpr int HB2 = (WS_HALO_BLOCKS + 1) / 2;      // halo blocks per wave
         // halo block k of this wave = block bw + 2k: lane -> (halo pixel, 16-byte slot); slot s of pixel (hy, hx) holds
-        // channel piece s ^ (2 * ((hx >> 2) & 1)).  Source pixel of every block lane, recomputed per tile only.
-        int hsrc[HB2];
+        // channel piece s ^ (2 * ((hx >> 2) & 1)).  Per tile each lane keeps the BYTE offset of its source piece inside either
+        // concat part (-1: zero padding): per chunk a DMA address is then one 64-bit add and a select — the movers' issue rate is
+        // what bounds this kernel, and 64-bit multiplies or a GOT load of the zero page per DMA (what the straightforward
+        // expression compiles to) cost more than the DMA itself.
+        const char* const zero_page = reinterpret_cast<const char*>(p.mask_src);    // 16 zero bytes (host: &ws_zero16)
+        int hoff0[HB2], hoff1[HB2];
         auto halo_plan = [&](const WsTile& t) {
 #pragma unroll
             for (int k = 0; k < HB2; ++k) {
@@ -322,43 +326,47 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 const int hy = hp / HP, hx = hp - hy * HP;
                 const int iy = t.oy0 - 1 + hy, ix = t.ox0 - 1 + hx;
                 const bool ok = hy < HH && hx < TW + 2 && iy >= 0 && ix >= 0 && iy < (p.IH << ups) && ix < (p.IW << ups);
-                hsrc[k] = ok ? (t.n0 * p.IH + (iy >> ups)) * p.IW + (ix >> ups) : -1;
+                const int pix = (t.n0 * p.IH + (iy >> ups)) * p.IW + (ix >> ups);
+                const int j8 = ((lane & 3) ^ (2 * ((hx >> 2) & 1))) * 8;
+                hoff0[k] = ok ? (pix * p.C0 + j8) * 2 : -1;
+                hoff1[k] = ok ? (pix * p.C1 + j8) * 2 : -1;
             }
         };
         auto halo_issue = [&](int c, char* buf, int ka, int kb) {     // blocks ka .. kb-1 of this wave's share (compile-time range)
             if (WS_DBG(2)) return;                  // timing-only ablation: no halo stream
             const int cbase = c * 32;
             const bool first = cbase < p.C0;
-            const bf16* src = first ? p.in0 : p.in1;
-            const int Cs = first ? p.C0 : p.C1;
-            const int coff = first ? cbase : cbase - p.C0;
+            const char* base = reinterpret_cast<const char*>(first ? p.in0 : p.in1) + (first ? cbase : cbase - p.C0) * 2;
 #pragma unroll
             for (int k = 0; k < HB2; ++k) {
                 if (k < ka || k >= kb) continue;
                 const int blk = bw + 2 * k;
-                const int hx = ((blk * 16 + (lane >> 2)) % HP);
-                const int j8 = ((lane & 3) ^ (2 * ((hx >> 2) & 1))) * 8;
-                const void* g = hsrc[k] >= 0 ? (const void*)(src + (size_t)hsrc[k] * Cs + coff + j8) : (const void*)&ws_zero16;
+                const int off = first ? hoff0[k] : hoff1[k];
+                const char* g = off >= 0 ? base + off : zero_page;
                 if (blk < WS_HALO_BLOCKS)
                     __builtin_amdgcn_global_load_lds(WS_GPTR(g), WS_LPTR(buf + blk * 1024), 16, 0, 0);
             }
         };
-        // output-tile pieces of this thread: L = k*128 + t2 (k = 0..31): pixel lp = k*8 + (t2 >> 4), cout piece (t2 & 15) ^ (lp & 15)
-        auto piece_off = [&](const WsTile& t, int k) -> long {
-            const int lp = k * 8 + (t2 >> 4);
-            const int c8 = (t2 & 15) ^ (lp & 15);
-            const int px = lp & (TW - 1), py = lp >> TWl;
-            return (long)((((size_t)t.n0 * p.OH + t.oy0 + py) * p.OW + t.ox0 + px) * p.Cout + t.cot * 128 + c8 * 8);
+        // output-tile pieces of this thread: L = k*128 + t2 (k = 0..31): pixel lp = k*8 + (t2 >> 4), cout piece (t2 & 15) ^ (lp & 15).
+        // Element offset of piece k = tile_base(tile) + piece_u(k) * Cout + lpar[k & 1]: a uniform part and two per-lane constants.
+        const int pr = t2 >> 4;
+        const int lpar[2] = {pr * p.Cout + (((t2 & 15) ^ pr) * 8), pr * p.Cout + (((t2 & 15) ^ (pr | 8)) * 8)};
+        auto tile_base = [&](const WsTile& t) -> size_t {
+            return (((size_t)t.n0 * p.OH + t.oy0) * p.OW + t.ox0) * p.Cout + t.cot * 128;
+        };
+        auto piece_rel = [&](int k) -> int {
+            return ((k >> (TWl - 3)) * p.OW + (k & (TW / 8 - 1)) * 8) * p.Cout + lpar[k & 1];
         };
         auto drain = [&](const WsTile& t) {
             if (WS_DBG(4)) return;                  // timing-only ablation: no output drain
+            bf16* const ob = reinterpret_cast<bf16*>(p.out) + tile_base(t);
 #pragma unroll 1
             for (int k = 0; k < 32; k += 4) {
                 bf16x8 v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(ro + ((k + u) * 128 + t2) * 16);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + piece_off(t, k + u)) = v[u];
+                for (int u = 0; u < 4; ++u) *reinterpret_cast<bf16x8*>(ob + piece_rel(k + u)) = v[u];
             }
         };
         auto fetch_table = [&](const WsTile& t) {            // bias[128] (2 x 64 floats) and this image's temb row: 4-byte DMA, 256 B per instruction
@@ -374,34 +382,14 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             }
         };
         const bool do_res = p.residual != nullptr && !(WS_DBG(8));
-        auto fetch_residual = [&](const WsTile& t, int k0, int k1) {
+        auto fetch_residual_at = [&](const bf16* rb, int k0, int k1) {      // rb = residual + tile_base(tile)
             if (!do_res) return;
 #pragma unroll 1
             for (int k = k0; k < k1; ++k)
-                __builtin_amdgcn_global_load_lds(WS_GPTR(p.residual + piece_off(t, k)), WS_LPTR(ro + (k * 128 + bw * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(WS_GPTR(rb + piece_rel(k)), WS_LPTR(ro + (k * 128 + bw * 64) * 16), 16, 0, 0);
         };
-        // pieces k0 .. k1-1 of this wave's share of the tile switch: previous tile's output pieces out, this tile's residual
-        // pieces into the same LDS rows (a wave refills exactly the rows it drained; its reads are complete when the stores
-        // that consume them have issued).  Returns the number of vector-memory operations it issued.
+        auto fetch_residual = [&](const WsTile& t, int k0, int k1) { fetch_residual_at(p.residual + tile_base(t), k0, k1); };
         const bool do_drain = !(WS_DBG(4));
-        auto tile_switch = [&](const WsTile& pt, const WsTile& ct, int k0, int k1) -> int {
-#pragma unroll 1
-            for (int k = k0; k < k1; k += 4) {
-                const int n = k1 - k < 4 ? k1 - k : 4;
-                if (do_drain) {
-                    bf16x8 v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (u < n) v[u] = *reinterpret_cast<const bf16x8*>(ro + ((k + u) * 128 + t2) * 16);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (u < n) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + piece_off(pt, k + u)) = v[u];
-                }
-                fetch_residual(ct, k, k + n);
-            }
-            return (k1 - k0) * ((do_drain ? 1 : 0) + (do_res ? 1 : 0));
-        };
-
         WsTile cur;
         tile_of(q, cur);
         // table rows that no DMA fills stay zero
@@ -421,14 +409,32 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         // CU) is issued in one burst: a DMA costs its wave ~100+ cycles of issue, and a mover that arrives late at a step
         // barrier stalls the MFMA waves (stamp build: 1.5k cycles per chunk for the halo burst, up to 6.6k with the tile
         // switch behind it).  Per step a mover issues two halo blocks (steps 0-5) and its share of the tile switch's pieces
-        // (spread over the first nchunks-1 chunks, steps 0-7).  vmcnt retires in order: the wait for the halo image at a
+        // (spread over the first nchunks-1 chunks, all nine steps).  vmcnt retires in order: the wait for the halo image at a
         // chunk's last step leaves in flight exactly the tile-switch operations issued after the last halo block.
         const int kpc = (32 + nchunks - 2) / (nchunks - 1);      // tile-switch pieces per chunk
-        const int pps = (kpc + 7) >> 3;                          // ... per step
+        // pieces [ka, kb) that step t of chunk c moves (empty before the first tile switch and in a tile's last chunk)
+        auto piece_range = [&](int c, int t, int& ka, int& kb) {
+            ka = kb = 32;
+            if (!have_prev || c + 1 >= nchunks) return;
+            const int k0 = c * kpc < 32 ? c * kpc : 32, k1 = k0 + kpc < 32 ? k0 + kpc : 32;
+            const int i0 = t < 6 ? t : 6 + 2 * (t - 6), i1 = t < 6 ? t + 1 : i0 + 2;
+            ka = k0 + i0 < k1 ? k0 + i0 : k1;
+            kb = k0 + i1 < k1 ? k0 + i1 : k1;
+        };
+        bf16x8 vcur[2], vnext[2];
+        bool pre_valid = false;
+        auto read_pieces = [&](int ka, int kb, bf16x8 (&v)[2]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (ka + u < kb) v[u] = *reinterpret_cast<const bf16x8*>(ro + ((ka + u) * 128 + t2) * 16);
+        };
         for (;;) {
             const bool more = q + qstride < ntiles;
             WsTile nxt = cur;
             if (more) tile_of(q + qstride, nxt);
+            // element bases of the tile switch, once per tile (64-bit multiplies are quarter rate)
+            bf16* const out_prev = reinterpret_cast<bf16*>(p.out) + tile_base(prev);
+            const bf16* const res_cur = p.residual + tile_base(cur);
             for (int c = 0; c < nchunks; ++c) {
                 const bool wrap = c + 1 == nchunks;
                 if (c == 0 && have_prev) fetch_table(cur);       // older than this chunk's halo DMAs: complete at its last barrier
@@ -436,30 +442,39 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 const bool do_halo = !wrap || more;
                 char* const hbuf = halo0 + ((c + 1) & 1) * WS_HALO;
                 const int hc = wrap ? 0 : c + 1;
-                int k0 = 32, k1 = 32;
-                if (have_prev && !wrap) {
-                    k0 = c * kpc < 32 ? c * kpc : 32;
-                    k1 = k0 + kpc < 32 ? k0 + kpc : 32;
-                }
                 int young = 0;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     if (t < 6 && do_halo) halo_issue(hc, hbuf, 2 * t, 2 * t + 2);
-                    if (t < 8) {
-                        const int ka = k0 + t * pps < k1 ? k0 + t * pps : k1, kb = ka + pps < k1 ? ka + pps : k1;
-                        if (ka < kb) {
-                            const int n = tile_switch(prev, cur, ka, kb);
-                            if (t >= 5) young += n;
+                    // tile-switch pieces of this step (piece_range: one per step while the halo blocks are being issued, two per
+                    // step afterwards — at most four vector-memory instructions per mover and step).  Their LDS reads were
+                    // issued one step ahead (completed by the barrier's lgkmcnt wait), so a step's chain is store + DMA only.
+                    int ka, kb, na, nb_;
+                    piece_range(c, t, ka, kb);
+                    if (ka < kb) {
+                        if (!pre_valid) read_pieces(ka, kb, vcur);       // first pieces of a tile switch: nothing was read ahead
+                        if (do_drain) {
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+                                if (ka + u < kb) *reinterpret_cast<bf16x8*>(out_prev + piece_rel(ka + u)) = vcur[u];
                         }
+                        fetch_residual_at(res_cur, ka, kb);
+                        if (t >= 5) young += (kb - ka) * ((do_drain ? 1 : 0) + (do_res ? 1 : 0));   // issued after the last halo block
                     }
+                    if (t < 8) piece_range(c, t + 1, na, nb_); else piece_range(c + 1, 0, na, nb_);
+                    pre_valid = na < nb_;
+                    if (pre_valid) read_pieces(na, nb_, vnext);
                     if (t == 8) {
                         // halo image (and everything older) landed; at the last chunk E1 needs the whole residual tile
                         if (wrap) ws_wait_vm(0);
                         else ws_wait_vm(young);
                     }
-                    if (!(WS_DBG(16))) ws_barrier();                                // B_g
+                    if (!(WS_DBG(16))) ws_barrier();                                // B_g (its lgkmcnt(0) completes the reads ahead)
+                    vcur[0] = vnext[0];
+                    vcur[1] = vnext[1];
                 }
             }
+            pre_valid = false;                                   // the epilogue rewrites the output tile: nothing read ahead survives it
             ws_barrier();                                        // E1
             ws_barrier();                                        // E2
             prev = cur;
@@ -487,11 +502,24 @@ int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     if (a.OH % TH != 0 || a.OW % TW != 0) return 1;
     const int nchunks = (a.C0 + a.C1) / 32;
     if ((9 * nchunks) % WS_RING != 0 || nchunks % 2 != 0) return 1;   // ring slot / halo image of a step must not depend on the tile
+    if (nchunks < 4) return 1;   // the tile switch is spread over nchunks-1 chunks at <= 12 pieces per chunk
+    // 32-bit byte offsets inside either input part (the movers' per-tile source tables)
+    if ((long)a.N * a.IH * a.IW * (a.C0 > a.C1 ? a.C0 : a.C1) * 2 >= (1L << 31)) return 1;
     if (kernel_id) {
         *kernel_id = 400000 + TW;    // conv_ws_kernel<TW>
         return DXMI_OK;
     }
+    static const void* zero_page = nullptr;
+    if (!zero_page) {
+        void* zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(ws_zero16)) != hipSuccess || !zp) {
+            dxmi_set_error("dxmi_conv2d_fwd(ws): hipGetSymbolAddress(ws_zero16) failed");
+            return DXMI_EINVAL;
+        }
+        zero_page = zp;
+    }
     ConvArgs b = a;
+    b.mask_src = reinterpret_cast<const bf16*>(zero_page);    // the kernel has no activation mask: the field carries the zero page
     b.SUBS = 1;
     b.PT = a.N * (a.OH / TH) * (a.OW / TW);
     b.CT = a.Cout / 128;
