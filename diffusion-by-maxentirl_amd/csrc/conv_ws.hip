@@ -401,7 +401,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         halo_issue(0, halo0, 0, HB2);
         fetch_table(cur);
         fetch_residual(cur, 0, 32);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // P0 needs the halo image and the table, not the residual tile (32 younger DMAs; E1's vmcnt(0) covers them)
+        if (do_res) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ws_barrier();                                           // P0
         bool have_prev = false;
         WsTile prev = cur;

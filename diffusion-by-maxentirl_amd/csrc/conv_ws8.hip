@@ -229,7 +229,10 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
         const int bw = wave - 6;
         const int t2 = bw * 64 + lane;                     // 0..127 over the two waves
         constexpr int HB2 = (W8_HALO_BLOCKS + 1) / 2;      // halo blocks per wave (block bw + 2k)
-        int hsrc[HB2];
+        // per tile each lane keeps the BYTE offset of its source piece inside either concat part (-1: zero padding): a DMA
+        // address per chunk is then one 64-bit add and a select (no 64-bit multiply, no GOT load of the zero page per DMA)
+        const char* const zero_page = reinterpret_cast<const char*>(p.mask_src);    // 16 zero bytes (host: &w8_zero16)
+        int hoff0[HB2], hoff1[HB2];
         auto halo_plan = [&](const W8Tile& t) {
 #pragma unroll
             for (int k = 0; k < HB2; ++k) {
@@ -238,22 +241,22 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
                 const int hy = r / W8_HP, hx = r - hy * W8_HP;
                 const int iy = hy - 1, ix = hx - 1;
                 const bool ok = sub < 4 && t.n0 + sub < p.N && iy >= 0 && ix >= 0 && iy < 8 && ix < 8;
-                hsrc[k] = ok ? ((t.n0 + sub) * 8 + iy) * 8 + ix : -1;
+                const int pix = ((t.n0 + sub) * 8 + iy) * 8 + ix;
+                const int j8 = ((lane & 3) ^ (hx & 2)) * 8;
+                hoff0[k] = ok ? (pix * p.C0 + j8) * 2 : -1;
+                hoff1[k] = ok ? (pix * p.C1 + j8) * 2 : -1;
             }
         };
         auto halo_issue = [&](int c, char* buf, int ka, int kb) {     // blocks ka .. kb-1 of this wave's share (compile-time range)
             const int cbase = c * 32;
             const bool first = cbase < p.C0;
-            const bf16* src = first ? p.in0 : p.in1;
-            const int Cs = first ? p.C0 : p.C1;
-            const int coff = first ? cbase : cbase - p.C0;
+            const char* base = reinterpret_cast<const char*>(first ? p.in0 : p.in1) + (first ? cbase : cbase - p.C0) * 2;
 #pragma unroll
             for (int k = 0; k < HB2; ++k) {
                 if (k < ka || k >= kb) continue;
                 const int blk = bw + 2 * k;
-                const int hx = ((blk * 16 + (lane >> 2)) % W8_HS) % W8_HP;
-                const int j8 = ((lane & 3) ^ (hx & 2)) * 8;
-                const void* g = hsrc[k] >= 0 ? (const void*)(src + (size_t)hsrc[k] * Cs + coff + j8) : (const void*)&w8_zero16;
+                const int off = first ? hoff0[k] : hoff1[k];
+                const char* g = off >= 0 ? base + off : zero_page;
                 if (blk < W8_HALO_BLOCKS)
                     __builtin_amdgcn_global_load_lds(W8_GPTR(g), W8_LPTR(buf + blk * 1024), 16, 0, 0);
             }
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
 #pragma unroll 1
             for (int k = k0; k < k1; ++k) {
                 const long o = piece_off(t, k);
-                const void* g = o >= 0 ? (const void*)(p.residual + o) : (const void*)&w8_zero16;
+                const void* g = o >= 0 ? (const void*)(p.residual + o) : (const void*)zero_page;
                 __builtin_amdgcn_global_load_lds(W8_GPTR(g), W8_LPTR(ro + (k * 128 + bw * 64) * 16), 16, 0, 0);
             }
         };
@@ -325,7 +328,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
         halo_issue(0, halo0, 0, HB2);
         fetch_table(cur);
         fetch_residual(cur, 0, 16);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // P0 needs the halo image and the table, not the residual tile (16 younger DMAs; E1's vmcnt(0) covers them)
+        if (do_res) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         w8_barrier();                                           // P0
         bool have_prev = false;
         W8Tile prev = cur;
@@ -402,11 +407,22 @@ int conv_ws8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     const int nchunks = (a.C0 + a.C1) / 32;
     if (nchunks < 4 || nchunks % 2 != 0 || (9 * nchunks) % W8_RING != 0) return 1;
     // no batch-size condition: an image's result must not depend on the batch it rides in (the kernels differ in summation order)
+    if ((long)a.N * 64 * (a.C0 > a.C1 ? a.C0 : a.C1) * 2 >= (1L << 31)) return 1;   // 32-bit byte offsets inside either input part
     if (kernel_id) {
         *kernel_id = 400008;    // conv_ws8_kernel
         return DXMI_OK;
     }
+    static const void* zero_page = nullptr;
+    if (!zero_page) {
+        void* zp = nullptr;
+        if (hipGetSymbolAddress(&zp, HIP_SYMBOL(w8_zero16)) != hipSuccess || !zp) {
+            dxmi_set_error("dxmi_conv2d_fwd(ws8): hipGetSymbolAddress(w8_zero16) failed");
+            return DXMI_EINVAL;
+        }
+        zero_page = zp;
+    }
     ConvArgs b = a;
+    b.mask_src = reinterpret_cast<const bf16*>(zero_page);    // the kernel has no activation mask: the field carries the zero page
     b.SUBS = 4;
     b.PT = (a.N + 3) / 4;      // the last tile may hold fewer than four images (masked)
     b.CT = a.Cout / 64;
