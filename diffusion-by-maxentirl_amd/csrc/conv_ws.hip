@@ -29,7 +29,7 @@
 
 #ifdef DXMI_CONV_STAMPS
 // timing-only build (make STAMPS=1): cycles MFMA wave 0 of every workgroup spends in each step barrier (tools/ws_stamps.py)
-__device__ unsigned g_ws_wait[256][160];
+__device__ unsigned g_ws_wait[256][176];
 extern "C" int dxmi_debug_read_ws_stamps(void* dst, int bytes) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ws_wait), bytes, 0, hipMemcpyDeviceToHost);
 }
@@ -40,11 +40,16 @@ extern "C" int dxmi_debug_read_ws_stamps(void* dst, int bytes) {
         const unsigned long long t1_ = __builtin_amdgcn_s_memtime();                                \
         if (wave == 0 && lane == 0 && (idx) < 160 && blockIdx.x < 256) g_ws_wait[blockIdx.x][(idx)] = (unsigned)(t1_ - t0_); \
     } while (0)
+#define WS_TSTAMP(slot, cond)                                                                        \
+    do {                                                                                            \
+        if ((cond) && lane == 0 && blockIdx.x < 256) g_ws_wait[blockIdx.x][(slot)] = (unsigned)__builtin_amdgcn_s_memtime(); \
+    } while (0)
 // timing-only ablations of the diagnostic build (DXMI_CONV_WS_DBG bits: 1 no weight stream, 2 no halo stream, 4 no drain,
 // 8 no residual / table fetch, 16 no step barriers — wrong results); compiled out of the product library
 #define WS_DBG(bit) (p.stagger & (bit))
 #else
 #define WS_STAMPED_BARRIER(idx) ws_barrier()
+#define WS_TSTAMP(slot, cond) do {} while (0)
 #define WS_DBG(bit) 0
 #endif
 
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 }
             }
             ws_barrier();                               // E2: output tile complete, the bulk movers may drain it
+            WS_TSTAMP(157, wave == 0 && q == (int)blockIdx.x);
             if (!more) break;
             q += qstride;
             stamp_i += S;
@@ -281,10 +287,28 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         for (int g = 0; g < WS_RING - 1; ++g) issue_tap(cur.cot, g);
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tap 0 landed (4 younger taps may be outstanding)
         ws_barrier();                                       // P0
+        bool first_tile = true;
         for (;;) {
             const bool more = q + qstride < ntiles;
             WsTile nxt = cur;
             if (more) tile_of(q + qstride, nxt);
+            if (!first_tile && lw == 0 && !(WS_DBG(8))) {
+                // bias / temb table of this tile (the first tile's is fetched by the bulk movers' prologue): the loaders have slack
+                // at a tile start, the bulk movers do not.  4-byte DMA, 256 B per instruction; issued after E2 (the previous
+                // tile's epilogue is done with the table), complete well before E1: a loader's vmcnt(16) waits leave only the 16
+                // youngest operations in flight and it issues four per step (being younger than the taps in flight, the table
+                // only makes those waits wait for a little more).
+                if (p.bias) {
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + cur.cot * 128 + lane), WS_LPTR(tb), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + cur.cot * 128 + 64 + lane), WS_LPTR(tb + 64), 4, 0, 0);
+                }
+                if (p.addvec) {
+                    const float* av = p.addvec + (size_t)cur.n0 * p.addvec_ld + cur.cot * 128;
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + lane), WS_LPTR(tb + 128), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + 64 + lane), WS_LPTR(tb + 192), 4, 0, 0);
+                }
+            }
+            first_tile = false;
             for (int g = 0; g < S; ++g) {
                 const int g3 = g + WS_RING - 1;
                 bool issued = true;
@@ -295,10 +319,12 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 // tile) the count of younger DMAs shrinks, so everything is awaited
                 if (issued) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                WS_TSTAMP(151, wave == 4 && g == 0 && q == (int)blockIdx.x + qstride);
                 if (!(WS_DBG(16))) ws_barrier();                                    // B_g
             }
             ws_barrier();                                        // E1
             ws_barrier();                                        // E2
+            WS_TSTAMP(150, wave == 4 && q == (int)blockIdx.x);
             if (!more) break;
             q += qstride;
             cur = nxt;
@@ -318,31 +344,47 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         // what bounds this kernel, and 64-bit multiplies or a GOT load of the zero page per DMA (what the straightforward
         // expression compiles to) cost more than the DMA itself.
         const char* const zero_page = reinterpret_cast<const char*>(p.mask_src);    // 16 zero bytes (host: &ws_zero16)
-        int hoff0[HB2], hoff1[HB2];
-        auto halo_plan = [&](const WsTile& t) {
+        // once per kernel: offset of every block lane's source piece relative to the tile's first input pixel (either concat
+        // part), and which of its blocks lie on the halo's border rows / columns; per TILE the plan is then a handful of scalar
+        // operations (the per-tile version of this loop cost the movers ~2 k cycles at every tile start)
+        int hrel0[HB2], hrel1[HB2];
+        unsigned m_in = 0, m_top = 0, m_bot = 0, m_left = 0, m_right = 0;
 #pragma unroll
-            for (int k = 0; k < HB2; ++k) {
-                const int hp = (bw + 2 * k) * 16 + (lane >> 2);
-                const int hy = hp / HP, hx = hp - hy * HP;
-                const int iy = t.oy0 - 1 + hy, ix = t.ox0 - 1 + hx;
-                const bool ok = hy < HH && hx < TW + 2 && iy >= 0 && ix >= 0 && iy < (p.IH << ups) && ix < (p.IW << ups);
-                const int pix = (t.n0 * p.IH + (iy >> ups)) * p.IW + (ix >> ups);
-                const int j8 = ((lane & 3) ^ (2 * ((hx >> 2) & 1))) * 8;
-                hoff0[k] = ok ? (pix * p.C0 + j8) * 2 : -1;
-                hoff1[k] = ok ? (pix * p.C1 + j8) * 2 : -1;
-            }
+        for (int k = 0; k < HB2; ++k) {
+            const int hp = (bw + 2 * k) * 16 + (lane >> 2);
+            const int hy = hp / HP, hx = hp - hy * HP;
+            const int rel = ((hy - 1) >> ups) * p.IW + ((hx - 1) >> ups);      // tile origins are even: (o - 1 + h) >> ups == (o >> ups) + ((h - 1) >> ups)
+            const int j8 = ((lane & 3) ^ (2 * ((hx >> 2) & 1))) * 8;
+            hrel0[k] = (rel * p.C0 + j8) * 2;
+            hrel1[k] = (rel * p.C1 + j8) * 2;
+            m_in |= (unsigned)(hy < HH && hx < TW + 2) << k;
+            m_top |= (unsigned)(hy == 0) << k;
+            m_bot |= (unsigned)(hy == HH - 1) << k;
+            m_left |= (unsigned)(hx == 0) << k;
+            m_right |= (unsigned)(hx == TW + 1) << k;
+        }
+        unsigned hmask = 0;          // blocks of the planned tile whose source pixel exists (the others are zero padding)
+        int hbase0 = 0, hbase1 = 0;  // byte offset of the planned tile's first input pixel in either concat part
+        auto halo_plan = [&](const WsTile& t) {
+            hmask = m_in;
+            if (t.oy0 == 0) hmask &= ~m_top;
+            if (t.oy0 + TH == p.OH) hmask &= ~m_bot;
+            if (t.ox0 == 0) hmask &= ~m_left;
+            if (t.ox0 + TW == p.OW) hmask &= ~m_right;
+            const int pix = (t.n0 * p.IH + (t.oy0 >> ups)) * p.IW + (t.ox0 >> ups);
+            hbase0 = pix * p.C0 * 2;
+            hbase1 = pix * p.C1 * 2;
         };
         auto halo_issue = [&](int c, char* buf, int ka, int kb) {     // blocks ka .. kb-1 of this wave's share (compile-time range)
             if (WS_DBG(2)) return;                  // timing-only ablation: no halo stream
             const int cbase = c * 32;
             const bool first = cbase < p.C0;
-            const char* base = reinterpret_cast<const char*>(first ? p.in0 : p.in1) + (first ? cbase : cbase - p.C0) * 2;
+            const char* base = reinterpret_cast<const char*>(first ? p.in0 : p.in1) + (first ? cbase : cbase - p.C0) * 2 + (first ? hbase0 : hbase1);
 #pragma unroll
             for (int k = 0; k < HB2; ++k) {
                 if (k < ka || k >= kb) continue;
                 const int blk = bw + 2 * k;
-                const int off = first ? hoff0[k] : hoff1[k];
-                const char* g = off >= 0 ? base + off : zero_page;
+                const char* g = (hmask >> k) & 1 ? base + (first ? hrel0[k] : hrel1[k]) : zero_page;
                 if (blk < WS_HALO_BLOCKS)
                     __builtin_amdgcn_global_load_lds(WS_GPTR(g), WS_LPTR(buf + blk * 1024), 16, 0, 0);
             }
@@ -425,6 +467,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         };
         bf16x8 vcur[2], vnext[2];
         bool pre_valid = false;
+        WsTile nxt = cur;
+        bf16* out_prev = reinterpret_cast<bf16*>(p.out);          // element bases of the tile switch (valid from the second tile on)
+        const bf16* res_cur = p.residual;
+        bf16* out_next = out_prev;
+        const bf16* res_next = res_cur;
         auto read_pieces = [&](int ka, int kb, bf16x8 (&v)[2]) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -432,15 +479,18 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         };
         for (;;) {
             const bool more = q + qstride < ntiles;
-            WsTile nxt = cur;
-            if (more) tile_of(q + qstride, nxt);
-            // element bases of the tile switch, once per tile (64-bit multiplies are quarter rate)
-            bf16* const out_prev = reinterpret_cast<bf16*>(p.out) + tile_base(prev);
-            const bf16* const res_cur = p.residual + tile_base(cur);
+            WS_TSTAMP(160, wave == 6 && q == (int)blockIdx.x + qstride);
             for (int c = 0; c < nchunks; ++c) {
                 const bool wrap = c + 1 == nchunks;
-                if (c == 0 && have_prev) fetch_table(cur);       // older than this chunk's halo DMAs: complete at its last barrier
-                if (wrap && more) halo_plan(nxt);
+                WS_TSTAMP(163, wave == 6 && c == 0 && q == (int)blockIdx.x + qstride);
+                if (wrap && more) {
+                    // the last chunk of a tile carries no tile-switch pieces: the next tile's coordinates (integer divisions),
+                    // element bases (64-bit multiplies) and halo plan are computed here, off the tile start's critical path
+                    tile_of(q + qstride, nxt);
+                    out_next = reinterpret_cast<bf16*>(p.out) + tile_base(cur);
+                    res_next = p.residual + tile_base(nxt);
+                    halo_plan(nxt);
+                }
                 const bool do_halo = !wrap || more;
                 char* const hbuf = halo0 + ((c + 1) & 1) * WS_HALO;
                 const int hc = wrap ? 0 : c + 1;
@@ -448,6 +498,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     if (t < 6 && do_halo) halo_issue(hc, hbuf, 2 * t, 2 * t + 2);
+                    WS_TSTAMP(164, wave == 6 && c == 0 && t == 0 && q == (int)blockIdx.x + qstride);
                     // tile-switch pieces of this step (piece_range: one per step while the halo blocks are being issued, two per
                     // step afterwards — at most four vector-memory instructions per mover and step).  Their LDS reads were
                     // issued one step ahead (completed by the barrier's lgkmcnt wait), so a step's chain is store + DMA only.
@@ -463,6 +514,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                         fetch_residual_at(res_cur, ka, kb);
                         if (t >= 5) young += (kb - ka) * ((do_drain ? 1 : 0) + (do_res ? 1 : 0));   // issued after the last halo block
                     }
+                    WS_TSTAMP(165, wave == 6 && c == 0 && t == 0 && q == (int)blockIdx.x + qstride);
                     if (t < 8) piece_range(c, t + 1, na, nb_); else piece_range(c + 1, 0, na, nb_);
                     pre_valid = na < nb_;
                     if (pre_valid) read_pieces(na, nb_, vnext);
@@ -471,6 +523,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                         if (wrap) ws_wait_vm(0);
                         else ws_wait_vm(young);
                     }
+                    WS_TSTAMP(153 + (t < 3 ? t : 3), wave == 6 && c == 0 && t < 3 && q == (int)blockIdx.x + qstride);
                     if (!(WS_DBG(16))) ws_barrier();                                // B_g (its lgkmcnt(0) completes the reads ahead)
                     vcur[0] = vnext[0];
                     vcur[1] = vnext[1];
@@ -479,11 +532,14 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             pre_valid = false;                                   // the epilogue rewrites the output tile: nothing read ahead survives it
             ws_barrier();                                        // E1
             ws_barrier();                                        // E2
+            WS_TSTAMP(152, wave == 6 && q == (int)blockIdx.x);
             prev = cur;
             have_prev = true;
             if (!more) break;
             q += qstride;
             cur = nxt;
+            out_prev = out_next;
+            res_cur = res_next;
         }
         drain(prev);
     }

@@ -18,7 +18,7 @@ for _ in range(5):
     ops.conv2d(x, pw, bias=bias, residual=r, out=out)
 torch.cuda.synchronize()
 lib = ctypes.CDLL(_lib.LIB_PATH)
-buf = np.zeros((256, 160), dtype=np.uint32)
+buf = np.zeros((256, 176), dtype=np.uint32)
 lib.dxmi_debug_read_ws_stamps(buf.ctypes.data_as(ctypes.c_void_p), buf.nbytes)
 w = buf.astype(np.int64)
 np.set_printoptions(linewidth=250, suppress=True)
@@ -29,3 +29,15 @@ print(f"{cin}->{cout} @{h} res={res}: steps per tile {S}; median barrier wait pe
 for i in range(0, n, 9):
     print(f"  steps {i:3d}..{i+8:3d}:", " ".join(f"{v:6.0f}" for v in med[i:i + 9]))
 print("sum over a tile (median wg):", med[:S].sum(), " second tile:", med[S:2 * S].sum() if n >= 2 * S else "-")
+# tile-switch timeline (second tile of every workgroup): ticks relative to the loader's E2 exit
+ts = w[:, 150:158]
+ok = ts[:, 0] > 0
+rel = (ts[ok] - ts[ok][:, [0]]) & 0xFFFFFFFF
+rel = np.where(rel > 1 << 31, rel - (1 << 32), rel)
+print("after E2 (ticks, median): loader E2 exit 0, loader at B_0", np.median(rel[:, 1]), "| bulk E2 exit", np.median(rel[:, 2]),
+      "bulk at B_0 / B_1 / B_2", np.median(rel[:, 3]), np.median(rel[:, 4]), np.median(rel[:, 5]), "| MFMA wave 0 E2 exit", np.median(rel[:, 7]))
+fine = w[:, 160:166]
+okf = ok & (fine[:, 0] > 0) & (fine[:, 3] > 0)
+relf = (fine[okf] - ts[okf][:, [0]]) & 0xFFFFFFFF
+print("bulk wave 6 after E2 (ticks, median): loop top, -, -, after fetch_table, after halo(2), after first piece:",
+      [float(np.median(relf[:, i])) for i in (0, 3, 4, 5)])
