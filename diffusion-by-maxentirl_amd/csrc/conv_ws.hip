@@ -40,6 +40,13 @@ extern "C" int dxmi_debug_read_ws_stamps(void* dst, int bytes) {
         const unsigned long long t1_ = __builtin_amdgcn_s_memtime();                                \
         if (wave == 0 && lane == 0 && (idx) < 160 && blockIdx.x < 256) g_ws_wait[blockIdx.x][(idx)] = (unsigned)(t1_ - t0_); \
     } while (0)
+#define WS_CLOCKSTAMP(slot, cond)                                                                    \
+    do {                                                                                            \
+        if ((cond) && lane == 0 && blockIdx.x < 256) {                                              \
+            g_ws_wait[blockIdx.x][(slot)] = (unsigned)__builtin_amdgcn_s_memtime();                 \
+            g_ws_wait[blockIdx.x][(slot) + 1] = (unsigned)__builtin_amdgcn_s_memrealtime();         \
+        }                                                                                           \
+    } while (0)
 #define WS_TSTAMP(slot, cond)                                                                        \
     do {                                                                                            \
         if ((cond) && lane == 0 && blockIdx.x < 256) g_ws_wait[blockIdx.x][(slot)] = (unsigned)__builtin_amdgcn_s_memtime(); \
@@ -50,6 +57,7 @@ extern "C" int dxmi_debug_read_ws_stamps(void* dst, int bytes) {
 #else
 #define WS_STAMPED_BARRIER(idx) ws_barrier()
 #define WS_TSTAMP(slot, cond) do {} while (0)
+#define WS_CLOCKSTAMP(slot, cond) do {} while (0)
 #define WS_DBG(bit) 0
 #endif
 
@@ -150,6 +158,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
     int q = blockIdx.x;
     if (q >= ntiles) return;
     const int qstride = gridDim.x;
+    WS_CLOCKSTAMP(172, wave == 0);
 
     if (wave < 4) {
         // ================================================================ MFMA waves: 64 couts (ch) x 128 pixels (ph)
@@ -199,9 +208,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         // (no s_setprio: giving the MFMA waves priority over the movers that share their SIMDs measured 5 % SLOWER on the
         // residual layers — late movers cost more than contended issue slots — and equal elsewhere)
         ws_barrier();                                   // P0: tap 0 and the first halo chunk have landed
+        WS_CLOCKSTAMP(168, wave == 0);
         read_a(0, A0);
         read_b(0, 0, Bx);
         int stamp_i = 0;                                // stamp build: index of the tile's first step
+        (void)stamp_i;
         for (;;) {
             const bool more = q + qstride < ntiles;
             // K loop: two chunks (18 steps) of straight-line code per iteration, no branches inside (a branch makes hipcc wait
@@ -224,10 +235,17 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            WS_TSTAMP(158, wave == 0 && q == (int)blockIdx.x);
             ws_barrier();                               // E1: residual tile + bias / temb table of this tile landed
+            WS_TSTAMP(159, wave == 0 && q == (int)blockIdx.x);
             {
                 // acc + bias + temb (+ residual) -> activation -> bf16 -> output tile, in place, accumulator layout:
-                // lane = pixel (lane & 15) of a 16-pixel block, couts 4 * (lane >> 4) .. + 3 of a 16-cout block
+                // lane = pixel (lane & 15) of a 16-pixel block, couts 4 * (lane >> 4) .. + 3 of a 16-cout block.  The epilogue is
+                // VALU work on the MFMA waves' critical path (stamp build: 4.2 k cycles per tile, 7.4 k with a residual, before
+                // this form): every address is a per-lane base + compile-time offset, the residual pieces of a cout block are
+                // requested together, and the activation code is skipped when there is none (the U-Net's convs).
+                const bool plain = p.act == DXMI_ACT_NONE;
+                char* const rowb = ro + ((ph * 128 + px) << 8) + 8 * (kg & 1);         // pixel row of block 0: blocks are 4 KiB apart
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
                     const int co = ch * 64 + cb * 16 + 4 * kg;
@@ -235,38 +253,45 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                     f32x4 bv;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) bv[e] = b0[e] + t0[e];
-                    const int c8 = ch * 8 + cb * 2 + (kg >> 1);
+                    char* const a0 = rowb + (((ch * 8 + cb * 2 + (kg >> 1)) ^ px) << 4);   // slot of this cout piece: (c8 ^ (pixel & 15))
+                    bf16x4 r[8];
+                    if (has_res) {
+#pragma unroll
+                        for (int nb = 0; nb < 8; ++nb) r[nb] = *reinterpret_cast<const bf16x4*>(a0 + nb * 4096);
+                    }
 #pragma unroll
                     for (int nb = 0; nb < 8; ++nb) {
-                        const int lp = (ph * 8 + nb) * 16 + px;
-                        char* a = ro + (lp * 16 + (c8 ^ (lp & 15))) * 16 + 8 * (kg & 1);
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = acc[cb][nb][e] + bv[e];
                         if (has_res) {
-                            const bf16x4 r = *reinterpret_cast<const bf16x4*>(a);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+                            for (int e = 0; e < 4; ++e) v[e] += (float)r[nb][e];
+                        }
+                        if (!plain) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = dxmi_act_lin(v[e], slope);
                         }
                         bf16x4 o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (bf16)dxmi_act_lin(v[e], slope);
-                        *reinterpret_cast<bf16x4*>(a) = o;
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+                        *reinterpret_cast<bf16x4*>(a0 + nb * 4096) = o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[cb][nb][e] = 0.f;
                     }
                 }
             }
+            WS_TSTAMP(166, wave == 0 && q == (int)blockIdx.x);
             ws_barrier();                               // E2: output tile complete, the bulk movers may drain it
             WS_TSTAMP(157, wave == 0 && q == (int)blockIdx.x);
-            if (!more) break;
+            if (!more) {
+                WS_CLOCKSTAMP(170, wave == 0);
+                break;
+            }
             q += qstride;
             stamp_i += S;
         }
-        return;
-    }
-
-    if (wave < 6) {
+    } else if (wave < 6) {
         // ================================================================ weight loaders (waves 4, 5)
         const int lw = wave - 4;
         const char* const wb = reinterpret_cast<const char*>(p.w) + (size_t)lane * 16;
@@ -330,11 +355,8 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             cur = nxt;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
-
+    } else {
     // ==================================================================== bulk movers (waves 6, 7)
-    {
         const int bw = wave - 6;
         const int t2 = bw * 64 + lane;                     // 0..127 over the two waves
         constexpr int HB2 = (WS_HALO_BLOCKS + 1) / 2;      // halo blocks per wave
@@ -398,18 +420,6 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         };
         auto piece_rel = [&](int k) -> int {
             return ((k >> (TWl - 3)) * p.OW + (k & (TW / 8 - 1)) * 8) * p.Cout + lpar[k & 1];
-        };
-        auto drain = [&](const WsTile& t) {
-            if (WS_DBG(4)) return;                  // timing-only ablation: no output drain
-            bf16* const ob = reinterpret_cast<bf16*>(p.out) + tile_base(t);
-#pragma unroll 1
-            for (int k = 0; k < 32; k += 4) {
-                bf16x8 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(ro + ((k + u) * 128 + t2) * 16);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) *reinterpret_cast<bf16x8*>(ob + piece_rel(k + u)) = v[u];
-            }
         };
         auto fetch_table = [&](const WsTile& t) {            // bias[128] (2 x 64 floats) and this image's temb row: 4-byte DMA, 256 B per instruction
             if (bw != 0 || (WS_DBG(8))) return;
@@ -541,7 +551,32 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             out_prev = out_next;
             res_cur = res_next;
         }
-        drain(prev);
+    }
+
+    // ==================================================================== last tile out: all eight waves
+    // (every wave has passed the last E2; the two bulk movers alone needed ~3 us for the 64 KB)
+    {
+        const int qlast = (int)blockIdx.x + ((ntiles - 1 - (int)blockIdx.x) / qstride) * qstride;
+        WsTile lt;
+        tile_of(qlast, lt);
+        bf16* const ob = reinterpret_cast<bf16*>(p.out) + ((((size_t)lt.n0 * p.OH + lt.oy0) * p.OW + lt.ox0) * p.Cout + lt.cot * 128);
+        const int t2 = tid & 127, kq = tid >> 7;      // piece L = k*128 + t2, k = 4 i + kq
+        const int pr = t2 >> 4;
+#pragma unroll
+        for (int i = 0; i < 8; i += 4) {
+            bf16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(ro + (((i + u) * 4 + kq) * 128 + t2) * 16);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = (i + u) * 4 + kq;
+                const int lp = k * 8 + pr;
+                const int c8 = (t2 & 15) ^ (lp & 15);
+                const int rel = ((lp >> TWl) * p.OW + (lp & (TW - 1))) * p.Cout + c8 * 8;
+                *reinterpret_cast<bf16x8*>(ob + rel) = v[u];
+            }
+        }
+        WS_CLOCKSTAMP(174, wave == 0);
     }
 }
 
