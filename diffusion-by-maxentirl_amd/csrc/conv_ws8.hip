@@ -147,32 +147,44 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
                 }
             }
             w8_barrier();                               // E1: residual tile + bias / temb table of this tile landed
+            {
+                // per-lane base + compile-time offsets, the residual pieces of a cout block requested together, no activation
+                // code when there is none (as conv_ws.hip)
+                const bool plain = p.act == DXMI_ACT_NONE;
+                char* const rowb = ro + ((wave * 64 + px) << 7) + 8 * (kg & 1);      // pixel row of block 0: blocks are 2 KiB apart
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                const int co = cb * 16 + 4 * kg;
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb + co), t0 = *reinterpret_cast<const f32x4*>(tb + 64 + wave * 64 + co);
-                f32x4 bv;
+                for (int cb = 0; cb < 4; ++cb) {
+                    const int co = cb * 16 + 4 * kg;
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb + co), t0 = *reinterpret_cast<const f32x4*>(tb + 64 + wave * 64 + co);
+                    f32x4 bv;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bv[e] = b0[e] + t0[e];
-                const int c8 = cb * 2 + (kg >> 1);
-#pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    const int lp = wave * 64 + nb * 16 + px;
-                    char* a = ro + (lp * 8 + (c8 ^ (lp & 7))) * 16 + 8 * (kg & 1);
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[cb][nb][e] + bv[e];
+                    for (int e = 0; e < 4; ++e) bv[e] = b0[e] + t0[e];
+                    char* const a0 = rowb + (((cb * 2 + (kg >> 1)) ^ (px & 7)) << 4);
+                    bf16x4 r[4];
                     if (has_res) {
-                        const bf16x4 r = *reinterpret_cast<const bf16x4*>(a);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+                        for (int nb = 0; nb < 4; ++nb) r[nb] = *reinterpret_cast<const bf16x4*>(a0 + nb * 2048);
                     }
-                    bf16x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (bf16)dxmi_act_lin(v[e], slope);
-                    *reinterpret_cast<bf16x4*>(a) = o;
+                    for (int nb = 0; nb < 4; ++nb) {
+                        f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[cb][nb][e] = 0.f;
+                        for (int e = 0; e < 4; ++e) v[e] = acc[cb][nb][e] + bv[e];
+                        if (has_res) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)r[nb][e];
+                        }
+                        if (!plain) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = dxmi_act_lin(v[e], slope);
+                        }
+                        bf16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+                        *reinterpret_cast<bf16x4*>(a0 + nb * 2048) = o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[cb][nb][e] = 0.f;
+                    }
                 }
             }
             w8_barrier();                               // E2: output tile complete, the bulk movers may drain it
