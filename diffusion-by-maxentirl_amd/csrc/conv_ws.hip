@@ -22,7 +22,7 @@
 // own cout columns), apply the activation, round ONCE to bf16 and write the output tile in place in LDS; two barriers.
 //
 // Scope: 3x3 / stride 1 / pad 1 (optionally behind a nearest x2 upsample), NHWC bf16 in (virtual concat) and out,
-// Cout % 128 == 0, an even number of 32-channel chunks, maps >= 16x16 (one image per 256-pixel tile); 8x8 maps: conv_ws8.hip.
+// Cout % 64 == 0 (half-empty last cout tile masked), an even number (>= 4) of 32-channel chunks, maps >= 16x16 (one image per 256-pixel tile); 8x8 maps: conv_ws8.hip.
 // Everything else stays on conv_pipe.hip.
 #include "conv_common.h"
 #include <stdlib.h>
@@ -303,10 +303,13 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             const int c = g / 9, t = g - c * 9;
             char* dst = aring + (g % WS_RING) * WS_A_SLOT + lw * 4096;
             // fragments (ks = lw, cbg = 0..3): contiguous 4 KiB of the packed weights
-            const char* src = wb + ((size_t)(t * p.KST + c * 2 + lw) * p.CB + cot * 4) * 1024;
+            const char* src = wb + ((size_t)(t * p.KST + c * 2 + lw) * p.CB) * 1024;
 #pragma unroll
-            for (int f = 0; f < 4; ++f)
-                __builtin_amdgcn_global_load_lds(WS_GPTR(src + f * 1024), WS_LPTR(dst + f * 1024), 16, 0, 0);
+            for (int f = 0; f < 4; ++f) {
+                // a half-empty last cout tile (Cout % 128 == 64): its missing fragments re-read the last valid one (results unused)
+                const int cb = cot * 4 + f < p.CB ? cot * 4 + f : p.CB - 1;
+                __builtin_amdgcn_global_load_lds(WS_GPTR(src + (size_t)cb * 1024), WS_LPTR(dst + f * 1024), 16, 0, 0);
+            }
         };
 #pragma unroll 1
         for (int g = 0; g < WS_RING - 1; ++g) issue_tap(cur.cot, g);
@@ -323,14 +326,16 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 // tile's epilogue is done with the table), complete well before E1: a loader's vmcnt(16) waits leave only the 16
                 // youngest operations in flight and it issues four per step (being younger than the taps in flight, the table
                 // only makes those waits wait for a little more).
+                // (couts past Cout in a half-empty last tile: clamped to the last valid one, results unused)
+                const int co_a = cur.cot * 128 + lane, co_b = co_a + 64 < p.Cout ? co_a + 64 : p.Cout - 1;
                 if (p.bias) {
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + cur.cot * 128 + lane), WS_LPTR(tb), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + cur.cot * 128 + 64 + lane), WS_LPTR(tb + 64), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_a), WS_LPTR(tb), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_b), WS_LPTR(tb + 64), 4, 0, 0);
                 }
                 if (p.addvec) {
-                    const float* av = p.addvec + (size_t)cur.n0 * p.addvec_ld + cur.cot * 128;
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + lane), WS_LPTR(tb + 128), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + 64 + lane), WS_LPTR(tb + 192), 4, 0, 0);
+                    const float* av = p.addvec + (size_t)cur.n0 * p.addvec_ld;
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_a), WS_LPTR(tb + 128), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_b), WS_LPTR(tb + 192), 4, 0, 0);
                 }
             }
             first_tile = false;
@@ -421,26 +426,32 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         auto piece_rel = [&](int k) -> int {
             return ((k >> (TWl - 3)) * p.OW + (k & (TW / 8 - 1)) * 8) * p.Cout + lpar[k & 1];
         };
+        // cout pieces past Cout (half-empty last cout tile): the lane's piece of even / odd k is c8e / c8o
+        const int c8e = (t2 & 15) ^ pr, c8o = (t2 & 15) ^ (pr | 8);
+        auto piece_ok = [&](const WsTile& t, int k) -> bool { return t.cot * 128 + ((k & 1) ? c8o : c8e) * 8 < p.Cout; };
         auto fetch_table = [&](const WsTile& t) {            // bias[128] (2 x 64 floats) and this image's temb row: 4-byte DMA, 256 B per instruction
             if (bw != 0 || (WS_DBG(8))) return;
+            const int co_a = t.cot * 128 + lane, co_b = co_a + 64 < p.Cout ? co_a + 64 : p.Cout - 1;
             if (p.bias) {
-                __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + t.cot * 128 + lane), WS_LPTR(tb), 4, 0, 0);
-                __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + t.cot * 128 + 64 + lane), WS_LPTR(tb + 64), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_a), WS_LPTR(tb), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_b), WS_LPTR(tb + 64), 4, 0, 0);
             }
             if (p.addvec) {
-                const float* av = p.addvec + (size_t)t.n0 * p.addvec_ld + t.cot * 128;
-                __builtin_amdgcn_global_load_lds(WS_GPTR(av + lane), WS_LPTR(tb + 128), 4, 0, 0);
-                __builtin_amdgcn_global_load_lds(WS_GPTR(av + 64 + lane), WS_LPTR(tb + 192), 4, 0, 0);
+                const float* av = p.addvec + (size_t)t.n0 * p.addvec_ld;
+                __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_a), WS_LPTR(tb + 128), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_b), WS_LPTR(tb + 192), 4, 0, 0);
             }
         };
         const bool do_res = p.residual != nullptr && !(WS_DBG(8));
-        auto fetch_residual_at = [&](const bf16* rb, int k0, int k1) {      // rb = residual + tile_base(tile)
+        auto fetch_residual_at = [&](const bf16* rb, const WsTile& t, int k0, int k1) {      // rb = residual + tile_base(t)
             if (!do_res) return;
 #pragma unroll 1
-            for (int k = k0; k < k1; ++k)
-                __builtin_amdgcn_global_load_lds(WS_GPTR(rb + piece_rel(k)), WS_LPTR(ro + (k * 128 + bw * 64) * 16), 16, 0, 0);
+            for (int k = k0; k < k1; ++k) {
+                const void* g = piece_ok(t, k) ? (const void*)(rb + piece_rel(k)) : (const void*)zero_page;
+                __builtin_amdgcn_global_load_lds(WS_GPTR(g), WS_LPTR(ro + (k * 128 + bw * 64) * 16), 16, 0, 0);
+            }
         };
-        auto fetch_residual = [&](const WsTile& t, int k0, int k1) { fetch_residual_at(p.residual + tile_base(t), k0, k1); };
+        auto fetch_residual = [&](const WsTile& t, int k0, int k1) { fetch_residual_at(p.residual + tile_base(t), t, k0, k1); };
         const bool do_drain = !(WS_DBG(4));
         WsTile cur;
         tile_of(q, cur);
@@ -518,10 +529,10 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                         if (!pre_valid) read_pieces(ka, kb, vcur);       // first pieces of a tile switch: nothing was read ahead
                         if (do_drain) {
 #pragma unroll
-                            for (int u = 0; u < 2; ++u)
-                                if (ka + u < kb) *reinterpret_cast<bf16x8*>(out_prev + piece_rel(ka + u)) = vcur[u];
+                            for (int u = 0; u < 2; ++u)      // (a store instruction always has valid lanes: every cout piece occurs in it)
+                                if (ka + u < kb && piece_ok(prev, ka + u)) *reinterpret_cast<bf16x8*>(out_prev + piece_rel(ka + u)) = vcur[u];
                         }
-                        fetch_residual_at(res_cur, ka, kb);
+                        fetch_residual_at(res_cur, cur, ka, kb);
                         if (t >= 5) young += (kb - ka) * ((do_drain ? 1 : 0) + (do_res ? 1 : 0));   // issued after the last halo block
                     }
                     WS_TSTAMP(165, wave == 6 && c == 0 && t == 0 && q == (int)blockIdx.x + qstride);
@@ -573,7 +584,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 const int lp = k * 8 + pr;
                 const int c8 = (t2 & 15) ^ (lp & 15);
                 const int rel = ((lp >> TWl) * p.OW + (lp & (TW - 1))) * p.Cout + c8 * 8;
-                *reinterpret_cast<bf16x8*>(ob + rel) = v[u];
+                if (lt.cot * 128 + c8 * 8 < p.Cout) *reinterpret_cast<bf16x8*>(ob + rel) = v[u];
             }
         }
         WS_CLOCKSTAMP(174, wave == 0);
@@ -588,7 +599,7 @@ int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     if (!enabled) return 1;
     if (a.in_mode != DXMI_IN_NHWC_BF16 || a.out_mode != DXMI_OUT_NHWC_BF16) return 1;
     if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups == 2 || a.mask_src || a.act == DXMI_ACT_SILU) return 1;
-    if (a.Cout % 128 != 0 || (a.C0 + a.C1) % 32 != 0 || a.C0 % 32 != 0) return 1;
+    if (a.Cout % 64 != 0 || (a.C0 + a.C1) % 32 != 0 || a.C0 % 32 != 0) return 1;   // Cout % 128 == 64: the last cout tile is half empty
     const int TW = a.OW >= 32 ? 32 : a.OW;
     if (TW != 32 && TW != 16) return 1;
     const int TH = 256 / TW;
@@ -615,7 +626,7 @@ int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     b.mask_src = reinterpret_cast<const bf16*>(zero_page);    // the kernel has no activation mask: the field carries the zero page
     b.SUBS = 1;
     b.PT = a.N * (a.OH / TH) * (a.OW / TW);
-    b.CT = a.Cout / 128;
+    b.CT = (a.Cout + 127) / 128;
     b.tile_px = 256;
 #ifdef DXMI_CONV_STAMPS
     static const int dbg = getenv("DXMI_CONV_WS_DBG") ? atoi(getenv("DXMI_CONV_WS_DBG")) : 0;

@@ -80,6 +80,9 @@ WS_CASES = [
     (5, 256, 0, 256, 16, True, "bias"),                     # nearest x2 upsample in front (32x32 output)
     (2, 128, 0, 128, 64, False, "bias+res"),                # 64x64 map: two 32-wide tile columns
     (9, 384, 0, 128, 32, False, "bias+vec"),                # 12 chunks
+    (6, 192, 0, 192, 32, False, "bias+res+vec"),            # Cout % 128 == 64: half-empty last cout tile (EDM nets: 192, 576)
+    (3, 128, 0, 64, 16, False, "bias+res"),                 # a single, half-empty cout tile
+    (70, 384, 192, 576, 16, False, "bias+res+vec+act"),     # 4.5 cout tiles, 350 tiles: tile switches into and out of the half tile
 ]
 
 
@@ -134,7 +137,7 @@ def test_conv1x1_rw(ops, N, C0, C1, Cout, H, fuse):
 
 def test_round2_kernels_out_of_scope_shapes_fall_back(ops):
     """shapes just outside the new kernels' scope still run (on the round-1 kernels) and agree with the reference"""
-    for (N, C0, C1, Cout, H, k, fuse) in [(2, 128, 0, 192, 32, 3, "bias"),      # Cout % 128 != 0
+    for (N, C0, C1, Cout, H, k, fuse) in [(2, 128, 0, 96, 32, 3, "bias"),       # Cout % 64 != 0
                                           (4, 256, 0, 256, 4, 3, "bias+res"),    # 4x4 map
                                           (2, 96, 0, 128, 32, 3, "bias"),        # odd chunk count
                                           (8, 256, 0, 256, 16, 1, "bias"),       # 1x1 with too few pixels
