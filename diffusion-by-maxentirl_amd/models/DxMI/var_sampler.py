@@ -222,12 +222,14 @@ class VARSampler(nn.Module):
         if hi >= self.n_timesteps or lo < -self.n_timesteps:
             raise IndexError(f"timestep out of range for a {self.n_timesteps}-step sampler: [{lo}, {hi}]")
 
-    def _transition(self, x, t, z, assoc, outs=None, sigma_out=None, temb_rows=None):
+    def _transition(self, x, t, z, assoc, outs=None, sigma_out=None, temb_rows=None, log_betas=None):
         """One fused transition for integer timesteps t [B] (device int64).  outs = (x_next, mean, control, logp) and
         sigma_out: preallocated destinations (rows of the trajectory block / replay ring).  temb_rows: this step's row of the
         U-Net's timestep-branch table when the whole batch shares t (sample())."""
+        if log_betas is None:
+            log_betas = self._log_betas_all().detach().float().contiguous()
         tau, xm, cm, sg = ops.var_gather_sched(t, self.continuous_steps, self.x_prev_multiplier, self.theta_multiplier,
-                                               self._log_betas_all().detach().float().contiguous(), sigma_out=sigma_out)
+                                               log_betas, sigma_out=sigma_out)
         eps = self.net(x, tau) if temb_rows is None else self.net(x, tau, temb_rows=temb_rows)
         if self.adhoc_scale1 != 1.0:
             cm = cm * self.adhoc_scale1
@@ -282,11 +284,12 @@ class VARSampler(nn.Module):
             table = None
             if self.temb_table and hasattr(self._bare_net(), "temb_table"):
                 table = self._bare_net().temb_table(self.continuous_steps[:T].to(device).float().contiguous())
+            lb = self._log_betas_all().detach().float().contiguous()     # the sigma table does not change inside a sample() call
             for i in range(T):
                 z = torch.randn(size, device=device) if noise is None else noise[i + 1].to(device).float().contiguous()
                 self._transition(traj[i], self._t_const(n_sample, i, device), z, assoc=1,
                                  outs=(traj[i + 1], mean_b[i], control_b[i], logp_b[i]), sigma_out=sigma_b[i],
-                                 temb_rows=None if table is None else table[i:i + 1])
+                                 temb_rows=None if table is None else table[i:i + 1], log_betas=lb)
         d = {"sample": traj[T], "l_sample": list(traj.unbind(0)), "logp": list(logp_b.unbind(0)),
              "logp_terminal": torch.zeros(n_sample, device=device), "mean": list(mean_b.unbind(0)),
              "sigma": [s_.view(-1, 1, 1, 1) for s_ in sigma_b.unbind(0)], "control": list(control_b.unbind(0))}
