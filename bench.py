@@ -244,12 +244,13 @@ def class_rooflines(summ, step_seconds):
         sec = c["ms"] * 1e-3
         if sec <= 0:
             continue
-        mfma = cls in ("conv3x3", "conv1x1", "conv_other", "wgrad")
+        # conv_other = conv_out (128 -> 3 channels): one read of the activation per 3 outputs, AI ~26 FLOP/B -> HBM-graded
+        mfma = cls in ("conv3x3", "conv1x1", "wgrad")
         e = {"bound": "mfma" if mfma else "hbm", "launches": c["launches"], "ms_per_step": round(c["ms"], 3),
              "share_of_step_time": round(sec / step_seconds, 4),
              "algorithmic_tflops": round(c["flops"] / sec / 1e12, 1), "algorithmic_gbps": round(c["bytes"] / sec / 1e9, 1)}
         e["frac"] = round(c["flops"] / sec / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS if mfma else c["bytes"] / sec / 1e9 / HBM_PEAK_GBPS, 4)
-        if cls in ("conv1x1", "attention"):      # both rooflines shown: these sit near the ridge
+        if cls in ("conv1x1", "attention", "conv_other"):      # both rooflines shown
             e["frac_hbm"] = round(c["bytes"] / sec / 1e9 / HBM_PEAK_GBPS, 4)
             e["frac_mfma"] = round(c["flops"] / sec / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)
         out[cls] = e
