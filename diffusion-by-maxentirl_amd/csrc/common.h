@@ -51,8 +51,11 @@ __device__ __forceinline__ float dxmi_silu_fast(float v) { return v * __builtin_
 // Branch-free form for the epilogues of the conv kernels: `act` is uniform, but a switch per element costs a ladder of
 // scalar branches per value (measured: the tile epilogue of conv_pipe_kernel spent thousands of cycles in them).
 // slope = 1 (none), 0.2 (leaky), 0 (relu): v > 0 ? v : slope * v.  SiLU keeps its own (hoisted) path.
+// One v_mul + v_cmp + v_cndmask; a NaN stays a NaN (NaN > 0 is false and slope * NaN = NaN) — the fmaxf/fminf form
+// used before returned 0 for NaN inputs and hid diverged activations from the non-finite checks downstream.
+// (relu of -inf gives NaN rather than 0: a non-finite activation stays non-finite.)
 __device__ __forceinline__ float dxmi_act_slope(int act) { return act == DXMI_ACT_LEAKY02 ? 0.2f : (act == DXMI_ACT_RELU ? 0.f : 1.f); }
-__device__ __forceinline__ float dxmi_act_lin(float v, float slope) { return fmaxf(v, 0.f) + slope * fminf(v, 0.f); }
+__device__ __forceinline__ float dxmi_act_lin(float v, float slope) { return v > 0.f ? v : slope * v; }
 
 // Workgroup barrier for LDS hand-offs that does NOT drain the vector-memory queue: __syncthreads()
 // makes hipcc emit s_waitcnt vmcnt(0) first, which stalls on every prefetched global load and on every

@@ -48,7 +48,8 @@ class FlatGradSync:
     behind an event on the compute stream), so the exchange of the deep layers runs under the backward of the shallow ones
     (train_cifar10.py:298-309 gets the same from DDP's 25 MB buckets).  Buckets are always launched in index order, so every
     rank issues the same sequence of collectives.  `sync()` (== `__call__`) after the backward: packs whatever the hooks did not
-    see (a parameter without gradient contributes zeros), launches the remaining buckets, waits, and scatters the means back
+    see (a parameter without a local gradient contributes zeros to the buffer and keeps `.grad = None` unless another rank
+    produced one), launches the remaining buckets, waits, and scatters the means back
     into the `.grad` tensors with one multi-tensor copy.  Two backward passes without a `sync()` in between fall back to
     one blocking all-reduce of the accumulated gradients."""
 
@@ -134,11 +135,14 @@ class FlatGradSync:
     def sync(self):
         if not self._active():
             return
-        for p in self.params:           # fixed element count on every rank
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        grads = [p.grad for p in self.params]
-        flat, views = self._buffers(grads[0].device)
+        missing = [i for i, p in enumerate(self.params) if p.grad is None]
+        dev = next((p.grad.device for p in self.params if p.grad is not None), self.params[0].device)
+        flat, views = self._buffers(dev)
+        if missing:
+            # fixed element count on every rank: a parameter without a local gradient contributes zeros to the FLAT buffer
+            # only; its .grad stays None unless some other rank produced one (torch DDP / torch.optim semantics: an unused
+            # parameter is skipped by the optimiser, not stepped with a zero gradient)
+            torch._foreach_zero_([views[i] for i in missing])
         world = dist.get_world_size()
         if self.dirty:
             # every rank must have issued every bucket collective exactly once before the blocking one (a rank whose hooks
@@ -148,7 +152,10 @@ class FlatGradSync:
                 self.next += 1
             for h in self.handles:
                 h.wait()
-            torch._foreach_copy_(views, grads)
+            have = [i for i in range(len(self.params)) if self.params[i].grad is not None]
+            torch._foreach_copy_([views[i] for i in have], [self.params[i].grad for i in have])
+            if missing:                 # the discarded collectives wrote into these slices
+                torch._foreach_zero_([views[i] for i in missing])
             if dist.get_backend() == "nccl":
                 dist.all_reduce(flat, op=dist.ReduceOp.AVG)
             else:
@@ -157,14 +164,28 @@ class FlatGradSync:
         else:
             late = [i for i in self.order if not self.ready[i]]
             if late:                    # gradients the hooks did not see (no hooks, constructed after backward, unused parameters)
-                torch._foreach_copy_([views[i] for i in late], [grads[i] for i in late])
+                have = [i for i in late if self.params[i].grad is not None]
+                if have:
+                    torch._foreach_copy_([views[i] for i in have], [self.params[i].grad for i in have])
                 for i in late:
                     self._mark(i)
             for h in self.handles:
                 h.wait()
             if dist.get_backend() != "nccl":
                 flat.div_(world)
-        torch._foreach_copy_(grads, views)                    # one multi-tensor scatter back
+        # which parameters received a gradient on ANY rank: one small collective, issued by every rank on every sync (same
+        # sequence everywhere); only a rank with locally missing gradients reads it back (one host sync on that rare path)
+        used = torch.ones(len(self.params), dtype=torch.float32, device=dev)
+        if missing:
+            used[missing] = 0.0
+        dist.all_reduce(used, op=dist.ReduceOp.SUM)
+        if missing:
+            flags = used[missing].tolist()
+            for i, f in zip(missing, flags):
+                if f > 0:
+                    self.params[i].grad = torch.empty_like(self.params[i])
+        have = [i for i in range(len(self.params)) if self.params[i].grad is not None]
+        torch._foreach_copy_([self.params[i].grad for i in have], [views[i] for i in have])   # one multi-tensor scatter back
         self._reset()
 
     __call__ = sync

@@ -39,41 +39,77 @@ class _FusedBase:
         return out
 
 
+def _ptr_key(params, ms, vs):
+    """Identity of the storages the cached pointer arrays describe: load_state_dict() replaces the moment tensors and
+    `p.data = ...` / `.to()` replace a parameter's storage while the python objects (and their ids) stay the same."""
+    return tuple(t.data_ptr() for ts in (params, ms, vs) for t in ts)
+
+
+def _bump_versions(params):
+    """The kernels write parameters through raw pointers, which autograd's version counters do not see, while every
+    packed bf16 weight cache (Model._param_key, modules._pack_t ...) is keyed on (data_ptr, _version): without the bump the
+    nets would keep running on the weights of the first pack.  No kernel is launched."""
+    torch.autograd.graph.increment_version(params)
+
+
+class _Batch:
+    """Tensors of one fused launch series: equal betas / eps / step count (bias corrections are per launch)."""
+
+    __slots__ = ("params", "grads", "ms", "vs", "lrs")
+
+    def __init__(self):
+        self.params, self.grads, self.ms, self.vs, self.lrs = [], [], [], [], []
+
+
+def _batches(opt, name):
+    """(betas, eps, step) -> _Batch.  Parameters that received their first gradient later than the others (or only
+    intermittently) have a lagging step counter; torch.optim handles them per tensor, here they form their own launch."""
+    out = {}
+    for group, ps in opt._gather():
+        if not ps:
+            continue
+        _check_group(group, name)
+        if name == "RAdam" and group.get("decoupled_weight_decay"):
+            raise DxmiError("dxmi_hip.optim.RAdam: decoupled_weight_decay is not implemented")
+        b1, b2 = group["betas"]
+        for p in ps:
+            st = opt.state[p]
+            st["step"] += 1
+            b = out.setdefault((b1, b2, group["eps"], float(st["step"])), _Batch())
+            b.params.append(p)
+            b.grads.append(p.grad)
+            b.ms.append(st["exp_avg"])
+            b.vs.append(st["exp_avg_sq"])
+            b.lrs.append(group["lr"])
+    return out
+
+
+def _cache_for(opt, key, b):
+    caches = opt.__dict__.setdefault("_dxmi_cache", {})
+    cache = caches.setdefault(key[:3] + (len(b.params),), {})
+    pk = _ptr_key(b.params, b.ms, b.vs)
+    if cache.get("ptr_key") != pk:
+        cache.clear()
+        cache["ptr_key"] = pk
+    return cache
+
+
 class Adam(_FusedBase, torch.optim.Adam):
     @torch.no_grad()
     def step(self, closure=None, grad_scale=None):
         """grad_scale: optional device scalar multiplied into every gradient (e.g. gradnorm_clip(...)[1:2])."""
         assert closure is None
-        params, grads, ms, vs, steps = [], [], [], [], []
-        key = None
-        for group, ps in self._gather():
-            if not ps:
-                continue
-            _check_group(group, "Adam")
-            b1, b2 = group["betas"]
-            k = (b1, b2, group["eps"])
-            for p in ps:
-                st = self.state[p]
-                st["step"] += 1
-                t = float(st["step"])
-                if key is None:
-                    key = k + (t,)
-                if k + (t,) != key:
-                    raise DxmiError("dxmi_hip.optim.Adam: betas / eps / step count must agree across parameter groups")
-                params.append(p)
-                grads.append(p.grad)
-                ms.append(st["exp_avg"])
-                vs.append(st["exp_avg_sq"])
-                steps.append(-(group["lr"] / (1 - b1 ** t)))          # step_size, in double as torch forms it
-        if not params:
-            return None
-        b1, b2, eps, t = key
-        cache = self.__dict__.setdefault("_dxmi_cache", {})
-        if cache.get("ids") != [id(p) for p in params]:
-            cache.clear()
-            cache["ids"] = [id(p) for p in params]
-        ops.adam_step(params, grads, ms, vs, steps, b1, b2, eps, (1 - b2 ** t) ** 0.5, grad_scale=grad_scale, cache=cache)
+        for key, b in _batches(self, "Adam").items():
+            b1, b2, eps, t = key
+            steps = [-(lr / (1 - b1 ** t)) for lr in b.lrs]            # step_size, in double as torch forms it
+            ops.adam_step(b.params, b.grads, b.ms, b.vs, steps, b1, b2, eps, (1 - b2 ** t) ** 0.5, grad_scale=grad_scale,
+                          cache=_cache_for(self, key, b))
+            _bump_versions(b.params)
         return None
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.__dict__.pop("_dxmi_cache", None)
 
 
 class RAdam(_FusedBase, torch.optim.RAdam):
@@ -82,45 +118,22 @@ class RAdam(_FusedBase, torch.optim.RAdam):
         """grad_scale / found_inf: optional device scalars (loss-scale reciprocal, overflow flag: a flagged step is skipped
         on the device; the caller rolls `step` back with `rollback_step()` once it reads the flag)."""
         assert closure is None
-        params, grads, ms, vs, lrs = [], [], [], [], []
-        key = None
-        for group, ps in self._gather():
-            if not ps:
-                continue
-            _check_group(group, "RAdam")
-            if group.get("decoupled_weight_decay"):
-                raise DxmiError("dxmi_hip.optim.RAdam: decoupled_weight_decay is not implemented")
-            b1, b2 = group["betas"]
-            k = (b1, b2, group["eps"])
-            for p in ps:
-                st = self.state[p]
-                st["step"] += 1
-                t = float(st["step"])
-                if key is None:
-                    key = k + (t,)
-                if k + (t,) != key:
-                    raise DxmiError("dxmi_hip.optim.RAdam: betas / eps / step count must agree across parameter groups")
-                params.append(p)
-                grads.append(p.grad)
-                ms.append(st["exp_avg"])
-                vs.append(st["exp_avg_sq"])
-                lrs.append(group["lr"])
-        if not params:
-            return None
-        b1, b2, eps, t = key
-        bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
-        rho_inf = 2 / (1 - b2) - 1
-        rho_t = rho_inf - 2 * t * (b2 ** t) / bc2
-        rect = -1.0
-        if rho_t > 5.0:
-            rect = ((rho_t - 4) * (rho_t - 2) * rho_inf / ((rho_inf - 4) * (rho_inf - 2) * rho_t)) ** 0.5
-        cache = self.__dict__.setdefault("_dxmi_cache", {})
-        if cache.get("ids") != [id(p) for p in params]:
-            cache.clear()
-            cache["ids"] = [id(p) for p in params]
-        ops.radam_step(params, grads, ms, vs, lrs, b1, b2, eps, bc1, math.sqrt(bc2), rect, grad_scale=grad_scale,
-                       found_inf=found_inf, cache=cache)
+        for key, b in _batches(self, "RAdam").items():
+            b1, b2, eps, t = key
+            bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+            rho_inf = 2 / (1 - b2) - 1
+            rho_t = rho_inf - 2 * t * (b2 ** t) / bc2
+            rect = -1.0
+            if rho_t > 5.0:
+                rect = ((rho_t - 4) * (rho_t - 2) * rho_inf / ((rho_inf - 4) * (rho_inf - 2) * rho_t)) ** 0.5
+            ops.radam_step(b.params, b.grads, b.ms, b.vs, b.lrs, b1, b2, eps, bc1, math.sqrt(bc2), rect, grad_scale=grad_scale,
+                           found_inf=found_inf, cache=_cache_for(self, key, b))
+            _bump_versions(b.params)
         return None
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.__dict__.pop("_dxmi_cache", None)
 
     def rollback_step(self):
         """Undo the step counter of a step the device skipped (found_inf was set)."""

@@ -114,15 +114,19 @@ def _ragged_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dxmi_hip.dist import FlatGradSync, broadcast_parameters
     torch.manual_seed(3)
-    m = torch.nn.ModuleDict({"a": torch.nn.Linear(4, 4), "b": torch.nn.Linear(4, 4)})
+    m = torch.nn.ModuleDict({"a": torch.nn.Linear(4, 4), "b": torch.nn.Linear(4, 4), "unused": torch.nn.Linear(4, 4)})
     x = torch.ones(2, 4)
+    # branch "unused" gets a gradient on NO rank: its .grad must stay None (the optimiser then skips it as torch does)
     # rank 1 never uses branch b: its parameters have grad None there (the collective must not shrink)
     (m["a"](x).sum() + (m["b"](x).sum() if rank == 0 else 0.0)).backward()
     want_b = m["b"].weight.grad.clone() / world if rank == 0 else None
     sync = FlatGradSync(m)
     sync()
+    assert m["unused"].weight.grad is None and m["unused"].bias.grad is None
+    assert m["b"].weight.grad is not None             # produced on rank 0 only: every rank receives the mean
     ptr = sync.flat.data_ptr()
     sync()                                            # persistent buffer: no reallocation on the second exchange
+    assert m["unused"].weight.grad is None
     # broadcast AFTER a version-keyed cache was filled must be visible through the version counter
     v_before = m["a"].weight._version
     broadcast_parameters(m, src=0)

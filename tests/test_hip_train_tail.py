@@ -209,3 +209,106 @@ def test_trainer_step_ring_equals_dict_buffer():
         finals.append([p.detach().clone() for p in list(v.parameters()) + list(net.parameters())])
     assert logs[0] == logs[1]
     assert all(torch.equal(a, b) for a, b in zip(*finals))
+
+
+# ------------------------------------------------------------------------------------------------ round-3 regressions
+def _small_unet():
+    from models.DxMI.unet_small import Model
+    from oracle.weights import formula_tensor
+    net = Model(ch=64, out_ch=3, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=[8], dropout=0.0, in_channels=3, resolution=16)
+    net.load_state_dict({k: (v if k in ("log_betas", "std") else formula_tensor(k, v.shape)) for k, v in net.state_dict().items()},
+                        strict=False)
+    return net.to(DEV)
+
+
+def test_fused_adam_step_invalidates_packed_weights():
+    """The fused optimisers write parameters through raw pointers; every packed bf16 weight cache is keyed on
+    (data_ptr, _version).  Two train steps with dxmi_hip.optim.Adam and with torch.optim.Adam (lr large enough that a
+    stale pack would be obvious) must leave the two nets computing the same function, and the pack must be rebuilt."""
+    from dxmi_hip.optim import Adam
+    torch.manual_seed(0)
+    x = torch.randn(4, 3, 16, 16, device=DEV)
+    t = torch.tensor([3.0, 50.0, 400.0, 900.0], device=DEV)
+    outs = []
+    for cls in (torch.optim.Adam, Adam):
+        net = _small_unet()
+        opt = cls([p for n, p in net.named_parameters() if n != "log_betas"], lr=1e-3)
+        with torch.no_grad():
+            y0 = net(x, t).clone()
+        key0 = net._packed_key
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            net(x, t).square().mean().backward()
+            opt.step()
+        assert net._param_key() != key0, "optimizer.step() must move the parameters' version counters"
+        with torch.no_grad():
+            y2 = net(x, t).clone()
+        assert net._packed_key != key0                                   # the fragments were re-packed
+        assert (y2 - y0).norm() > 1e-2 * y0.norm(), "two lr=1e-3 Adam steps must change the network's output"
+        outs.append(y2)
+    rel = ((outs[0] - outs[1]).norm() / outs[0].norm()).item()
+    assert rel < 2e-2, rel                                                # same function up to the bf16 noise of the backward
+
+
+def test_fused_adam_lagging_step_counters_and_reloaded_state():
+    """A parameter that receives its first gradient later has a lagging step counter (torch.optim handles it per tensor):
+    the fused step forms one launch series per step count instead of raising.  load_state_dict() replaces the moment
+    tensors: the cached pointer arrays must follow."""
+    from dxmi_hip.optim import Adam
+    a = [p.clone().requires_grad_(True) for p in _params(7)[:6]]
+    b = [p.detach().clone().requires_grad_(True) for p in a]
+    ref, new = torch.optim.Adam(a, lr=1e-3), Adam(b, lr=1e-3)
+    for step in range(4):
+        _set_grads(a, 300 + step)
+        _set_grads(b, 300 + step)
+        if step < 2:                       # the last two tensors join at step 2
+            for ps in (a, b):
+                ps[4].grad = ps[5].grad = None
+        ref.step()
+        new.step()
+        assert max(_max_ulp(x, y) for x, y in zip(a, b)) == 0, step
+    assert float(new.state[b[5]]["step"]) == 2.0 and float(new.state[b[0]]["step"]) == 4.0
+    # reload: new moment tensors at new addresses
+    import copy
+    new.load_state_dict(copy.deepcopy(ref.state_dict()))      # (load_state_dict aliases same-device tensors: copy first)
+    _set_grads(a, 400)
+    _set_grads(b, 400)
+    ref.step()
+    new.step()
+    assert max(_max_ulp(x, y) for x, y in zip(a, b)) == 0
+    for x, y in zip(a, b):
+        assert torch.equal(ref.state[x]["exp_avg_sq"], new.state[y]["exp_avg_sq"])
+    # p.data replaced: same python object, new storage
+    with torch.no_grad():
+        for ps in (a, b):
+            ps[0].data = ps[0].data.clone()
+    _set_grads(a, 401)
+    _set_grads(b, 401)
+    ref.step()
+    new.step()
+    assert max(_max_ulp(x, y) for x, y in zip(a, b)) == 0
+
+
+# (Cin, Cout, H, k, batch, out_nchw_f32): one shape per forward conv kernel family
+NAN_CASES = {"ws<32>": (128, 128, 32, 3, 8, False), "ws<16>": (256, 256, 16, 3, 16, False), "ws8": (256, 256, 8, 3, 8, False),
+             "pipe": (256, 256, 4, 3, 32, False), "1x1_rw": (256, 768, 16, 1, 128, False), "1x1_stream": (256, 256, 4, 1, 8, False),
+             "head": (128, 3, 32, 3, 4, True)}
+
+
+@pytest.mark.parametrize("case", list(NAN_CASES))
+def test_conv_epilogue_keeps_nan(case):
+    """A NaN activation must come out of every conv kernel family as NaN (act none / leaky / relu), so that the non-finite
+    checks downstream (gradient-norm flag, MixedPrecisionTrainer overflow test, NaN poisoning of bad timesteps) can fire."""
+    from dxmi_hip import ops
+    cin, cout, hw, k, n, nchw = NAN_CASES[case]
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, hw, hw, cin, generator=g).to(DEV).to(torch.bfloat16)
+    x[0, hw // 2, hw // 2, 5] = float("nan")
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.05).to(DEV)
+    pw = ops.pack_conv_weight(w)
+    bias = torch.zeros(cout, device=DEV)
+    for act in (ops.ACT_NONE, ops.ACT_LEAKY02, ops.ACT_RELU):
+        y = ops.conv2d(x, pw, bias=bias, act=act, out_nchw_f32=nchw)
+        y = y.permute(0, 2, 3, 1) if nchw else y
+        assert torch.isnan(y[0, hw // 2, hw // 2].float()).all(), (case, act)
+        assert torch.isfinite(y[1:].float()).all(), (case, act)

@@ -139,8 +139,9 @@ TRAINER_KW = {"trainer_step": dict(time_cost_sig=True), "trainer_step_T4_resampl
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True], ids=["torch_adam", "dxmi_adam"])
 @pytest.mark.parametrize("fixture", list(TRAINER_KW))
-def test_hip_trainer_step_vs_reference(golden_dir, fixture):
+def test_hip_trainer_step_vs_reference(golden_dir, fixture, fused):
     """Full HIP train step at the reference's golden configurations: configs/cifar10/T10.yaml (T=10) and the
     T4_ddgan.yaml protocol (T=4, value_resample: sample_step inside the TD loop, trainer.py:281-285).
     bf16 activations / gradients against the reference's fp32:
@@ -159,8 +160,8 @@ def test_hip_trainer_step_vs_reference(golden_dir, fixture):
     net, sampler, v = build_models(T)
     sampler, v = sampler.to(DEV), v.to(DEV)
     params_not_beta = [p for n, p in net.named_parameters() if "log_betas" not in n]
-    opt = torch.optim.Adam([{"params": net.log_betas, "lr": 1e-5}, {"params": params_not_beta, "lr": 1e-7}])
-    opt_v = torch.optim.Adam(v.parameters(), lr=1e-5)
+    opt = AdamCls([{"params": net.log_betas, "lr": 1e-5}, {"params": params_not_beta, "lr": 1e-7}])
+    opt_v = AdamCls(v.parameters(), lr=1e-5)
     vnamed, nnamed = dict(v.named_parameters()), dict(net.named_parameters())
     vgrads, orig_step = [], opt_v.step
 
