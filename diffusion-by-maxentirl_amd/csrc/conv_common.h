@@ -22,7 +22,31 @@ struct ConvArgs {
     float mask_slope;        // factor applied where mask_src <= 0 (0.2 leaky, 0 relu)
     int stagger;             // conv_pipe: start delay (units of s_sleep 127 ~ 8k cycles) of the second resident half
     int RP, SP;              // conv_pipe: LDS pitch of a halo row / of a sub-image, bytes (bank-conflict-free choice)
+    float* gn_stats;         // optional: GroupNorm block statistics of the OUTPUT, fp32 [N][P][Cout/4][2] (dxmi_conv_desc.gn_stats)
 };
+
+// Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15): every lane of the row ends with the row's total.  Each step adds
+// two partial sums over disjoint, equally shaped lane sets, so all lanes hold bitwise the same value.
+__device__ __forceinline__ float dxmi_row16_sum(float t) {
+#define DXMI_DPP_ADD(ctrl) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), ctrl, 0xf, 0xf, false))
+    DXMI_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+    DXMI_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+    DXMI_DPP_ADD(0x141);   // row_half_mirror
+    DXMI_DPP_ADD(0x140);   // row_mirror
+#undef DXMI_DPP_ADD
+    return t;
+}
+
+// (sum, sum of squares) of four bf16 values — the values as STORED, so a GroupNorm fed by these statistics normalises
+// exactly the tensor the consumer reads — added to (s, q): four v_dot2c_f32_bf16.
+__device__ __forceinline__ void dxmi_stats4(const bf16x4& o, float& s, float& q) {
+    const bf16x2 lo = {o[0], o[1]}, hi = {o[2], o[3]};
+    const bf16x2 one = {(bf16)1.f, (bf16)1.f};
+    s = __builtin_amdgcn_fdot2_f32_bf16(lo, one, s, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(hi, one, s, false);
+    q = __builtin_amdgcn_fdot2_f32_bf16(lo, lo, q, false);
+    q = __builtin_amdgcn_fdot2_f32_bf16(hi, hi, q, false);
+}
 
 // XCD-aware block mapping: blocks b and b+8 share an XCD (round-robin dispatch), so the CT
 // cout-tiles of one pixel tile are made consecutive *within* an XCD and re-read the input halo

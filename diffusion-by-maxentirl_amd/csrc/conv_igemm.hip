@@ -309,6 +309,8 @@ int dispatch_conv(ConvArgs& a, int variant, hipStream_t st, int* kernel_id = nul
         const int rc = conv_pipe_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;  // launched (or failed loudly); rc == 1: not eligible
     }
+    DXMI_CHECK_ARG(!a.gn_stats || kernel_id, "dxmi_conv2d_fwd: the kernel for this shape does not emit GroupNorm block statistics "
+                                             "(dxmi_conv2d_gn_stats_partials returns 0 for it)");
     constexpr int CK = 32;
     a.tile_px = 256;
     a.stagger = 0;
@@ -373,7 +375,9 @@ static int conv2d_impl(const dxmi_conv_desc* d, void* stream, int* kernel_id) {
     ConvArgs a;
     a.in0 = (const bf16*)d->in0; a.in1 = (const bf16*)d->in1; a.w = (const bf16*)d->wpacked;
     a.bias = d->bias; a.addvec = d->addvec; a.residual = (const bf16*)d->residual; a.out = d->out;
-    a.mask_src = (const bf16*)d->mask_src; a.mask_slope = d->mask_slope;
+    a.mask_src = (const bf16*)d->mask_src; a.mask_slope = d->mask_slope; a.gn_stats = d->gn_stats;
+    DXMI_CHECK_ARG(!d->gn_stats || (d->variant == 0 && d->out_mode == DXMI_OUT_NHWC_BF16 && d->Cout % 4 == 0),
+                   "dxmi_conv2d_fwd: gn_stats needs the default variant, NHWC bf16 output and Cout%%4==0");
     a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.C0 = d->C0; a.C1 = d->C1; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
     a.ksize = d->ksize; a.stride = d->stride; a.pad = d->pad; a.ups = d->upsample; a.act = d->act;
     a.addvec_ld = d->addvec_ld; a.in_mode = d->in_mode; a.out_mode = d->out_mode; a.P = 0; a.pre_act = 0;
@@ -390,6 +394,25 @@ static int conv2d_impl(const dxmi_conv_desc* d, void* stream, int* kernel_id) {
 }
 
 extern "C" int dxmi_conv2d_fwd(const dxmi_conv_desc* d, void* stream) { return conv2d_impl(d, stream, nullptr); }
+
+// Partials per image of the GroupNorm block statistics the selected kernel writes (0: it writes none).
+static int gn_stats_partials_of(const dxmi_conv_desc* d, int id) {
+    if (id >= 400000 && id < 400100) {            // conv_ws_kernel<TW>: (pixel tile, pixel half) of the image
+        const int TW = id - 400000, TH = 256 / TW;
+        return (d->OH / TH) * (d->OW / TW) * 2;
+    }
+    return 0;
+}
+
+extern "C" int dxmi_conv2d_gn_stats_partials(const dxmi_conv_desc* d) {
+    int id = 0;
+    if (!d) return 0;
+    dxmi_conv_desc q = *d;
+    q.gn_stats = nullptr;
+    if (q.variant != 0 || q.out_mode != DXMI_OUT_NHWC_BF16) return 0;
+    const int rc = conv2d_impl(&q, nullptr, &id);
+    return rc == DXMI_OK ? gn_stats_partials_of(d, id) : 0;
+}
 
 // Which template instantiation dxmi_conv2d_fwd would launch for this descriptor (no launch):
 // MB*1000 + NB*100 + PMAX, e.g. 1806 = conv_igemm_kernel<1,8,32,6>.  Used by bench.py to attribute
@@ -477,7 +500,7 @@ extern "C" int dxmi_linear_fwd(const float* x, const void* wpacked, const float*
     }
     ConvArgs a;
     a.in0 = (const bf16*)x; a.in1 = nullptr; a.w = (const bf16*)wpacked; a.bias = bias; a.addvec = nullptr;
-    a.residual = nullptr; a.out = out; a.mask_src = nullptr; a.mask_slope = 0.f;
+    a.residual = nullptr; a.out = out; a.mask_src = nullptr; a.mask_slope = 0.f; a.gn_stats = nullptr;
     a.N = 1; a.IH = 1; a.IW = P; a.C0 = K; a.C1 = 0; a.OH = 1; a.OW = P; a.Cout = M;
     a.ksize = 1; a.stride = 1; a.pad = 0; a.ups = 0; a.act = post_act; a.addvec_ld = 0;
     a.in_mode = DXMI_IN_ROWS_F32; a.out_mode = DXMI_OUT_ROWS_F32; a.P = P; a.pre_act = pre_act;

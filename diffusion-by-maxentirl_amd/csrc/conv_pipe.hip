@@ -646,6 +646,9 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     {
         int rc = conv_ws_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;
+        // only the kernels tried above emit GroupNorm block statistics (dxmi_conv2d_gn_stats_partials says which shapes)
+        DXMI_CHECK_ARG(!a.gn_stats || kernel_id, "dxmi_conv2d_fwd: the kernel for this shape does not emit GroupNorm block statistics "
+                                                 "(dxmi_conv2d_gn_stats_partials returns 0 for it)");
         rc = conv1x1_rw_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;
         rc = conv_head_try_launch(a, st, kernel_id);

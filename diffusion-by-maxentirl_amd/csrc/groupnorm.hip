@@ -10,7 +10,7 @@
 //
 // Reference: Normalize()/nonlinearity, models/DxMI/unet_small.py:30-36,119-126,169,329-330;
 // GroupNorm32, models/cm/nn.py:19-21.
-#include "common.h"
+#include "conv_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -308,6 +308,162 @@ __global__ __launch_bounds__(256) void gn_gen_apply_kernel(GnGenArgs p) {
                 *reinterpret_cast<bf16x8*>(dst + (size_t)rr * C) = o;
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming GroupNorm(+SiLU) apply (round 3): the statistics pass of Normalize() is folded into whatever PRODUCED the
+// tensor — the conv kernels' epilogues write (sum, sum of squares) per (image, partial, 4-channel block) of the bf16
+// values they store (dxmi_conv_desc.gn_stats), gn_block_stats_kernel does the same for tensors without a producer-side
+// epilogue — so the normalisation itself is ONE read + ONE write with nothing resident: a workgroup re-reduces its
+// image's partials in a fixed order (32 threads, a few dozen L2 hits), forms one (scale, offset) pair per channel and
+// streams its rows with U 16-byte loads in flight per thread.  The one-pass resident kernel above needed the whole
+// (image, slice) in registers before the first store (all workgroups of a launch load, reduce and store in lock step:
+// 3.2 TB/s in the U-Net); this one has no phase structure at all.
+// 4-channel blocks are the finest group granularity of the U-Net (128 channels / 32 groups) and divide every concat
+// boundary and group width it has (8, 12, 16 channels per group), so one statistics tensor per activation serves every
+// GroupNorm that reads it, alone or as either half of a virtual concat.
+struct GnApplyArgs {
+    const bf16* in0;
+    const bf16* in1;
+    const float* st0;    // [N][P0][C0/4][2]
+    const float* st1;    // [N][P1][C1/4][2]
+    const float* gamma;
+    const float* beta;
+    bf16* out;
+    int C0, C1, HW, groups, cpg, chunks, rows_per_chunk, P0, P1;
+    float eps;
+    int silu;
+};
+
+template <int U>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
+    __shared__ float mean_s[32], rstd_s[32];
+    const int C = p.C0 + p.C1, c8n = C >> 3;
+    const int n = blockIdx.x / p.chunks, chunk = blockIdx.x - n * p.chunks;
+    const int tid = threadIdx.x;
+    const int rows_par = 256 / c8n;
+    const int rl = tid / c8n, pc = tid - rl * c8n;
+    const bool active = rl < rows_par;
+    const int c = pc * 8;
+    const bool from0 = c < p.C0;
+    const int Cs = from0 ? p.C0 : p.C1;
+    const bf16* src = from0 ? p.in0 + (size_t)n * p.HW * p.C0 + c : p.in1 + (size_t)n * p.HW * p.C1 + (c - p.C0);
+    bf16* dst = p.out + (size_t)n * p.HW * C + c;
+    const int row0 = chunk * p.rows_per_chunk;
+    const int row1 = min(row0 + p.rows_per_chunk, p.HW);
+    // the first trip's rows are requested before the statistics prologue (independent of it)
+    bf16x8 v[U];
+    int r = row0 + rl;
+    if (active) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * rows_par;
+            if (rr < row1) v[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)rr * Cs);
+        }
+    }
+    if (tid < p.groups) {
+        // group tid = blocks [tid*cpg/4, (tid+1)*cpg/4) of the virtual concat, each from one source's statistics
+        const int bpg = p.cpg >> 2, nb0 = p.C0 >> 2;
+        float s = 0.f, q = 0.f;
+        for (int b = tid * bpg; b < (tid + 1) * bpg; ++b) {
+            const bool f0 = b < nb0;
+            const float* st = f0 ? p.st0 : p.st1;
+            const int P = f0 ? p.P0 : p.P1, nbs = f0 ? nb0 : (p.C1 >> 2), bl = f0 ? b : b - nb0;
+            const float2* sp = reinterpret_cast<const float2*>(st) + (size_t)n * P * nbs + bl;
+            for (int k = 0; k < P; ++k) {
+                const float2 t = sp[(size_t)k * nbs];
+                s += t.x;
+                q += t.y;
+            }
+        }
+        const float cnt = (float)p.HW * (float)p.cpg;
+        const float m = s / cnt;
+        mean_s[tid] = m;
+        rstd_s[tid] = rsqrtf(fmaxf(q / cnt - m * m, 0.f) + p.eps);
+    }
+    __syncthreads();
+    if (!active) return;
+    float A[8], Bv[8];
+    {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + c), g1 = *reinterpret_cast<const f32x4*>(p.gamma + c + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + c), b1 = *reinterpret_cast<const f32x4*>(p.beta + c + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / p.cpg;
+            const float a = rstd_s[g] * (e < 4 ? g0[e] : g1[e - 4]);
+            A[e] = a;
+            Bv[e] = (e < 4 ? b0[e] : b1[e - 4]) - mean_s[g] * a;
+        }
+    }
+    for (;;) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * rows_par;
+            if (rr < row1) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float y = (float)v[u][e] * A[e] + Bv[e];
+                    if (p.silu) y = dxmi_silu_fast(y);
+                    o[e] = (bf16)y;
+                }
+                *reinterpret_cast<bf16x8*>(dst + (size_t)rr * C) = o;
+            }
+        }
+        r += U * rows_par;
+        if (r >= row1) break;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + u * rows_par;
+            if (rr < row1) v[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)rr * Cs);
+        }
+    }
+}
+
+// Block statistics of a tensor nobody produced statistics for: x [N,HW,C] -> st [N][P][C/4][2], P row chunks per image.
+// Thread = one 8-channel piece column (two blocks) over the chunk's rows; the row-parallel partials are added in a fixed
+// order through LDS.
+__global__ __launch_bounds__(256) void gn_block_stats_kernel(const bf16* __restrict__ x, float* __restrict__ st, int HW, int C,
+                                                             int chunks, int rows_per_chunk) {
+    __shared__ float sm[256 * 4];         // [row lane][piece][s0 q0 s1 q1]: rows_par * c8n <= 256 entries of 4
+    const int c8n = C >> 3;
+    const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
+    const int tid = threadIdx.x;
+    const int rows_par = 256 / c8n;
+    const int rl = tid / c8n, pc = tid - rl * c8n;
+    const int row0 = chunk * rows_per_chunk;
+    const int row1 = min(row0 + rows_per_chunk, HW);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rl < rows_par) {
+        const bf16* src = x + (size_t)n * HW * C + pc * 8;
+        for (int r = row0 + rl; r < row1; r += 4 * rows_par) {
+            bf16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * rows_par;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[u][e] = (bf16)0.f;
+                if (rr < row1) v[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)rr * C);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bf16x4 lo = {v[u][0], v[u][1], v[u][2], v[u][3]}, hi = {v[u][4], v[u][5], v[u][6], v[u][7]};
+                dxmi_stats4(lo, acc[0], acc[1]);
+                dxmi_stats4(hi, acc[2], acc[3]);
+            }
+        }
+        float* d = sm + (rl * c8n + pc) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = acc[e];
+    }
+    __syncthreads();
+    // one thread per (block, s|q): C/4 * 2 <= 256 outputs for C <= 512; larger C loops
+    for (int i = tid; i < (C >> 2) * 2; i += 256) {
+        const int b = i >> 1, w = i & 1;      // block b = piece b/2, half b&1
+        float t = 0.f;
+        for (int rr = 0; rr < rows_par; ++rr) t += sm[(rr * c8n + (b >> 1)) * 4 + (b & 1) * 2 + w];
+        st[(((size_t)n * chunks + chunk) * (C >> 2) + b) * 2 + w] = t;
     }
 }
 
@@ -903,5 +1059,48 @@ extern "C" int dxmi_groupnorm_generic_bwd(const void* in0, int32_t C0, const voi
     DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_bwd(reduce)");
     hipLaunchKernelGGL(gn_gen_bwd_apply_kernel, dim3(N * chunks), dim3(256), 0, st, a);
     DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_bwd(apply)");
+    return DXMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming apply + block statistics (see gn_apply_kernel)
+static inline int gn_stats_chunks(int HW) { return HW >= 512 ? HW / 256 : 1; }
+
+extern "C" int dxmi_gn_block_stats_partials(int32_t HW) { return gn_stats_chunks(HW); }
+
+extern "C" int dxmi_gn_block_stats(const void* x, float* stats, int32_t N, int32_t HW, int32_t C, void* stream) {
+    DXMI_CHECK_ARG(x && stats && N > 0 && HW > 0, "dxmi_gn_block_stats: null pointer / empty shape");
+    DXMI_CHECK_ARG(C % 8 == 0 && C >= 8 && C <= 2048, "dxmi_gn_block_stats: C=%d must be a multiple of 8, <= 2048", C);
+    const int chunks = gn_stats_chunks(HW);
+    const int rpc = (HW + chunks - 1) / chunks;
+    hipLaunchKernelGGL(gn_block_stats_kernel, dim3(N * chunks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, stats, HW, C,
+                       chunks, rpc);
+    DXMI_CHECK_LAUNCH("dxmi_gn_block_stats");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_groupnorm_apply(const void* in0, int32_t C0, const float* stats0, int32_t P0, const void* in1, int32_t C1,
+                                    const float* stats1, int32_t P1, const float* gamma, const float* beta, void* out,
+                                    int32_t N, int32_t HW, int32_t groups, float eps, int32_t apply_silu, void* stream) {
+    DXMI_CHECK_ARG(in0 && stats0 && gamma && beta && out && P0 > 0, "dxmi_groupnorm_apply: null pointer");
+    DXMI_CHECK_ARG(C1 == 0 || (in1 && stats1 && P1 > 0), "dxmi_groupnorm_apply: C1>0 needs in1 and stats1");
+    const int C = C0 + C1;
+    DXMI_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0, "dxmi_groupnorm_apply: C=%d groups=%d", C, groups);
+    const int cpg = C / groups;
+    DXMI_CHECK_ARG(cpg % 4 == 0 && C0 % 8 == 0 && C1 % 8 == 0 && C <= 2048,
+                   "dxmi_groupnorm_apply: channels per group (%d) must be a multiple of 4, C0/C1 (%d/%d) multiples of 8", cpg, C0, C1);
+    GnApplyArgs a;
+    a.in0 = (const bf16*)in0; a.in1 = (const bf16*)in1; a.st0 = stats0; a.st1 = stats1; a.gamma = gamma; a.beta = beta;
+    a.out = (bf16*)out; a.C0 = C0; a.C1 = C1; a.HW = HW; a.groups = groups; a.cpg = cpg; a.P0 = P0; a.P1 = P1;
+    a.eps = eps; a.silu = apply_silu;
+    // a workgroup streams ~64 KB: four trips of U = 4 rows x (256 / (C/8)) row lanes
+    constexpr int U = 4;
+    const int rows_par = 256 / (C / 8);
+    int rpc = 4 * U * rows_par;
+    if (rpc > HW) rpc = HW;
+    a.chunks = (HW + rpc - 1) / rpc;
+    a.rows_per_chunk = rpc;
+    hipLaunchKernelGGL(gn_apply_kernel<U>, dim3(N * a.chunks), dim3(256), 0, (hipStream_t)stream, a);
+    DXMI_CHECK_LAUNCH("dxmi_groupnorm_apply");
     return DXMI_OK;
 }

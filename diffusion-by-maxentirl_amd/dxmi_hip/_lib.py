@@ -22,7 +22,7 @@ class ConvDesc(ctypes.Structure):
         ("OH", c_int), ("OW", c_int), ("Cout", c_int),
         ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int), ("act", c_int),
         ("addvec_ld", c_int), ("in_mode", c_int), ("out_mode", c_int), ("variant", c_int),
-        ("mask_src", c_void_p), ("mask_slope", c_float),
+        ("mask_src", c_void_p), ("mask_slope", c_float), ("gn_stats", c_void_p),
     ]
 
 
@@ -33,6 +33,11 @@ SIGNATURES = {
     "dxmi_device_check": (c_int, []),
     "dxmi_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
     "dxmi_conv2d_kernel_id": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "dxmi_conv2d_gn_stats_partials": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "dxmi_gn_block_stats_partials": (c_int, [c_int]),
+    "dxmi_gn_block_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dxmi_groupnorm_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dxmi_packed_conv_weight_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "dxmi_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_conv2d_wgrad_workspace_bytes": (c_int64, [c_int] * 6),

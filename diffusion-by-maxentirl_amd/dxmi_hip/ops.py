@@ -62,9 +62,25 @@ def pack_conv_weight(w, transpose_flip=False, k27=False, out=None):
     return PackedConvWeight(out, Cout, Cin, k, k27)
 
 
+class BlockStats:
+    """GroupNorm block statistics of an NHWC bf16 activation: fp32 [N, P, C/4, 2] = (sum, sum of squares) of the stored
+    values per 4-channel block, over the pixels of partial p of the image (dxmi_conv_desc.gn_stats / dxmi_gn_block_stats).
+    Travels with the tensor it describes; `groupnorm_silu(..., stats=...)` then runs as one streaming read + write."""
+
+    __slots__ = ("buf", "P")
+
+    def __init__(self, buf, P):
+        self.buf, self.P = buf, P
+
+
+_STATS_P = {}
+
+
 def conv2d(x, pw, *, in1=None, bias=None, addvec=None, residual=None, stride=1, pad=None, pad_br=None, upsample=False,
-           act=ACT_NONE, out=None, out_nchw_f32=False, variant=0, mask_src=None, mask_slope=0.0):
-    """x: NHWC bf16 [N,IH,IW,C0] (or NCHW fp32 [N,3,H,W] when pw.k27)."""
+           act=ACT_NONE, out=None, out_nchw_f32=False, variant=0, mask_src=None, mask_slope=0.0, want_stats=False):
+    """x: NHWC bf16 [N,IH,IW,C0] (or NCHW fp32 [N,3,H,W] when pw.k27).
+    want_stats: return (out, BlockStats | None) — the output's GroupNorm block statistics written by the conv's own epilogue
+    where the selected kernel can (None otherwise: the caller falls back to block_stats() or the one-pass GroupNorm)."""
     _need_cuda(x, in1, bias, addvec, residual, out)
     k = pw.ksize
     if pad is None:
@@ -113,11 +129,21 @@ def conv2d(x, pw, *, in1=None, bias=None, addvec=None, residual=None, stride=1, 
         assert mask_src.dtype == torch.bfloat16 and mask_src.is_contiguous() and tuple(mask_src.shape) == (N, OH, OW, Cout)
     d.mask_src = mask_src.data_ptr() if mask_src is not None else None
     d.mask_slope = float(mask_slope)
+    d.gn_stats = None
+    stats = None
+    if want_stats and not out_nchw_f32 and variant == 0:
+        key = (N, IH, IW, C0, C1, OH, OW, Cout, k, stride, pad, int(upsample), act, d.in_mode, residual is not None, mask_src is not None)
+        P = _STATS_P.get(key)
+        if P is None:
+            P = _STATS_P[key] = int(load().dxmi_conv2d_gn_stats_partials(ctypes.byref(d)))
+        if P > 0:
+            stats = BlockStats(torch.empty((N, P, Cout // 4, 2), dtype=torch.float32, device=x.device), P)
+            d.gn_stats = stats.buf.data_ptr()
     if PROFILER is not None:
         PROFILER.launch_conv(d)
     else:
         check(load().dxmi_conv2d_fwd(ctypes.byref(d), _stream()), "dxmi_conv2d_fwd")
-    return out
+    return (out, stats) if want_stats else out
 
 
 class OpProfiler:
@@ -320,12 +346,47 @@ def attention_bwd(qkv, do, heads, scale):
     return dqkv
 
 
-def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, out=None, scale_shift=None):
-    """GroupNorm(+SiLU).  The register-resident one-pass kernel serves channels-per-group % 4 == 0 slices that fit;
-    everything else (EDM shapes, scale-shift norm) goes to the generic two-kernel path."""
+def block_stats(x):
+    """GroupNorm block statistics of an activation that has none from its producer (one read of x)."""
+    _need_cuda(x)
+    N, H, W, C = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    lib = load()
+    P = int(lib.dxmi_gn_block_stats_partials(H * W))
+    st = BlockStats(torch.empty((N, P, C // 4, 2), dtype=torch.float32, device=x.device), P)
+    _prof("groupnorm", "block_stats", 0.0, 2.0 * x.numel(), lambda: check(
+        lib.dxmi_gn_block_stats(_ptr(x), _ptr(st.buf), N, H * W, C, _stream()), "dxmi_gn_block_stats"))
+    return st
+
+
+def groupnorm_apply(x, st, gamma, beta, *, in1=None, st1=None, groups=32, eps=1e-6, silu=True, out=None):
+    """GroupNorm(+SiLU) of [x | in1] given their block statistics: one streaming read + write (dxmi_groupnorm_apply)."""
+    _need_cuda(x, in1, gamma, beta, out, st.buf, st1.buf if st1 is not None else None)
+    N, H, W, C0 = x.shape
+    C1 = in1.shape[3] if in1 is not None else 0
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and (in1 is None or (in1.is_contiguous() and st1 is not None))
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C0 + C1
+    assert tuple(st.buf.shape) == (N, st.P, C0 // 4, 2) and (st1 is None or tuple(st1.buf.shape) == (N, st1.P, C1 // 4, 2))
+    if out is None:
+        out = torch.empty((N, H, W, C0 + C1), dtype=torch.bfloat16, device=x.device)
+    _prof("groupnorm", "apply", 0.0, 4.0 * N * H * W * (C0 + C1), lambda: check(
+        load().dxmi_groupnorm_apply(_ptr(x), C0, _ptr(st.buf), st.P, _ptr(in1), C1, _ptr(st1.buf) if st1 is not None else None,
+                                    st1.P if st1 is not None else 0, _ptr(gamma), _ptr(beta), _ptr(out), N, H * W, groups,
+                                    float(eps), int(silu), _stream()), "dxmi_groupnorm_apply"))
+    return out
+
+
+def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, out=None, scale_shift=None, stats=None):
+    """GroupNorm(+SiLU).  stats = (BlockStats of x, BlockStats of in1 | None): the streaming apply kernel.  Otherwise the
+    register-resident one-pass kernel serves channels-per-group % 4 == 0 slices that fit; everything else (EDM shapes,
+    scale-shift norm) goes to the generic two-kernel path."""
     _need_cuda(x, in1, gamma, beta, out, scale_shift)
     N, H, W, C0 = x.shape
     C1 = in1.shape[3] if in1 is not None else 0
+    if stats is not None and scale_shift is None and stats[0] is not None and (in1 is None or stats[1] is not None) \
+            and ((C0 + C1) // groups) % 4 == 0 and C0 % 8 == 0 and C1 % 8 == 0:
+        return groupnorm_apply(x, stats[0], gamma, beta, in1=in1, st1=stats[1] if in1 is not None else None, groups=groups,
+                               eps=eps, silu=silu, out=out)
     if scale_shift is not None or not load().dxmi_groupnorm_silu_supported(C0, C1, H * W, groups):
         return groupnorm_generic(x, gamma, beta, in1=in1, groups=groups, eps=eps, silu=silu, out=out, scale_shift=scale_shift)
     assert x.dtype == torch.bfloat16 and x.is_contiguous()

@@ -212,26 +212,45 @@ class Model(nn.Module):
         return self._packed
 
     # ------------------------------------------------------------------ fused blocks
-    def _resblock(self, pk, b, x0, x1, tp):
-        """GN+SiLU -> conv1(+bias+temb) -> GN+SiLU -> conv2(+bias+shortcut); x = [x0 | x1] virtual concat."""
-        a = ops.groupnorm_silu(x0, b.norm1.weight, b.norm1.bias, in1=x1, eps=1e-6, silu=True)
+    # Activations on maps of >= STREAM_GN_MIN_HW pixels travel as (tensor, BlockStats): the producing conv's epilogue writes the
+    # GroupNorm block statistics of what it stores, so every Normalize() on them is one streaming read + write
+    # (ops.groupnorm_apply).  Smaller maps (8x8, 4x4: 8 % of the GroupNorm bytes) keep the one-pass resident kernel.
+    STREAM_GN_MIN_HW = 256            # instance attribute override (tests / A-B timing): 1 << 30 = one-pass GroupNorm everywhere
+
+    def _conv_s(self, x, pw, **kw):
+        """conv2d -> (out, BlockStats | None): statistics from the conv's own epilogue where its kernel writes them, else from
+        one extra read of the output (stem conv, stride-2 Downsample, 1x1 proj_out)."""
+        out, st = ops.conv2d(x, pw, want_stats=True, **kw)
+        if st is None and out.shape[1] * out.shape[2] >= self.STREAM_GN_MIN_HW:
+            st = ops.block_stats(out)
+        return out, st
+
+    def _resblock(self, pk, b, x0, x1, tp, s0=None, s1=None):
+        """GN+SiLU -> conv1(+bias+temb) -> GN+SiLU -> conv2(+bias+shortcut); x = [x0 | x1] virtual concat; s0 / s1 their block
+        statistics (None: one-pass GroupNorm).  Returns (h, BlockStats | None)."""
+        a = ops.groupnorm_silu(x0, b.norm1.weight, b.norm1.bias, in1=x1, eps=1e-6, silu=True, stats=(s0, s1))
         off = pk[id(b), "toff"]
-        h = ops.conv2d(a, pk[id(b), "conv1"], bias=b.conv1.bias, addvec=tp[:, off:off + b.out_channels])
-        a = ops.groupnorm_silu(h, b.norm2.weight, b.norm2.bias, eps=1e-6, silu=True)
+        stream = x0.shape[1] * x0.shape[2] >= self.STREAM_GN_MIN_HW
+        h, sh = ops.conv2d(a, pk[id(b), "conv1"], bias=b.conv1.bias, addvec=tp[:, off:off + b.out_channels], want_stats=True)
+        a = ops.groupnorm_silu(h, b.norm2.weight, b.norm2.bias, eps=1e-6, silu=True, stats=(sh, None))
         if b.in_channels != b.out_channels:
             sc_mod = b.conv_shortcut if b.use_conv_shortcut else b.nin_shortcut
             sc = ops.conv2d(x0, pk[id(b), "short"], in1=x1, bias=sc_mod.bias)
         else:
             assert x1 is None
             sc = x0
-        return ops.conv2d(a, pk[id(b), "conv2"], bias=b.conv2.bias, residual=sc)
+        if stream:
+            return self._conv_s(a, pk[id(b), "conv2"], bias=b.conv2.bias, residual=sc)
+        return ops.conv2d(a, pk[id(b), "conv2"], bias=b.conv2.bias, residual=sc), None
 
-    def _attn(self, pk, m, x):
+    def _attn(self, pk, m, x, sx=None):
         N, H, W, C = x.shape
-        hn = ops.groupnorm_silu(x, m.norm.weight, m.norm.bias, eps=1e-6, silu=False)
+        hn = ops.groupnorm_silu(x, m.norm.weight, m.norm.bias, eps=1e-6, silu=False, stats=(sx, None))
         qkv = ops.conv2d(hn, pk[id(m), "qkv"], bias=pk[id(m), "qkv_bias"])
         a = ops.attention(qkv.view(N, H * W, 3 * C), heads=1, scale=float(int(C) ** (-0.5)))
-        return ops.conv2d(a.view(N, H, W, C), pk[id(m), "proj"], bias=m.proj_out.bias, residual=x)
+        if H * W >= self.STREAM_GN_MIN_HW:
+            return self._conv_s(a.view(N, H, W, C), pk[id(m), "proj"], bias=m.proj_out.bias, residual=x)
+        return ops.conv2d(a.view(N, H, W, C), pk[id(m), "proj"], bias=m.proj_out.bias, residual=x), None
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, t, temb_rows=None):
@@ -273,44 +292,45 @@ class Model(nn.Module):
             tp = temb_rows.expand(x.shape[0], -1)      # row stride 0 when one row serves the whole batch
 
         if pk["conv_in"].k27:
-            h = ops.conv2d(x, pk["conv_in"], bias=self.conv_in.bias)
+            h, sh = self._conv_s(x, pk["conv_in"], bias=self.conv_in.bias)
         else:
-            h = ops.conv2d(ops.nchw_f32_to_nhwc_bf16(x), pk["conv_in"], bias=self.conv_in.bias)
-        hs = [h]
+            h, sh = self._conv_s(ops.nchw_f32_to_nhwc_bf16(x), pk["conv_in"], bias=self.conv_in.bias)
+        hs = [(h, sh)]
         tr("conv_in", h)
         for i_level, lvl in enumerate(self.down):
             for i_block, blk in enumerate(lvl.block):
-                h = self._resblock(pk, blk, hs[-1], None, tp)
+                h, sh = self._resblock(pk, blk, hs[-1][0], None, tp, s0=hs[-1][1])
                 tr(f"down.{i_level}.block.{i_block}", h)
                 if len(lvl.attn) > 0:
-                    h = self._attn(pk, lvl.attn[i_block], h)
+                    h, sh = self._attn(pk, lvl.attn[i_block], h, sh)
                     tr(f"down.{i_level}.attn.{i_block}", h)
-                hs.append(h)
+                hs.append((h, sh))
             if i_level != self.num_resolutions - 1:
                 ds = lvl.downsample
-                hs.append(ops.conv2d(hs[-1], pk[id(ds), "conv"], bias=ds.conv.bias, stride=2, pad=0, pad_br=1))
-                tr(f"down.{i_level}.downsample", hs[-1])
+                hs.append(self._conv_s(hs[-1][0], pk[id(ds), "conv"], bias=ds.conv.bias, stride=2, pad=0, pad_br=1))
+                tr(f"down.{i_level}.downsample", hs[-1][0])
 
-        h = hs[-1]
-        h = self._resblock(pk, self.mid.block_1, h, None, tp)
+        h, sh = hs[-1]
+        h, sh = self._resblock(pk, self.mid.block_1, h, None, tp, s0=sh)
         tr("mid.block_1", h)
-        h = self._attn(pk, self.mid.attn_1, h)
+        h, sh = self._attn(pk, self.mid.attn_1, h, sh)
         tr("mid.attn_1", h)
-        h = self._resblock(pk, self.mid.block_2, h, None, tp)
+        h, sh = self._resblock(pk, self.mid.block_2, h, None, tp, s0=sh)
         tr("mid.block_2", h)
 
         for i_level in reversed(range(self.num_resolutions)):
             lvl = self.up[i_level]
             for i_block, blk in enumerate(lvl.block):
-                h = self._resblock(pk, blk, h, hs.pop(), tp)  # cat(h, skip) is never materialised
+                skip, sskip = hs.pop()
+                h, sh = self._resblock(pk, blk, h, skip, tp, s0=sh, s1=sskip)  # cat(h, skip) is never materialised
                 tr(f"up.{i_level}.block.{i_block}", h)
                 if len(lvl.attn) > 0:
-                    h = self._attn(pk, lvl.attn[i_block], h)
+                    h, sh = self._attn(pk, lvl.attn[i_block], h, sh)
                     tr(f"up.{i_level}.attn.{i_block}", h)
             if i_level != 0:
                 us = lvl.upsample
-                h = ops.conv2d(h, pk[id(us), "conv"], bias=us.conv.bias, upsample=True)
+                h, sh = self._conv_s(h, pk[id(us), "conv"], bias=us.conv.bias, upsample=True)
                 tr(f"up.{i_level}.upsample", h)
 
-        a = ops.groupnorm_silu(h, self.norm_out.weight, self.norm_out.bias, eps=1e-6, silu=True)
+        a = ops.groupnorm_silu(h, self.norm_out.weight, self.norm_out.bias, eps=1e-6, silu=True, stats=(sh, None))
         return ops.conv2d(a, pk["conv_out"], bias=self.conv_out.bias, out_nchw_f32=True)

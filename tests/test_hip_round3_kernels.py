@@ -1,0 +1,169 @@
+"""Round-3 kernels through the C-ABI: GroupNorm block statistics from the conv epilogue (dxmi_conv_desc.gn_stats) and from
+the statistics kernel, the streaming GroupNorm apply pass, and the U-Net forward on that path against the one-pass path."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+
+
+def nchw(y):
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dxmi_hip import ops as o
+    o.device_check()
+    return o
+
+
+def _torch_block_stats(y):
+    """y NHWC bf16 -> [N, C/4, 2] fp64 (sum, sum of squares) of the stored values."""
+    N, H, W, C = y.shape
+    f = y.double().view(N, H * W, C // 4, 4)
+    return torch.stack([f.sum((1, 3)), (f * f).sum((1, 3))], -1)
+
+
+# shapes that select conv_ws_kernel<32> / <16> (incl. upsample, concat, residual, half-empty last cout tile, uneven persistent loop)
+STATS_CONV_CASES = [
+    # N, C0, C1, Cout, H(out), upsample, residual
+    (3, 128, 0, 128, 32, False, True),
+    (2, 256, 128, 128, 32, False, False),
+    (2, 256, 0, 256, 32, True, False),
+    (5, 256, 0, 256, 16, False, True),
+    (2, 256, 256, 256, 16, False, False),
+    (2, 256, 0, 192, 32, False, False),      # Cout % 128 == 64
+    (70, 128, 0, 128, 32, False, True),      # 280 tiles on 256 workgroups
+]
+
+
+@pytest.mark.parametrize("N,C0,C1,Cout,H,ups,res", STATS_CONV_CASES)
+def test_conv_epilogue_block_stats(ops, N, C0, C1, Cout, H, ups, res):
+    """The statistics the conv writes are those of the bf16 tensor it stores (exact sums in fp64 within fp32 accumulation
+    error), the output is bitwise the one of a launch without statistics, and both are bitwise reproducible."""
+    g = torch.Generator().manual_seed(7 + N + Cout)
+    IH = H // 2 if ups else H
+    x0 = torch.randn(N, IH, IH, C0, generator=g).to(torch.bfloat16).to(DEV)
+    x1 = torch.randn(N, IH, IH, C1, generator=g).to(torch.bfloat16).to(DEV) if C1 else None
+    pw = ops.pack_conv_weight((torch.randn(Cout, C0 + C1, 3, 3, generator=g) * 0.03).to(DEV))
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    temb = torch.randn(N, Cout, generator=g).to(DEV)
+    r = torch.randn(N, H, H, Cout, generator=g).to(torch.bfloat16).to(DEV) if res else None
+    kw = dict(in1=x1, bias=bias, addvec=temb, residual=r, upsample=ups)
+    y, st = ops.conv2d(x0, pw, want_stats=True, **kw)
+    assert st is not None and st.P == (2 if H == 16 else 8) and tuple(st.buf.shape) == (N, st.P, Cout // 4, 2)
+    y_plain = ops.conv2d(x0, pw, **kw)
+    assert torch.equal(y, y_plain)
+    ref = _torch_block_stats(y)
+    got = st.buf.double().sum(1)
+    assert (got - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    y2, st2 = ops.conv2d(x0, pw, want_stats=True, **kw)
+    assert torch.equal(st.buf, st2.buf) and torch.equal(y, y2)
+    # the statistics kernel on the same tensor: same sums up to fp32 order
+    st3 = ops.block_stats(y)
+    assert (st3.buf.double().sum(1) - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    # batch independence: image 0 alone gives bitwise the same statistics rows
+    y0, st0 = ops.conv2d(x0[:1].contiguous(), pw, want_stats=True, in1=None if x1 is None else x1[:1].contiguous(), bias=bias,
+                         addvec=temb[:1].contiguous(), residual=None if r is None else r[:1].contiguous(), upsample=ups)
+    assert torch.equal(st0.buf[0], st.buf[0])
+
+
+def test_conv_stats_unsupported_kernel_is_loud(ops):
+    """Shapes whose kernel writes no statistics report P = 0 (ops.conv2d then returns None for them), and forcing the
+    descriptor field anyway is an error, not a silent no-op."""
+    import ctypes
+    from dxmi_hip import _lib
+    x = torch.randn(2, 4, 4, 256).to(torch.bfloat16).to(DEV)
+    pw = ops.pack_conv_weight((torch.randn(256, 256, 3, 3) * 0.03).to(DEV))
+    y, st = ops.conv2d(x, pw, want_stats=True)
+    assert st is None
+    d = _lib.ConvDesc()
+    out = torch.empty_like(y)
+    junk = torch.empty(2 * 64 * 2, device=DEV)
+    d.in0, d.wpacked, d.out, d.gn_stats = x.data_ptr(), pw.buf.data_ptr(), out.data_ptr(), junk.data_ptr()
+    d.N, d.IH, d.IW, d.C0, d.C1, d.OH, d.OW, d.Cout = 2, 4, 4, 256, 0, 4, 4, 256
+    d.ksize, d.stride, d.pad = 3, 1, 1
+    assert _lib.load().dxmi_conv2d_fwd(ctypes.byref(d), None) == -1
+    assert b"statistics" in _lib.load().dxmi_last_error()
+
+
+GN_APPLY_CASES = [
+    # N, C0, C1, H, silu
+    (3, 128, 0, 32, True),
+    (2, 256, 0, 16, False),
+    (2, 256, 128, 32, True),     # 12 channels per group, groups straddle the concat boundary
+    (2, 256, 128, 16, True),
+    (2, 256, 256, 16, True),
+    (3, 128, 128, 32, True),
+    (2, 256, 0, 8, True),        # one chunk, partial trip
+    (1, 512, 0, 64, True),       # 4096 rows: 64 chunks per image
+    (2, 64, 0, 5, True),         # HW = 25: ragged rows
+]
+
+
+@pytest.mark.parametrize("N,C0,C1,H,silu", GN_APPLY_CASES)
+def test_groupnorm_apply_vs_torch_and_resident(ops, N, C0, C1, H, silu):
+    C = C0 + C1
+    g = torch.Generator().manual_seed(31 + C + H)
+    x = bf(torch.randn(N, C, H, H, generator=g) * 2.0 + 0.5)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    ref = F.group_norm(x, 32, gamma, beta, 1e-6)
+    if silu:
+        ref = F.silu(ref)
+    x0 = nhwc(x[:, :C0])
+    x1 = nhwc(x[:, C0:]) if C1 else None
+    s0 = ops.block_stats(x0)
+    s1 = ops.block_stats(x1) if C1 else None
+    assert s0.P == ops.load().dxmi_gn_block_stats_partials(H * H)
+    ga, be = gamma.to(DEV), beta.to(DEV)
+    y = ops.groupnorm_silu(x0, ga, be, in1=x1, eps=1e-6, silu=silu, stats=(s0, s1))
+    got = nchw(y)
+    assert (got - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+    assert ((got - ref).norm() / ref.norm()).item() < 4e-3
+    # against the exact result rounded once to bf16: all but a handful of values identical
+    same = (y.float().cpu() == ref.permute(0, 2, 3, 1).to(torch.bfloat16).float()).float().mean().item()
+    assert same > 0.999, same
+    if ops.load().dxmi_groupnorm_silu_supported(C0, C1, H * H, 32):
+        yr = ops.groupnorm_silu(x0, ga, be, in1=x1, eps=1e-6, silu=silu)
+        assert (y == yr).float().mean().item() > 0.999
+    y2 = ops.groupnorm_silu(x0, ga, be, in1=x1, eps=1e-6, silu=silu, stats=(s0, s1))
+    assert torch.equal(y, y2)                                   # bitwise reproducible
+    # batch independence
+    s00 = ops.BlockStats(s0.buf[:1].contiguous(), s0.P)
+    s10 = ops.BlockStats(s1.buf[:1].contiguous(), s1.P) if C1 else None
+    y0 = ops.groupnorm_silu(x0[:1].contiguous(), ga, be, in1=None if x1 is None else x1[:1].contiguous(), eps=1e-6, silu=silu, stats=(s00, s10))
+    assert torch.equal(y0[0], y[0])
+
+
+def test_unet_forward_streaming_groupnorm_vs_one_pass():
+    """The whole DDPM U-Net forward with the streaming GroupNorm path (default) and with the one-pass kernel everywhere:
+    same function up to the bf16 noise floor of a re-ordered fp32 variance (a flipped rounding perturbs ~1e3
+    downstream values), the default path bitwise reproducible and batch independent."""
+    from models.DxMI.unet_small import Model
+    from oracle.weights import formula_tensor
+    net = Model(ch=128, out_ch=3, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=[16], dropout=0.1, in_channels=3, resolution=32)
+    net.load_state_dict({k: (v if k in ("log_betas", "std") else formula_tensor(k, v.shape)) for k, v in net.state_dict().items()})
+    net = net.to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 3, 32, 32, generator=g).to(DEV)
+    t = torch.tensor([0.5, 30.0, 200.0, 640.0, 999.0], device=DEV)
+    with torch.no_grad():
+        y = net(x, t).clone()
+        y_again = net(x, t)
+        y_one = net(x[2:3].contiguous(), t[2:3].contiguous())
+        net.STREAM_GN_MIN_HW = 1 << 30
+        y_res = net(x, t)
+    assert torch.isfinite(y).all() and torch.equal(y, y_again)
+    assert torch.equal(y_one[0], y[2])
+    rel = ((y - y_res).norm() / y_res.norm()).item()
+    assert rel < 1.2e-2, rel

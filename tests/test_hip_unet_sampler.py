@@ -115,7 +115,7 @@ def test_resnet_and_attn_block_ops_vs_bf16_model(sampler10):
         att, pre = net.down[1].attn[0], "down.1.attn.0"
         xa = prec.act(torch.randn(2, 256, 16, 16, generator=g))
         ref = ounet.attn_block(sd, pre, xa, prec)
-        got = nchw(net._attn(pk, att, nhwc(xa)))
+        got = nchw(net._attn(pk, att, nhwc(xa))[0])          # (_attn returns (out, block statistics))
         check("attn block", got, ref, min_same=0.9, max_rel=5e-3)
         # stride-2 downsample and upsample convs
         ds = net.down[0].downsample

@@ -152,8 +152,12 @@ def test_hip_trainer_step_vs_reference(golden_dir, fixture, fused):
         (measured 0.9989-1.0000; bound 0.995) and by norm (the global clip coefficient agrees: within 5 %);
       * parameter updates: Adam's first step is -lr*g/(|g|+1e-8), so an update direction is the gradient's sign
         pattern: cosine of the update against the reference's update (measured 0.983-1.0; bound 0.97 — elements whose
-        gradient is below the bf16 noise flip sign)."""
+        gradient is below the bf16 noise flip sign).
+    fused: the shipped configuration — dxmi_hip.optim.Adam (multi-tensor kernel; the trainer's gradient clip is the
+    device-side dxmi_gradnorm_clip in both cases) instead of torch.optim.Adam."""
     from models.DxMI.trainer import DxMI_Trainer, append_buffer, reset_buffer
+    from dxmi_hip.optim import Adam as FusedAdam
+    AdamCls = FusedAdam if fused else torch.optim.Adam
     DEV = "cuda:0"
     g = load(golden_dir, fixture)
     B, T = int(g["B"]), int(g["T"])
