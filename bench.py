@@ -90,6 +90,8 @@ def kernel_name(kid):
         return f"conv1x1_rw_kernel<{(kid // 1000) % 10}, {(kid // 10) % 100}, {'true' if kid % 10 else 'false'}>"
     if kid == 400008:
         return "conv_ws8_kernel"
+    if kid >= 450000:
+        return f"conv_sm_kernel<{2 if (kid - 450000) // 100 == 4 else 3}, 8, {kid % 100}>"
     if kid >= 400000:
         return f"conv_ws_kernel<{kid - 400000}>"
     if kid >= 300000:

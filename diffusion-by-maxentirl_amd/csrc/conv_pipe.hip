@@ -641,6 +641,7 @@ int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);       // co
 int conv1x1_rw_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);   // conv1x1_rw.hip
 int conv_head_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);    // conv_head.hip
 int conv_ws8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);     // conv_ws8.hip
+int conv_sm_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);      // conv_sm.hip
 
 int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     {
@@ -652,6 +653,8 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
         rc = conv1x1_rw_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;
         rc = conv_head_try_launch(a, st, kernel_id);
+        if (rc <= 0) return rc;
+        rc = conv_sm_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;
         rc = conv_ws8_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;

@@ -138,7 +138,7 @@ def test_conv1x1_rw(ops, N, C0, C1, Cout, H, fuse):
 def test_round2_kernels_out_of_scope_shapes_fall_back(ops):
     """shapes just outside the new kernels' scope still run (on the round-1 kernels) and agree with the reference"""
     for (N, C0, C1, Cout, H, k, fuse) in [(2, 128, 0, 96, 32, 3, "bias"),       # Cout % 64 != 0
-                                          (4, 256, 0, 256, 4, 3, "bias+res"),    # 4x4 map
+                                          (4, 128, 0, 256, 4, 3, "bias+res"),    # 4x4 map, four chunks (conv_sm_kernel takes >= 5)
                                           (2, 96, 0, 128, 32, 3, "bias"),        # odd chunk count
                                           (8, 256, 0, 256, 16, 1, "bias"),       # 1x1 with too few pixels
                                           (128, 192, 0, 384, 16, 1, "bias")]:    # 1x1 with K % 128 != 0

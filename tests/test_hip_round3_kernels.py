@@ -167,3 +167,67 @@ def test_unet_forward_streaming_groupnorm_vs_one_pass():
     assert torch.equal(y_one[0], y[2])
     rel = ((y - y_res).norm() / y_res.norm()).item()
     assert rel < 1.2e-2, rel
+
+
+# ------------------------------------------------------------------------------------------------ conv_sm_kernel (4x4 maps)
+def _conv_ref(x0, x1, w, bias, temb, r, act):
+    xin = torch.cat([x0, x1], 3) if x1 is not None else x0
+    ref = F.conv2d(xin.float().permute(0, 3, 1, 2).cpu(), w.to(torch.bfloat16).float().cpu(), bias.cpu() if bias is not None else None, padding=1)
+    if temb is not None:
+        ref = ref + temb.cpu()[:, :, None, None]
+    if r is not None:
+        ref = ref + r.float().cpu().permute(0, 3, 1, 2)
+    if act == 1:
+        ref = F.leaky_relu(ref, 0.2)
+    elif act == 2:
+        ref = F.relu(ref)
+    return ref.permute(0, 2, 3, 1)
+
+
+SM_CASES = [
+    # N, C0, C1, Cout, residual, temb, bias, act
+    (256, 256, 0, 256, True, True, True, 0),       # one tile per CU
+    (37, 256, 0, 256, True, True, True, 0),        # ragged last 8-image tile
+    (3, 256, 256, 256, False, True, True, 0),      # concat, 16 chunks, fewer images than one tile
+    (70, 160, 96, 64, True, False, False, 1),      # odd concat split, two cout tiles, leaky, no bias / temb
+    (300, 256, 0, 256, True, True, True, 2),       # 304 tiles on 256 workgroups: the stream runs across tile ends
+]
+
+
+@pytest.mark.parametrize("N,C0,C1,Cout,res,temb,bias,act", SM_CASES)
+def test_conv_sm_4x4(ops, N, C0, C1, Cout, res, temb, bias, act):
+    import ctypes
+    g = torch.Generator().manual_seed(5 + N + Cout)
+    x0 = torch.randn(N, 4, 4, C0, generator=g).to(torch.bfloat16).to(DEV)
+    x1 = torch.randn(N, 4, 4, C1, generator=g).to(torch.bfloat16).to(DEV) if C1 else None
+    w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) * 0.03).to(DEV)
+    pw = ops.pack_conv_weight(w)
+    bv = torch.randn(Cout, generator=g).to(DEV) if bias else None
+    tv = torch.randn(N, Cout, generator=g).to(DEV) if temb else None
+    r = torch.randn(N, 4, 4, Cout, generator=g).to(torch.bfloat16).to(DEV) if res else None
+    kw = dict(in1=x1, bias=bv, addvec=tv, residual=r, act=act)
+    y = ops.conv2d(x0, pw, **kw)
+    ref = _conv_ref(x0, x1, w, bv, tv, r, act)
+    rel = ((y.float().cpu() - ref).norm() / ref.norm()).item()
+    assert rel < 4e-3, rel
+    # it IS the small-map kernel
+    prof = ops.OpProfiler()
+    ops.PROFILER = prof
+    try:
+        ops.conv2d(x0, pw, **kw)
+    finally:
+        ops.PROFILER = None
+    torch.cuda.synchronize()
+    assert [k[1] for k in prof.summary()] == [450432]          # conv_sm_kernel<2, 8, 32>
+    # bitwise reproducible and independent of the batch an image rides in (first, middle, last image alone)
+    assert torch.equal(y, ops.conv2d(x0, pw, **kw))
+    for i in {0, N // 2, N - 1}:
+        one = ops.conv2d(x0[i:i + 1].contiguous(), pw, in1=None if x1 is None else x1[i:i + 1].contiguous(), bias=bv,
+                         addvec=None if tv is None else tv[i:i + 1].contiguous(), residual=None if r is None else r[i:i + 1].contiguous(), act=act)
+        assert torch.equal(one[0], y[i]), i
+    # a NaN input pixel poisons its 3x3 neighbourhood of every cout and nothing else
+    xn = x0.clone()
+    xn[N - 1, 1, 2, 7] = float("nan")
+    yn = ops.conv2d(xn, pw, **kw)
+    bad = torch.isnan(yn.float())
+    assert bad[N - 1, 0:3, 1:4].all() and not bad[N - 1, 3].any() and not bad[N - 1, :, 0].any() and not bad[:N - 1].any()
