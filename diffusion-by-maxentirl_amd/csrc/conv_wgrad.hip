@@ -172,11 +172,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll 8
             for (int px = part * 32; px < part * 32 + 32; ++px) bsum += (float)*reinterpret_cast<const bf16*>(ydy + px * WG_PITCH + col * 2);
         }
-        // ---- 8 k-steps of 16 pixels
-#pragma unroll 2
-        for (int kb = 0; kb < TP / 16; ++kb) {
+        // ---- 8 k-steps of 16 pixels.  The 20 transposing reads of k-step kb + 1 (one A fragment, nine B windows) are issued
+        // BEFORE the nine MFMAs of k-step kb (double-buffered fragments): left to itself hipcc reads a fragment one or two
+        // MFMAs ahead of its use and the wave — alone on its SIMD at 288 registers — exposes an LDS latency per MFMA
+        // (round-2 profile: 0.13 of the MFMA peak).
+        auto read_step = [&](int kb, bf16x8& a, bf16x8 (&bw)[TAPS]) {
             const int plo = kb * 16 + krow, phi = plo + 4;
-            const bf16x8 a = tr_frag(ydy + plo * WG_PITCH + wr * 64 + ch_off, ydy + phi * WG_PITCH + wr * 64 + ch_off);
+            a = tr_frag(ydy + plo * WG_PITCH + wr * 64 + ch_off, ydy + phi * WG_PITCH + wr * 64 + ch_off);
             // halo offsets of the two pixel rows this lane addresses
             const int xl = plo & (TW - 1), yl = (plo >> p.TWl) & (TH - 1), sl = plo >> (p.TWl + p.THl);
             const int xh = phi & (TW - 1), yh = (phi >> p.TWl) & (TH - 1), sh = phi >> (p.TWl + p.THl);
@@ -185,9 +187,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
                 const int toff = ((t / KS) * p.HWd + (t % KS)) * WG_PITCH;
-                const bf16x8 bfrag = tr_frag(bl + toff, bh + toff);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfrag, acc[t], 0, 0, 0);
+                bw[t] = tr_frag(bl + toff, bh + toff);
             }
+        };
+        bf16x8 a0, a1, b0[TAPS], b1[TAPS];
+        read_step(0, a0, b0);
+#pragma unroll
+        for (int kb = 0; kb < TP / 16; kb += 2) {
+            read_step(kb + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 2 < TP / 16) read_step(kb + 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (p.bpart && cib == 0) p.bpart[((size_t)split * 4 + (tid >> 6)) * p.Cout + co0 + (tid & 63)] = bsum;
@@ -279,7 +295,7 @@ int ilog2w(int v) {
 
 extern "C" int64_t dxmi_conv2d_wgrad_workspace_bytes(int32_t N, int32_t OH, int32_t OW, int32_t Cin, int32_t Cout, int32_t ksize) {
     const long PT = ((long)N * OH * OW + 127) / 128 + 16;
-    long S = 512 / ((long)(Cin / 64) * (Cout / 64));
+    long S = 512 / ((long)(Cin / 64) * (Cout / 64));      // upper bound of the split count chosen at launch
     if (S < 1) S = 1;
     if (S > PT) S = PT;
     return S * ksize * ksize * (int64_t)Cout * Cin * 4 + S * 4 * (int64_t)Cout * 4;   // + bias-gradient partials
@@ -306,7 +322,13 @@ static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, co
     const int ngroups = (N + a.SUBS - 1) / a.SUBS;
     a.PT = ngroups * (OH / TH) * (OW / TW);
     a.CIB = Cin / 64; a.COB = Cout / 64;
-    int S = 512 / (a.CIB * a.COB);
+    // pixel splits: the kernel holds one workgroup per CU (368 registers per lane), so 256 workgroups fill the chip; more
+    // splits only add partial-sum traffic (each split writes and the reduce re-reads taps x Cout x Cin floats)
+    // (the 1x1 kernel's single accumulator block lets two workgroups share a CU: 512 there; fewer, longer splits on the 4x4
+    // maps measured slower: 64 workgroups instead of 256)
+    static const int wgs_env = getenv("DXMI_WGRAD_WGS") ? atoi(getenv("DXMI_WGRAD_WGS")) : 0;      // tuning override
+    const int wgs = wgs_env > 0 ? wgs_env : (ksize == 3 ? 256 : 512);
+    int S = wgs / (a.CIB * a.COB);
     if (S < 1) S = 1;
     if (S > a.PT) S = a.PT;
     a.S = S;
