@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--no-eager-reference", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the per-launch HIP events (roofline legs)")
     ap.add_argument("--train-steps", type=int, default=5, help="timed DxMI train steps (0 = skip the train leg)")
+    ap.add_argument("--no-edm", action="store_true", help="skip the EDM legs (BASELINE configs[3], configs[4] at their per-GPU sizes)")
     return ap.parse_args()
 
 
@@ -234,6 +235,116 @@ def train_step(tr, sampler, images, device, ring):
     return d_energy, d_sampler
 
 
+def edm_generation_leg(device, name, B, reps=2, events=True):
+    """BASELINE configs[3] / configs[4] at their per-GPU batch (generate_large.py:22-44: `--batchsize` is per rank): the
+    reference's EDM / ADM U-Net (models/cm/unet.py) under OpenAIDiffusion.sample (models/DxMI/openai_diffusion.py:101) on the HIP
+    path, random-init weights of the named architecture (zero-initialised layers get weights so no work is skipped),
+    x_T and the per-step draws inside the timed call.  Outside the headline timed region; one warm-up call + `reps` timed."""
+    import torch
+    import configs_builtin
+    from dxmi_hip import ops
+    from models.cm.script_util import create_model_and_diffusion
+    from models.DxMI.openai_diffusion import OpenAIDiffusion
+    cfg = configs_builtin.get(name)
+    torch.manual_seed(0)
+    with torch.device(device):            # parameters are created (and initialised) on the GPU: 0.3 / 0.5 G parameters
+        net, diffusion = create_model_and_diffusion(**cfg.diffusion)
+    with torch.no_grad():
+        for p in net.parameters():
+            if float(p.abs().max()) == 0:
+                torch.nn.init.normal_(p, std=0.02)
+    s = OpenAIDiffusion(net, diffusion, **cfg.sampler)
+    net.to(device).eval()
+    T = s.n_timesteps
+    out = {"workload": f"{name}: EDM U-Net ({sum(p.numel() for p in net.parameters()) / 1e6:.1f}M params) OpenAIDiffusion T={T}, "
+                       f"{B} images/GPU/call, 3x{cfg.diffusion.image_size}x{cfg.diffusion.image_size}, bf16 torso", "T": T, "batch": B}
+    with torch.no_grad():
+        d = s.sample(B, device=device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            d = s.sample(B, device=device)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        assert torch.isfinite(d["sample"]).all()
+        out.update({"images_per_sec": round(B / dt, 1), "ms_per_call": round(dt * 1e3, 1), "timed_calls": reps})
+        if events:
+            prof = ops.OpProfiler()
+            ops.PROFILER = prof
+            s.sample(B, device=device)
+            torch.cuda.synchronize()
+            ops.PROFILER = None
+            summ = prof.summary()
+            out["roofline_classes"] = class_rooflines(summ, dt)
+            convs = {k: v for k, v in summ.items() if k[0].startswith("conv")}
+            (cls, kid), c = max(convs.items(), key=lambda kv: kv[1]["ms"])
+            tf = c["flops"] / (c["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": kernel_name(kid), "achieved": round(tf, 1), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "launches_per_call": c["launches"],
+                               "avg_launch_us": round(1e3 * c["ms"] / c["launches"], 1), "share_of_call_time": round(c["ms"] * 1e-3 / dt, 4)}
+            out["conv_kernels"] = {kernel_name(k[1]): {"launches": v["launches"], "ms": round(v["ms"], 2),
+                                                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in convs.items()}
+    del s, net, d
+    torch.cuda.empty_cache()
+    return out
+
+
+def edm_train_leg(device, name="imagenet64_T10", B=16, steps=2):
+    """One DxMI_Trainer_Cond step (models/DxMI/trainer.py:693-746 through MixedPrecisionTrainer, models/cm/fp16_util.py) on the
+    ImageNet-64 EDM net at per-GPU batch `B` (synthetic images / labels): sample T + update_f_v + update_sampler_mixed_precision."""
+    import torch
+    import configs_builtin
+    import dxmi_config
+    from dxmi_hip.optim import Adam, RAdam
+    from models.cm.fp16_util import MixedPrecisionTrainer
+    from models.cm.script_util import create_model_and_diffusion
+    from models.DxMI.openai_diffusion import OpenAIDiffusion
+    from models.DxMI.trainer import append_buffer, reset_buffer
+    cfg = configs_builtin.get(name)
+    torch.manual_seed(0)
+    with torch.device(device):
+        unet, diffusion = create_model_and_diffusion(**cfg.diffusion)
+    with torch.no_grad():
+        for p in unet.parameters():
+            if float(p.abs().max()) == 0:
+                torch.nn.init.normal_(p, std=0.02)
+    sampler = OpenAIDiffusion(unet, diffusion, **cfg.sampler)
+    unet.to(device)
+    v = dxmi_config.instantiate(cfg.value).to(device)
+    mp = MixedPrecisionTrainer(model=unet, use_fp16=True, initial_lg_loss_scale=20, special_key="log_betas")
+    opt = RAdam([{"params": mp.master_params[1:], "lr": 1e-8}, {"params": mp.master_params[0:1], "lr": 1e-6}])
+    opt_v = Adam(v.parameters(), lr=1e-5)
+    trainer = dxmi_config.instantiate(cfg.trainer, batchsize=B)
+    trainer.set_models(v=v, sampler=sampler, optimizer=opt, optimizer_v=opt_v)
+    res = cfg.diffusion.image_size
+    g = torch.Generator(device=device).manual_seed(1)
+
+    def step():
+        data = torch.rand(B, 3, res, res, device=device, generator=g) * 2 - 1
+        y = torch.randint(0, 1000, (B,), device=device, generator=g)
+        sampler.eval()
+        d = sampler.sample(B, device=device, i_class=y)
+        buf = append_buffer(reset_buffer(device), d)
+        le = trainer.update_f_v(data, d, buf, y=y)
+        ls = trainer.update_sampler_mixed_precision(buf, mp_trainer=mp)
+        return le, ls
+
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        le, ls = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert all(x == x for x in le.values())
+    out = {"workload": f"{name}: DxMI_Trainer_Cond step, per-GPU batch {B}, T={sampler.n_timesteps}, fused RAdam / Adam, loss scale 2^20",
+           "train_steps_per_sec": round(1 / dt, 3), "ms_per_step": round(dt * 1e3, 1), "timed_steps": steps,
+           "lg_loss_scale_after": round(float(mp.lg_loss_scale), 3)}
+    del trainer, mp, opt, opt_v, sampler, unet, v
+    torch.cuda.empty_cache()
+    return out
+
+
 def class_rooflines(summ, step_seconds):
     """Per kernel class: MFMA-graded (conv*, attention also reported against MFMA, wgrad) or HBM-graded."""
     by_cls = {}
@@ -395,6 +506,11 @@ def main():
                                                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in convs.items()}
     if train_summ:
         line["train_roofline_classes"] = class_rooflines(train_summ, t_train_step)
+    if world == 1 and not args.no_edm:
+        # BASELINE configs[3] / [4] (EDM backbones) at their per-GPU sizes + the EDM train step: rank 0, outside the timed region
+        line["edm"] = {"imagenet64_T10_b100": edm_generation_leg(device, "imagenet64_T10", 100, events=not args.no_events),
+                       "lsun_bedroom_T4_b16": edm_generation_leg(device, "lsun_bedroom_T4", 16, events=not args.no_events),
+                       "imagenet64_T10_train_b16": edm_train_leg(device)}
     if world == 1 and not args.no_eager_reference:
         eg = eager_reference_gpu(device, T, B)
         line["reference_eager_gpu"] = {

@@ -22,7 +22,7 @@ struct ConvArgs {
     float mask_slope;        // factor applied where mask_src <= 0 (0.2 leaky, 0 relu)
     int stagger;             // conv_pipe: start delay (units of s_sleep 127 ~ 8k cycles) of the second resident half
     int RP, SP;              // conv_pipe: LDS pitch of a halo row / of a sub-image, bytes (bank-conflict-free choice)
-    float* gn_stats;         // optional: GroupNorm block statistics of the OUTPUT, fp32 [N][P][Cout/4][2] (dxmi_conv_desc.gn_stats)
+    float* gn_stats;         // optional: GroupNorm block statistics of the OUTPUT, fp32 [N][P][Cout/2][2] (dxmi_conv_desc.gn_stats)
 };
 
 // Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15): every lane of the row ends with the row's total.  Each step adds
@@ -37,15 +37,17 @@ __device__ __forceinline__ float dxmi_row16_sum(float t) {
     return t;
 }
 
-// (sum, sum of squares) of four bf16 values — the values as STORED, so a GroupNorm fed by these statistics normalises
-// exactly the tensor the consumer reads — added to (s, q): four v_dot2c_f32_bf16.
-__device__ __forceinline__ void dxmi_stats4(const bf16x4& o, float& s, float& q) {
+// (sum, sum of squares) of the two channel PAIRS of four bf16 values — the values as STORED, so a GroupNorm fed by these
+// statistics normalises exactly the tensor the consumer reads — added to st = (s_lo, q_lo, s_hi, q_hi): four v_dot2c_f32_bf16.
+// Pairs are the granularity of the statistics tensors: every group width of the U-Nets (4 ... 32 channels per group, 6 and
+// 18 in the ImageNet-64 net) and every concat boundary is a whole number of pairs.
+__device__ __forceinline__ void dxmi_stats4(const bf16x4& o, float (&st)[4]) {
     const bf16x2 lo = {o[0], o[1]}, hi = {o[2], o[3]};
     const bf16x2 one = {(bf16)1.f, (bf16)1.f};
-    s = __builtin_amdgcn_fdot2_f32_bf16(lo, one, s, false);
-    s = __builtin_amdgcn_fdot2_f32_bf16(hi, one, s, false);
-    q = __builtin_amdgcn_fdot2_f32_bf16(lo, lo, q, false);
-    q = __builtin_amdgcn_fdot2_f32_bf16(hi, hi, q, false);
+    st[0] = __builtin_amdgcn_fdot2_f32_bf16(lo, one, st[0], false);
+    st[1] = __builtin_amdgcn_fdot2_f32_bf16(lo, lo, st[1], false);
+    st[2] = __builtin_amdgcn_fdot2_f32_bf16(hi, one, st[2], false);
+    st[3] = __builtin_amdgcn_fdot2_f32_bf16(hi, hi, st[3], false);
 }
 
 // XCD-aware block mapping: blocks b and b+8 share an XCD (round-robin dispatch), so the CT

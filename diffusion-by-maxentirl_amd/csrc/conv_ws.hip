@@ -247,14 +247,14 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 const bool plain = p.act == DXMI_ACT_NONE;
                 char* const rowb = ro + ((ph * 128 + px) << 8) + 8 * (kg & 1);         // pixel row of block 0: blocks are 4 KiB apart
                 // GroupNorm block statistics of the output (optional): this wave's 128 pixels x its 64 couts -> (sum, sum of
-                // squares) per 4-cout block, partial (pixel tile, pixel half) of the image: [pt * 2 + ph][Cout / 4][2].  A lane's
-                // four accumulator values of a (cb, nb) ARE one 4-cout block of one pixel: 8 pixels in registers, 16 in the DPP row.
+                // squares) per cout PAIR, partial (pixel tile, pixel half) of the image: [pt * 2 + ph][Cout / 2][2].  A lane's
+                // four accumulator values of a (cb, nb) are two pairs of one pixel: 8 pixels in registers, 16 in the DPP row.
                 const bool want_stats = p.gn_stats != nullptr;
                 const int cot_ = q % p.CT;
-                float* const stp = want_stats ? p.gn_stats + ((size_t)((q / p.CT) * 2 + ph) * (p.Cout >> 2) + cot_ * 32 + ch * 16 + kg) * 2 : nullptr;
+                float* const stp = want_stats ? p.gn_stats + ((size_t)((q / p.CT) * 2 + ph) * (p.Cout >> 1) + cot_ * 64 + ch * 32 + kg * 2) * 2 : nullptr;
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
-                    float st_s = 0.f, st_q = 0.f;
+                    float st[4] = {0.f, 0.f, 0.f, 0.f};
                     const int co = ch * 64 + cb * 16 + 4 * kg;
                     const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb + co), t0 = *reinterpret_cast<const f32x4*>(tb + 128 + co);
                     f32x4 bv;
@@ -283,17 +283,18 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
                         *reinterpret_cast<bf16x4*>(a0 + nb * 4096) = o;
-                        if (want_stats) dxmi_stats4(o, st_s, st_q);
+                        if (want_stats) dxmi_stats4(o, st);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[cb][nb][e] = 0.f;
                     }
                     if (want_stats) {
-                        st_s = dxmi_row16_sum(st_s);
-                        st_q = dxmi_row16_sum(st_q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) st[e] = dxmi_row16_sum(st[e]);
                         if (px == 0 && cot_ * 128 + co < p.Cout) {
-                            float2 sv;
-                            sv.x = st_s; sv.y = st_q;
-                            *reinterpret_cast<float2*>(stp + cb * 8) = sv;
+                            f32x4 sv;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) sv[e] = st[e];
+                            *reinterpret_cast<f32x4*>(stp + cb * 16) = sv;     // pairs (co / 2, co / 2 + 1): 8 pairs per 16-cout block
                         }
                     }
                 }

@@ -326,12 +326,13 @@ __global__ __launch_bounds__(256) void gn_gen_apply_kernel(GnGenArgs p) {
 struct GnApplyArgs {
     const bf16* in0;
     const bf16* in1;
-    const float* st0;    // [N][P0][C0/4][2]
-    const float* st1;    // [N][P1][C1/4][2]
+    const float* st0;    // [N][P0][C0/2][2]
+    const float* st1;    // [N][P1][C1/2][2]
     const float* gamma;
     const float* beta;
+    const float* ss;     // optional FiLM scale-shift [N][ss_ld]: scale at [c], shift at [C + c] (models/cm/unet.py:252-256)
     bf16* out;
-    int C0, C1, HW, groups, cpg, chunks, rows_per_chunk, P0, P1;
+    int C0, C1, HW, groups, cpg, chunks, rows_per_chunk, P0, P1, ss_ld;
     float eps;
     int silu;
 };
@@ -363,13 +364,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
         }
     }
     if (tid < p.groups) {
-        // group tid = blocks [tid*cpg/4, (tid+1)*cpg/4) of the virtual concat, each from one source's statistics
-        const int bpg = p.cpg >> 2, nb0 = p.C0 >> 2;
+        // group tid = channel pairs [tid*cpg/2, (tid+1)*cpg/2) of the virtual concat, each from one source's statistics
+        const int bpg = p.cpg >> 1, nb0 = p.C0 >> 1;
         float s = 0.f, q = 0.f;
         for (int b = tid * bpg; b < (tid + 1) * bpg; ++b) {
             const bool f0 = b < nb0;
             const float* st = f0 ? p.st0 : p.st1;
-            const int P = f0 ? p.P0 : p.P1, nbs = f0 ? nb0 : (p.C1 >> 2), bl = f0 ? b : b - nb0;
+            const int P = f0 ? p.P0 : p.P1, nbs = f0 ? nb0 : (p.C1 >> 1), bl = f0 ? b : b - nb0;
             const float2* sp = reinterpret_cast<const float2*>(st) + (size_t)n * P * nbs + bl;
             for (int k = 0; k < P; ++k) {
                 const float2 t = sp[(size_t)k * nbs];
@@ -391,9 +392,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int g = (c + e) / p.cpg;
-            const float a = rstd_s[g] * (e < 4 ? g0[e] : g1[e - 4]);
+            float a = rstd_s[g] * (e < 4 ? g0[e] : g1[e - 4]);
+            float b = (e < 4 ? b0[e] : b1[e - 4]) - mean_s[g] * a;
+            if (p.ss) {
+                const float sc = 1.f + p.ss[(size_t)n * p.ss_ld + c + e];
+                a *= sc;
+                b = b * sc + p.ss[(size_t)n * p.ss_ld + C + c + e];
+            }
             A[e] = a;
-            Bv[e] = (e < 4 ? b0[e] : b1[e - 4]) - mean_s[g] * a;
+            Bv[e] = b;
         }
     }
     for (;;) {
@@ -421,12 +428,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
     }
 }
 
-// Block statistics of a tensor nobody produced statistics for: x [N,HW,C] -> st [N][P][C/4][2], P row chunks per image.
-// Thread = one 8-channel piece column (two blocks) over the chunk's rows; the row-parallel partials are added in a fixed
+// Block statistics of a tensor nobody produced statistics for: x [N,HW,C] -> st [N][P][C/2][2], P row chunks per image.
+// Thread = one 8-channel piece column (four pairs) over the chunk's rows; the row-parallel partials are added in a fixed
 // order through LDS.
 __global__ __launch_bounds__(256) void gn_block_stats_kernel(const bf16* __restrict__ x, float* __restrict__ st, int HW, int C,
                                                              int chunks, int rows_per_chunk) {
-    __shared__ float sm[256 * 4];         // [row lane][piece][s0 q0 s1 q1]: rows_par * c8n <= 256 entries of 4
+    __shared__ float sm[256 * 8];         // [row lane][piece][4 pairs x (s, q)]
     const int c8n = C >> 3;
     const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
     const int tid = threadIdx.x;
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(256) void gn_block_stats_kernel(const bf16* __restr
     const int rl = tid / c8n, pc = tid - rl * c8n;
     const int row0 = chunk * rows_per_chunk;
     const int row1 = min(row0 + rows_per_chunk, HW);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
     if (rl < rows_par) {
         const bf16* src = x + (size_t)n * HW * C + pc * 8;
         for (int r = row0 + rl; r < row1; r += 4 * rows_par) {
@@ -449,22 +456,37 @@ __global__ __launch_bounds__(256) void gn_block_stats_kernel(const bf16* __restr
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bf16x4 lo = {v[u][0], v[u][1], v[u][2], v[u][3]}, hi = {v[u][4], v[u][5], v[u][6], v[u][7]};
-                dxmi_stats4(lo, acc[0], acc[1]);
-                dxmi_stats4(hi, acc[2], acc[3]);
+                dxmi_stats4(lo, a0);
+                dxmi_stats4(hi, a1);
             }
         }
-        float* d = sm + (rl * c8n + pc) * 4;
+        float* d = sm + (rl * c8n + pc) * 8;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) d[e] = acc[e];
+        for (int e = 0; e < 4; ++e) { d[e] = a0[e]; d[4 + e] = a1[e]; }
     }
     __syncthreads();
-    // one thread per (block, s|q): C/4 * 2 <= 256 outputs for C <= 512; larger C loops
-    for (int i = tid; i < (C >> 2) * 2; i += 256) {
-        const int b = i >> 1, w = i & 1;      // block b = piece b/2, half b&1
+    // one thread per output float: (C/2 pairs) x (s, q) = C values, laid out exactly like a piece's 8 LDS floats
+    for (int i = tid; i < C; i += 256) {
         float t = 0.f;
-        for (int rr = 0; rr < rows_par; ++rr) t += sm[(rr * c8n + (b >> 1)) * 4 + (b & 1) * 2 + w];
-        st[(((size_t)n * chunks + chunk) * (C >> 2) + b) * 2 + w] = t;
+        for (int rr = 0; rr < rows_par; ++rr) t += sm[(rr * c8n) * 8 + i];
+        st[((size_t)n * chunks + chunk) * C + i] = t;
     }
+}
+
+// Partial sums of an image folded G at a time: st [N][P][C/2][2] -> out [N][ceil(P/G)][C/2][2], fixed order.  The conv
+// epilogue writes one partial per (pixel tile, pixel half): 8 at 32x32, but 512 at 256x256 (LSUN) — too many for every apply
+// workgroup to re-add, and too long a dependent chain for one thread per value (a 512-deep fold by N x C threads measured
+// ~0.3 ms): G <= 32 per thread, a second launch folds what is left.
+__global__ __launch_bounds__(256) void gn_stats_fold_kernel(const float* __restrict__ st, float* __restrict__ out, int P, int C, int G) {
+    const int PG = (P + G - 1) / G;
+    const int n = blockIdx.y / PG, pg = blockIdx.y - n * PG, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= C) return;
+    const int k0 = pg * G, k1 = min(k0 + G, P);
+    const float* s = st + ((size_t)n * P + k0) * C + i;
+    float t = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < k1 - k0; ++k) t += s[(size_t)k * C];
+    out[((size_t)n * PG + pg) * C + i] = t;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1079,18 +1101,28 @@ extern "C" int dxmi_gn_block_stats(const void* x, float* stats, int32_t N, int32
     return DXMI_OK;
 }
 
+extern "C" int dxmi_gn_stats_fold(const float* stats, float* out, int32_t N, int32_t P, int32_t C, int32_t group, void* stream) {
+    DXMI_CHECK_ARG(stats && out && N > 0 && P > 0 && C > 0 && C % 2 == 0 && group > 0, "dxmi_gn_stats_fold: bad arguments");
+    const int PG = (P + group - 1) / group;
+    hipLaunchKernelGGL(gn_stats_fold_kernel, dim3((C + 255) / 256, N * PG), dim3(256), 0, (hipStream_t)stream, stats, out, P, C, group);
+    DXMI_CHECK_LAUNCH("dxmi_gn_stats_fold");
+    return DXMI_OK;
+}
+
 extern "C" int dxmi_groupnorm_apply(const void* in0, int32_t C0, const float* stats0, int32_t P0, const void* in1, int32_t C1,
-                                    const float* stats1, int32_t P1, const float* gamma, const float* beta, void* out,
-                                    int32_t N, int32_t HW, int32_t groups, float eps, int32_t apply_silu, void* stream) {
+                                    const float* stats1, int32_t P1, const float* gamma, const float* beta,
+                                    const float* scale_shift, int32_t ss_ld, void* out, int32_t N, int32_t HW, int32_t groups,
+                                    float eps, int32_t apply_silu, void* stream) {
     DXMI_CHECK_ARG(in0 && stats0 && gamma && beta && out && P0 > 0, "dxmi_groupnorm_apply: null pointer");
     DXMI_CHECK_ARG(C1 == 0 || (in1 && stats1 && P1 > 0), "dxmi_groupnorm_apply: C1>0 needs in1 and stats1");
     const int C = C0 + C1;
     DXMI_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0, "dxmi_groupnorm_apply: C=%d groups=%d", C, groups);
     const int cpg = C / groups;
-    DXMI_CHECK_ARG(cpg % 4 == 0 && C0 % 8 == 0 && C1 % 8 == 0 && C <= 2048,
-                   "dxmi_groupnorm_apply: channels per group (%d) must be a multiple of 4, C0/C1 (%d/%d) multiples of 8", cpg, C0, C1);
+    DXMI_CHECK_ARG(cpg % 2 == 0 && C0 % 8 == 0 && C1 % 8 == 0 && C <= 2048,
+                   "dxmi_groupnorm_apply: channels per group (%d) must be even, C0/C1 (%d/%d) multiples of 8", cpg, C0, C1);
     GnApplyArgs a;
     a.in0 = (const bf16*)in0; a.in1 = (const bf16*)in1; a.st0 = stats0; a.st1 = stats1; a.gamma = gamma; a.beta = beta;
+    a.ss = scale_shift; a.ss_ld = ss_ld;
     a.out = (bf16*)out; a.C0 = C0; a.C1 = C1; a.HW = HW; a.groups = groups; a.cpg = cpg; a.P0 = P0; a.P1 = P1;
     a.eps = eps; a.silu = apply_silu;
     // a workgroup streams ~64 KB: four trips of U = 4 rows x (256 / (C/8)) row lanes

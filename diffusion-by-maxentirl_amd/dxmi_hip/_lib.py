@@ -36,8 +36,9 @@ SIGNATURES = {
     "dxmi_conv2d_gn_stats_partials": (c_int, [ctypes.POINTER(ConvDesc)]),
     "dxmi_gn_block_stats_partials": (c_int, [c_int]),
     "dxmi_gn_block_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "dxmi_groupnorm_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                     c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "dxmi_gn_stats_fold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dxmi_groupnorm_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dxmi_packed_conv_weight_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
     "dxmi_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_conv2d_wgrad_workspace_bytes": (c_int64, [c_int] * 6),

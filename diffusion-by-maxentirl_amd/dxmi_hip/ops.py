@@ -63,8 +63,8 @@ def pack_conv_weight(w, transpose_flip=False, k27=False, out=None):
 
 
 class BlockStats:
-    """GroupNorm block statistics of an NHWC bf16 activation: fp32 [N, P, C/4, 2] = (sum, sum of squares) of the stored
-    values per 4-channel block, over the pixels of partial p of the image (dxmi_conv_desc.gn_stats / dxmi_gn_block_stats).
+    """GroupNorm block statistics of an NHWC bf16 activation: fp32 [N, P, C/2, 2] = (sum, sum of squares) of the stored
+    values per channel PAIR, over the pixels of partial p of the image (dxmi_conv_desc.gn_stats / dxmi_gn_block_stats).
     Travels with the tensor it describes; `groupnorm_silu(..., stats=...)` then runs as one streaming read + write."""
 
     __slots__ = ("buf", "P")
@@ -137,12 +137,14 @@ def conv2d(x, pw, *, in1=None, bias=None, addvec=None, residual=None, stride=1, 
         if P is None:
             P = _STATS_P[key] = int(load().dxmi_conv2d_gn_stats_partials(ctypes.byref(d)))
         if P > 0:
-            stats = BlockStats(torch.empty((N, P, Cout // 4, 2), dtype=torch.float32, device=x.device), P)
+            stats = BlockStats(torch.empty((N, P, Cout // 2, 2), dtype=torch.float32, device=x.device), P)
             d.gn_stats = stats.buf.data_ptr()
     if PROFILER is not None:
         PROFILER.launch_conv(d)
     else:
         check(load().dxmi_conv2d_fwd(ctypes.byref(d), _stream()), "dxmi_conv2d_fwd")
+    if stats is not None and stats.P > MAX_APPLY_PARTIALS:
+        stats = fold_stats(stats)
     return (out, stats) if want_stats else out
 
 
@@ -346,6 +348,22 @@ def attention_bwd(qkv, do, heads, scale):
     return dqkv
 
 
+MAX_APPLY_PARTIALS = 8      # more partials per image than this are folded into one before the apply pass (dxmi_gn_stats_fold)
+
+
+def fold_stats(st, group=32):
+    """[N, P, C/2, 2] -> [N, P', C/2, 2] with P' <= MAX_APPLY_PARTIALS: `group` consecutive partials are added per thread, in
+    order; a second pass folds what is left (P > 256: the 256x256 maps of the LSUN net)."""
+    while st.P > MAX_APPLY_PARTIALS:
+        N, P, C2, _ = st.buf.shape
+        PG = (P + group - 1) // group
+        out = torch.empty((N, PG, C2, 2), dtype=torch.float32, device=st.buf.device)
+        _prof("groupnorm", "fold", 0.0, 4.0 * (st.buf.numel() + out.numel()), lambda: check(
+            load().dxmi_gn_stats_fold(_ptr(st.buf), _ptr(out), N, P, C2 * 2, group, _stream()), "dxmi_gn_stats_fold"))
+        st = BlockStats(out, PG)
+    return st
+
+
 def block_stats(x):
     """GroupNorm block statistics of an activation that has none from its producer (one read of x)."""
     _need_cuda(x)
@@ -353,26 +371,32 @@ def block_stats(x):
     assert x.dtype == torch.bfloat16 and x.is_contiguous()
     lib = load()
     P = int(lib.dxmi_gn_block_stats_partials(H * W))
-    st = BlockStats(torch.empty((N, P, C // 4, 2), dtype=torch.float32, device=x.device), P)
+    st = BlockStats(torch.empty((N, P, C // 2, 2), dtype=torch.float32, device=x.device), P)
     _prof("groupnorm", "block_stats", 0.0, 2.0 * x.numel(), lambda: check(
         lib.dxmi_gn_block_stats(_ptr(x), _ptr(st.buf), N, H * W, C, _stream()), "dxmi_gn_block_stats"))
-    return st
+    return fold_stats(st) if P > MAX_APPLY_PARTIALS else st
 
 
-def groupnorm_apply(x, st, gamma, beta, *, in1=None, st1=None, groups=32, eps=1e-6, silu=True, out=None):
-    """GroupNorm(+SiLU) of [x | in1] given their block statistics: one streaming read + write (dxmi_groupnorm_apply)."""
-    _need_cuda(x, in1, gamma, beta, out, st.buf, st1.buf if st1 is not None else None)
+def groupnorm_apply(x, st, gamma, beta, *, in1=None, st1=None, groups=32, eps=1e-6, silu=True, out=None, scale_shift=None):
+    """GroupNorm(+FiLM scale-shift)(+SiLU) of [x | in1] given their block statistics: one streaming read + write
+    (dxmi_groupnorm_apply)."""
+    _need_cuda(x, in1, gamma, beta, out, st.buf, st1.buf if st1 is not None else None, scale_shift)
     N, H, W, C0 = x.shape
     C1 = in1.shape[3] if in1 is not None else 0
+    C = C0 + C1
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and (in1 is None or (in1.is_contiguous() and st1 is not None))
-    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C0 + C1
-    assert tuple(st.buf.shape) == (N, st.P, C0 // 4, 2) and (st1 is None or tuple(st1.buf.shape) == (N, st1.P, C1 // 4, 2))
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C
+    assert tuple(st.buf.shape) == (N, st.P, C0 // 2, 2) and (st1 is None or tuple(st1.buf.shape) == (N, st1.P, C1 // 2, 2))
+    ss_ld = 0
+    if scale_shift is not None:
+        assert scale_shift.dtype == torch.float32 and scale_shift.stride(-1) == 1 and scale_shift.shape[1] == 2 * C
+        ss_ld = scale_shift.stride(0)
     if out is None:
-        out = torch.empty((N, H, W, C0 + C1), dtype=torch.bfloat16, device=x.device)
-    _prof("groupnorm", "apply", 0.0, 4.0 * N * H * W * (C0 + C1), lambda: check(
+        out = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device)
+    _prof("groupnorm", "apply", 0.0, 4.0 * N * H * W * C, lambda: check(
         load().dxmi_groupnorm_apply(_ptr(x), C0, _ptr(st.buf), st.P, _ptr(in1), C1, _ptr(st1.buf) if st1 is not None else None,
-                                    st1.P if st1 is not None else 0, _ptr(gamma), _ptr(beta), _ptr(out), N, H * W, groups,
-                                    float(eps), int(silu), _stream()), "dxmi_groupnorm_apply"))
+                                    st1.P if st1 is not None else 0, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld, _ptr(out),
+                                    N, H * W, groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_apply"))
     return out
 
 
@@ -383,10 +407,10 @@ def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, 
     _need_cuda(x, in1, gamma, beta, out, scale_shift)
     N, H, W, C0 = x.shape
     C1 = in1.shape[3] if in1 is not None else 0
-    if stats is not None and scale_shift is None and stats[0] is not None and (in1 is None or stats[1] is not None) \
-            and ((C0 + C1) // groups) % 4 == 0 and C0 % 8 == 0 and C1 % 8 == 0:
+    if stats is not None and stats[0] is not None and (in1 is None or stats[1] is not None) \
+            and ((C0 + C1) // groups) % 2 == 0 and C0 % 8 == 0 and C1 % 8 == 0:
         return groupnorm_apply(x, stats[0], gamma, beta, in1=in1, st1=stats[1] if in1 is not None else None, groups=groups,
-                               eps=eps, silu=silu, out=out)
+                               eps=eps, silu=silu, out=out, scale_shift=scale_shift)
     if scale_shift is not None or not load().dxmi_groupnorm_silu_supported(C0, C1, H * W, groups):
         return groupnorm_generic(x, gamma, beta, in1=in1, groups=groups, eps=eps, silu=silu, out=out, scale_shift=scale_shift)
     assert x.dtype == torch.bfloat16 and x.is_contiguous()

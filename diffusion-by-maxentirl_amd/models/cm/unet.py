@@ -204,9 +204,19 @@ class UNetModel(nn.Module):
         return self._packed
 
     # ------------------------------------------------------------------ fused blocks
-    def _res(self, pk, b, x0, x1, emb_all):
+    # Activations on maps of >= STREAM_GN_MIN_HW pixels travel as (tensor, BlockStats): the conv that produces a tensor writes
+    # the GroupNorm statistics of what it stores (per channel pair: the group widths of these nets are 6 ... 32 channels), so
+    # GroupNorm32 (+ scale-shift) + SiLU on them is one streaming read + write (ops.groupnorm_apply) instead of the generic
+    # statistics + apply pair.  Tensors whose producer writes none (stem, pooled / upsampled x, 1x1 proj_out, 8x8 maps) get
+    # them from one extra read (ops.block_stats) when that is cheaper than the generic path, else None = generic path.
+    STREAM_GN_MIN_HW = 256
+
+    def _stats_of(self, t):
+        return ops.block_stats(t) if t.shape[1] * t.shape[2] >= self.STREAM_GN_MIN_HW and t.shape[3] % 8 == 0 else None
+
+    def _res(self, pk, b, x0, x1, emb_all, s0=None, s1=None):
         gn1, conv1, gn2, conv2 = b.in_layers[0], b.in_layers[2], b.out_layers[0], b.out_layers[3]
-        a = ops.groupnorm_silu(x0, gn1.weight, gn1.bias, in1=x1, eps=gn1.eps, silu=True)
+        a = ops.groupnorm_silu(x0, gn1.weight, gn1.bias, in1=x1, eps=gn1.eps, silu=True, stats=(s0, s1))
         xs = x0
         if b.up:
             assert x1 is None
@@ -217,39 +227,49 @@ class UNetModel(nn.Module):
         off, eo = pk[id(b), "eoff"], b.emb_layers[1].out_features
         e = emb_all[:, off:off + eo]
         if b.use_scale_shift_norm:
-            h = ops.conv2d(a, pk[id(b), "conv1"], bias=conv1.bias, upsample=b.up)
-            a = ops.groupnorm_silu(h, gn2.weight, gn2.bias, eps=gn2.eps, silu=True, scale_shift=e)
+            h, sh = ops.conv2d(a, pk[id(b), "conv1"], bias=conv1.bias, upsample=b.up, want_stats=True)
+            a = ops.groupnorm_silu(h, gn2.weight, gn2.bias, eps=gn2.eps, silu=True, scale_shift=e, stats=(sh, None))
         else:
-            h = ops.conv2d(a, pk[id(b), "conv1"], bias=conv1.bias, upsample=b.up, addvec=e)
-            a = ops.groupnorm_silu(h, gn2.weight, gn2.bias, eps=gn2.eps, silu=True)
+            h, sh = ops.conv2d(a, pk[id(b), "conv1"], bias=conv1.bias, upsample=b.up, addvec=e, want_stats=True)
+            a = ops.groupnorm_silu(h, gn2.weight, gn2.bias, eps=gn2.eps, silu=True, stats=(sh, None))
         if (id(b), "skip") in pk:
             sk = b.skip_connection
             xs = ops.conv2d(x0, pk[id(b), "skip"], in1=x1, bias=sk.bias)
-        return ops.conv2d(a, pk[id(b), "conv2"], bias=conv2.bias, residual=xs)
+        out, so = ops.conv2d(a, pk[id(b), "conv2"], bias=conv2.bias, residual=xs, want_stats=True)
+        return out, (so if so is not None else self._stats_of(out))
 
-    def _attn(self, pk, m, x):
+    def _attn(self, pk, m, x, sx=None):
         N, H, W, C = x.shape
-        hn = ops.groupnorm_silu(x, m.norm.weight, m.norm.bias, eps=m.norm.eps, silu=False)
+        hn = ops.groupnorm_silu(x, m.norm.weight, m.norm.bias, eps=m.norm.eps, silu=False, stats=(sx, None))
         qkv = ops.conv2d(hn, pk[id(m), "qkv"], bias=m.qkv.bias)
         ch = C // m.num_heads
         a = ops.attention(qkv.view(N, H * W, 3 * C), heads=m.num_heads, scale=1.0 / math.sqrt(ch))
-        return ops.conv2d(a.view(N, H, W, C), pk[id(m), "proj"], bias=m.proj_out.bias, residual=x)
+        out = ops.conv2d(a.view(N, H, W, C), pk[id(m), "proj"], bias=m.proj_out.bias, residual=x)
+        return out, self._stats_of(out)
 
-    def _seq(self, pk, seq, h, skip, emb_all):
+    def _seq(self, pk, seq, h, skip, emb_all, sh=None, sskip=None):
+        """-> (h, BlockStats | None)"""
         for m in seq:
             if isinstance(m, ResBlock):
-                h = self._res(pk, m, h, skip, emb_all)
-                skip = None
+                h, sh = self._res(pk, m, h, skip, emb_all, s0=sh, s1=sskip)
+                skip = sskip = None
             elif isinstance(m, AttentionBlock):
-                h = self._attn(pk, m, h)
+                h, sh = self._attn(pk, m, h, sh)
             elif isinstance(m, Downsample):
-                h = ops.conv2d(h, pk[id(m), "conv"], bias=m.op.bias, stride=2, pad=1) if m.use_conv \
-                    else ops.pool_act(h, True, ops.ACT_NONE)
+                if m.use_conv:
+                    h, sh = ops.conv2d(h, pk[id(m), "conv"], bias=m.op.bias, stride=2, pad=1, want_stats=True)
+                else:
+                    h, sh = ops.pool_act(h, True, ops.ACT_NONE), None
+                sh = sh if sh is not None else self._stats_of(h)
             elif isinstance(m, Upsample):
-                h = ops.conv2d(h, pk[id(m), "conv"], bias=m.conv.bias, upsample=True) if m.use_conv else ops.upsample2x(h)
+                if m.use_conv:
+                    h, sh = ops.conv2d(h, pk[id(m), "conv"], bias=m.conv.bias, upsample=True, want_stats=True)
+                else:
+                    h, sh = ops.upsample2x(h), None
+                sh = sh if sh is not None else self._stats_of(h)
             else:
                 raise DxmiError(f"unexpected layer {type(m).__name__}")
-        return h
+        return h, sh
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, timesteps, y=None):
@@ -281,17 +301,19 @@ class UNetModel(nn.Module):
             h = ops.conv2d(x, pk["conv_in"], bias=conv_in.bias)
         else:
             h = ops.conv2d(ops.nchw_f32_to_nhwc_bf16(x), pk["conv_in"], bias=conv_in.bias)
-        hs = [h]
+        sh = self._stats_of(h)
+        hs = [(h, sh)]
         tr("input_blocks.0", h)
         for i in range(1, len(self.input_blocks)):
-            h = self._seq(pk, self.input_blocks[i], h, None, emb_all)
-            hs.append(h)
+            h, sh = self._seq(pk, self.input_blocks[i], h, None, emb_all, sh=sh)
+            hs.append((h, sh))
             tr(f"input_blocks.{i}", h)
-        h = self._seq(pk, self.middle_block, h, None, emb_all)
+        h, sh = self._seq(pk, self.middle_block, h, None, emb_all, sh=sh)
         tr("middle_block", h)
         for i, blk in enumerate(self.output_blocks):
-            h = self._seq(pk, blk, h, hs.pop(), emb_all)   # the concat is never materialised
+            skip, sskip = hs.pop()
+            h, sh = self._seq(pk, blk, h, skip, emb_all, sh=sh, sskip=sskip)   # the concat is never materialised
             tr(f"output_blocks.{i}", h)
         gn = self.out[0]
-        a = ops.groupnorm_silu(h, gn.weight, gn.bias, eps=gn.eps, silu=True)
+        a = ops.groupnorm_silu(h, gn.weight, gn.bias, eps=gn.eps, silu=True, stats=(sh, None))
         return ops.conv2d(a, pk["conv_out"], bias=self.out[2].bias, out_nchw_f32=True)

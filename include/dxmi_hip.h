@@ -82,8 +82,8 @@ typedef struct dxmi_conv_desc {
                                 after bias/residual, i.e. the LeakyReLU/ReLU derivative of a saved activation; or NULL */
     float        mask_slope;
     float*       gn_stats;   /* optional output: GroupNorm block statistics of `out` for the Normalize() that consumes it
-                                (unet_small.py:35-36,119-126): fp32 [N][P][Cout/4][2] = (sum, sum of squares) of the STORED bf16
-                                values over the pixels of partial p of the image, per block of 4 consecutive channels, summed in a
+                                (unet_small.py:35-36,119-126): fp32 [N][P][Cout/2][2] = (sum, sum of squares) of the STORED bf16
+                                values over the pixels of partial p of the image, per PAIR of consecutive channels, summed in a
                                 fixed order inside the conv's epilogue (bitwise reproducible).  P = dxmi_conv2d_gn_stats_partials(d);
                                 NULL = not wanted.  Setting it for a shape whose kernel cannot produce them is DXMI_EINVAL. */
 } dxmi_conv_desc;
@@ -181,18 +181,25 @@ int dxmi_groupnorm_silu_fwd(const void* in0, int32_t C0, const void* in1, int32_
                             int32_t apply_silu, void* stream);
 
 /* GroupNorm(+SiLU) as ONE streaming read + write, given block statistics of the input(s) (the statistics pass of
- * Normalize() is folded into whatever produced the tensor: dxmi_conv_desc.gn_stats, or dxmi_gn_block_stats):
- *   stats0 / stats1: fp32 [N][P0|P1][C0|C1 / 4][2] (sum, sum of squares per 4-channel block and partial).  Every workgroup
- *   re-reduces its image's partials in a fixed order (p outer, block inner), mean = s/cnt, var = max(q/cnt - mean^2, 0),
- *   then streams its rows: y = x*(rstd*gamma) + (beta - mean*rstd*gamma), optional SiLU, one rounding to bf16.
- * Channels per group must be a multiple of 4 (so must C0), C0 and C1 multiples of 8.  No residency limit on HW.
+ * Normalize() / GroupNorm32 is folded into whatever produced the tensor: dxmi_conv_desc.gn_stats, or dxmi_gn_block_stats):
+ *   stats0 / stats1: fp32 [N][P0|P1][C0|C1 / 2][2] (sum, sum of squares per channel pair and partial).  Every workgroup
+ *   re-reduces its image's partials in a fixed order (pair outer, partial inner), mean = s/cnt, var = max(q/cnt - mean^2, 0),
+ *   then streams its rows: y = x*(rstd*gamma) + (beta - mean*rstd*gamma), optional FiLM scale-shift
+ *   (y*(1+scale[n,c]) + shift[n,c]: scale_shift fp32 [N, ss_ld], scale at [c], shift at [C + c]; models/cm/unet.py:252-256),
+ *   optional SiLU, one rounding to bf16.
+ * Channels per group must be even, C0 and C1 multiples of 8.  No residency limit on HW.
  * dxmi_gn_block_stats: the statistics of a tensor that has no producer-side statistics: x [N,HW,C] -> stats
- *   [N][P][C/4][2] with P = dxmi_gn_block_stats_partials(HW) row chunks per image. */
+ *   [N][P][C/2][2] with P = dxmi_gn_block_stats_partials(HW) row chunks per image.
+ * dxmi_gn_stats_fold: [N][P][C/2][2] -> [N][ceil(P/group)][C/2][2], `group` consecutive partials added in order (large maps:
+ *   a conv writes one partial per 128-pixel half tile — 512 per 256x256 image — too many for every apply workgroup to
+ *   re-add); C = floats per partial (= channels). */
 int dxmi_gn_block_stats_partials(int32_t HW);
 int dxmi_gn_block_stats(const void* x, float* stats, int32_t N, int32_t HW, int32_t C, void* stream);
+int dxmi_gn_stats_fold(const float* stats, float* out, int32_t N, int32_t P, int32_t C, int32_t group, void* stream);
 int dxmi_groupnorm_apply(const void* in0, int32_t C0, const float* stats0, int32_t P0, const void* in1, int32_t C1,
-                         const float* stats1, int32_t P1, const float* gamma, const float* beta, void* out, int32_t N,
-                         int32_t HW, int32_t groups, float eps, int32_t apply_silu, void* stream);
+                         const float* stats1, int32_t P1, const float* gamma, const float* beta, const float* scale_shift,
+                         int32_t ss_ld, void* out, int32_t N, int32_t HW, int32_t groups, float eps, int32_t apply_silu,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Single-/multi-head self-attention over a fused qkv tensor, MFMA QK^T and PV with an
