@@ -313,6 +313,60 @@ inline unsigned grid_for(long total, int threads) {
     return (unsigned)b;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Output stage of the generate scripts: NCHW fp32 sampler output -> uint8 pixels, the reference's two quantisers with its
+// fp32 operation order (every intermediate rounded to fp32 where torch stores one: no fused multiply-add across them):
+//   mode 0  generate_cifar10.py:41-42,205-209 / generate_large.py:36-41 through torchvision.utils.save_image:
+//           v = (x - (-1)) / 2 ; clamp(0, 1) ; v * 255 ; + 0.5 ; clamp(0, 255) ; truncate
+//   mode 1  generate_large.py:43 (the FID / samples_N.npz array): (x + 1) * 127.5 ; clamp(0, 255) ; truncate
+// Four pixels per thread: one 16-byte load per channel plane, 12 output bytes (NHWC, C = 3) or 4 bytes per plane (NCHW).
+__device__ __forceinline__ uint32_t quant_u8(float x, int mode) {
+    float v;
+    if (mode == 0) {
+        v = __fmul_rn(__fsub_rn(x, -1.f), 0.5f);                // (x - (-1)) / 2: the division by two is exact
+        v = fminf(fmaxf(v, 0.f), 1.f);
+        v = __fadd_rn(__fmul_rn(v, 255.f), 0.5f);
+    } else {
+        v = __fmul_rn(__fadd_rn(x, 1.f), 127.5f);
+    }
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    return (uint32_t)v;                                         // truncation, as tensor.to(torch.uint8)
+}
+
+__global__ __launch_bounds__(256) void quantize_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out, int N, int C, int HW,
+                                                         int mode, int nhwc) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;       // quad of pixels
+    const int qpi = HW >> 2;
+    if (q >= (long)N * qpi) return;
+    const int n = (int)(q / qpi), p0 = (int)(q - (long)n * qpi) * 4;
+    if (nhwc && C == 3) {
+        uint32_t b[12];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)n * 3 + c) * HW + p0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e * 3 + c] = quant_u8(v[e], mode);
+        }
+        u32x4 w;      // 12 bytes = 3 dwords
+        uint32_t* o = reinterpret_cast<uint32_t*>(out + ((size_t)n * HW + p0) * 3);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) o[d] = b[4 * d] | (b[4 * d + 1] << 8) | (b[4 * d + 2] << 16) | (b[4 * d + 3] << 24);
+        (void)w;
+    } else {
+        for (int c = 0; c < C; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)n * C + c) * HW + p0);
+            if (nhwc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[((size_t)n * HW + p0 + e) * C + c] = (uint8_t)quant_u8(v[e], mode);
+            } else {
+                const uint32_t w = quant_u8(v[0], mode) | (quant_u8(v[1], mode) << 8) | (quant_u8(v[2], mode) << 16) | (quant_u8(v[3], mode) << 24);
+                *reinterpret_cast<uint32_t*>(out + ((size_t)n * C + c) * HW + p0) = w;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int dxmi_timestep_embedding(const float* t, float* out, int32_t N, int32_t dim, int32_t order,
@@ -409,6 +463,16 @@ extern "C" int dxmi_edm_step_fwd(const float* x, const float* model_out, const f
     hipLaunchKernelGGL(edm_step_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, model_out, z, sigma, sigma_down, sigma_up,
                        sample, mean, CHW, sigma_data);
     DXMI_CHECK_LAUNCH("dxmi_edm_step_fwd");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_quantize_u8(const float* x, void* out, int32_t N, int32_t C, int32_t HW, int32_t mode, int32_t out_nhwc,
+                                void* stream) {
+    DXMI_CHECK_ARG(x && out && N > 0 && C > 0 && HW > 0, "dxmi_quantize_u8: null pointer / empty shape");
+    DXMI_CHECK_ARG(HW % 4 == 0 && (mode == 0 || mode == 1), "dxmi_quantize_u8: HW (%d) must be a multiple of 4, mode 0 or 1", HW);
+    hipLaunchKernelGGL(quantize_u8_kernel, dim3(grid_for((long)N * (HW / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, (uint8_t*)out, N, C,
+                       HW, mode, out_nhwc);
+    DXMI_CHECK_LAUNCH("dxmi_quantize_u8");
     return DXMI_OK;
 }
 

@@ -599,6 +599,20 @@ def stem_conv_wgrad(x_nchw, dy):
     return dw[:, :27, 0, 0].reshape(dy.shape[3], 3, 3, 3).contiguous()
 
 
+def quantize_u8(x, mode=0, nhwc=True, out=None):
+    """Output stage: NCHW fp32 [N,C,H,W] -> uint8 [N,H,W,C] (nhwc) or [N,C,H,W]; mode 0 = rescale + save_image rounding
+    (generate_cifar10.py:205-209), mode 1 = (x + 1) * 127.5 truncated (generate_large.py:43).  Bit-exact pixel values."""
+    _need_cuda(x, out)
+    N, C, H, W = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    if out is None:
+        out = torch.empty((N, H, W, C) if nhwc else (N, C, H, W), dtype=torch.uint8, device=x.device)
+    assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() == x.numel()
+    _prof("output_stage", f"quantize{mode}", 0.0, 5.0 * x.numel(), lambda: check(
+        load().dxmi_quantize_u8(_ptr(x), _ptr(out), N, C, H * W, mode, int(nhwc), _stream()), "dxmi_quantize_u8"))
+    return out
+
+
 def nchw_f32_to_nhwc_bf16(x, out=None):
     _need_cuda(x, out)
     N, C, H, W = x.shape

@@ -101,8 +101,8 @@ def main():
 
     n_batches = int(args.n_generate / args.batchsize / world)
     i_img = 0
-    from concurrent.futures import ThreadPoolExecutor
-    png_pool, pending = ThreadPoolExecutor(max_workers=8), []
+    from utils import ImageWriter
+    writer = ImageWriter()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n_batches):
@@ -112,13 +112,12 @@ def main():
             else:
                 d_sample = sampler.sample(args.batchsize, device=device)
         if args.save_images:
-            # quantise on the device, one device->host copy per batch, PNGs from a thread pool
-            u8 = to_uint8_nhwc(rescale(d_sample["sample"]).clamp(0, 1))
-            pending += write_png_batch(u8, [os.path.join(output_path, f"{local_rank}_{i_img + k}.png") for k in range(len(u8))], pool=png_pool)
-            i_img += len(u8)
-    for f in pending:
-        f.result()
-    png_pool.shutdown()
+            # rescale -> clamp -> save_image rounding on the device (dxmi_quantize_u8), pinned double-buffered copy on a side
+            # stream, PNGs from a thread pool: the sampler never waits for the files
+            n = d_sample["sample"].shape[0]
+            writer.submit(d_sample["sample"], [os.path.join(output_path, f"{local_rank}_{i_img + k}.png") for k in range(n)])
+            i_img += n
+    writer.close()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:

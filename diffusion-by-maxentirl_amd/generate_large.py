@@ -82,8 +82,9 @@ def main():
 
     n_batches = int(args.n_sample / args.batchsize / world)
     l_sample, i_img = [], 0
-    from concurrent.futures import ThreadPoolExecutor
-    png_pool, pending = ThreadPoolExecutor(max_workers=8), []
+    from dxmi_hip import ops
+    from utils import ImageWriter
+    writer = ImageWriter()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n_batches):
@@ -93,14 +94,12 @@ def main():
             d_sample = sampler.sample(args.batchsize, device=device, i_class=None, enable_grad=False)
         sample = d_sample["sample"]
         if args.skip_fid:
-            u8 = to_uint8_nhwc(((sample + 1) / 2).clamp(0, 1))
-            pending += write_png_batch(u8, [os.path.join(output_path, f"{local_rank}_{i_img + k}.png") for k in range(len(u8))], pool=png_pool)
-            i_img += len(u8)
+            # ((sample + 1) / 2).clamp(0, 1) -> save_image (:36-41) on the device, pinned copy on a side stream, PNG thread pool
+            writer.submit(sample, [os.path.join(output_path, f"{local_rank}_{i_img + k}.png") for k in range(len(sample))])
+            i_img += len(sample)
         else:
-            l_sample.append(((sample + 1) * 127.5).clamp(0, 255).to(torch.uint8))
-    for f in pending:
-        f.result()
-    png_pool.shutdown()
+            l_sample.append(ops.quantize_u8(sample.contiguous().float(), mode=1, nhwc=False))      # ((x + 1) * 127.5).clamp.to(uint8), :43
+    writer.close()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print0(f"generated {n_batches * args.batchsize} images/rank x {world} ranks, "

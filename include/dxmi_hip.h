@@ -298,6 +298,15 @@ int dxmi_edm_step_fwd(const float* x, const float* model_out, const float* z, co
  * (dxmi_conv2d_wgrad with ksize 1). */
 int dxmi_im2col27(const float* x, void* out, int32_t N, int32_t H, int32_t W, void* stream);
 
+/* Output stage of generate_cifar10.py / generate_large.py: NCHW fp32 sampler output -> uint8 pixels (NHWC when out_nhwc,
+ * else NCHW), the reference's fp32 operation order, no fused multiply-add between its steps (bit-exact pixel values):
+ *   mode 0: v = (x - (-1)) / 2 -> clamp(0,1) -> * 255 -> + 0.5 -> clamp(0,255) -> truncate
+ *           (rescale(), generate_cifar10.py:41-42 and :205-209; generate_large.py:36-41; torchvision.utils.save_image)
+ *   mode 1: (x + 1) * 127.5 -> clamp(0,255) -> truncate   (the FID / samples_N.npz array, generate_large.py:43)
+ * HW must be a multiple of 4. */
+int dxmi_quantize_u8(const float* x, void* out, int32_t N, int32_t C, int32_t HW, int32_t mode, int32_t out_nhwc,
+                     void* stream);
+
 /* Layout converters at the network edge. */
 int dxmi_nchw_f32_to_nhwc_bf16(const float* in, void* out, int32_t N, int32_t C, int32_t HW,
                                void* stream);

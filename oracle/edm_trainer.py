@@ -111,7 +111,9 @@ class OracleDxMICond:
             logs[f"adavelreg/beta{t}_"] = b.item()
         return logs
 
-    def update_sampler_mixed_precision(self, buf):
+    def update_sampler_mixed_precision(self, buf, record=None):
+        """record: optional list receiving, per optimiser step, {name: unscaled gradient} (what opt.step() sees after
+        fp16_util.py:204-223 has divided by 2^lg_loss_scale)."""
         permutation = torch.randperm(buf["state"].shape[0])
         B = self.B
         for m in range(0, len(permutation), B):
@@ -130,6 +132,8 @@ class OracleDxMICond:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
                 p.grad.mul_(1.0 / (2 ** self.lg_loss_scale))
+            if record is not None:
+                record.append({k: p.grad.detach().clone() for k, p in self.net.items()})
             self.opt.step()
             self.lg_loss_scale += 1e-3
             for p in self.val.values():

@@ -400,16 +400,50 @@ def gen_edm_trainer():
     buf = ref_tr.append_buffer(ref_tr.reset_buffer("cpu"), d_sample)
     w0 = {k: p.detach().clone() for k, p in net.named_parameters()}
     d_energy = trainer.update_f_v(img, d_sample, buf, y=y)
+    # the UNSCALED master gradients the optimiser sees (fp16_util.py:204-223: model grads -> flat masters -> / 2^lg_loss_scale
+    # -> opt.step()), recorded at every optimiser step of the policy loop for tensors spread over the depth of the net
+    names = [k for k, _ in net.named_parameters()]
+    want = ["input_blocks.0.0.weight", "input_blocks.1.0.in_layers.2.weight", "input_blocks.1.0.out_layers.3.weight",
+            "input_blocks.1.0.emb_layers.1.weight", "middle_block.0.in_layers.2.weight", "middle_block.1.qkv.weight",
+            "middle_block.1.proj_out.weight", "middle_block.2.out_layers.0.weight", "output_blocks.0.0.in_layers.2.weight",
+            "output_blocks.0.0.skip_connection.weight", "out.0.weight", "out.2.weight", "time_embed.0.weight", "label_emb.weight",
+            "log_betas"]
+    gpick = [k for k in want if k in names]
+    assert len(gpick) >= 12, gpick
+    recorded = []
+    orig_step = opt.step
+
+    def rec_step(*a, **k):
+        flat = {}
+        for (group, _shape), master in zip(mp.param_groups_and_shapes, mp.master_params):
+            off = 0
+            gflat = master.grad.detach().view(-1)
+            for name, prm in group:
+                n = prm.numel()
+                if name in gpick:
+                    flat[name] = gflat[off:off + n].view(prm.shape).clone()
+                off += n
+        recorded.append(flat)
+        return orig_step(*a, **k)
+    opt.step = rec_step
     d_sampler = trainer.update_sampler_mixed_precision(buf, mp_trainer=mp)
+    opt.step = orig_step
+    assert len(recorded) >= 2
     nsd = dict(net.named_parameters())
     pick = ["out.2.weight", "input_blocks.1.0.in_layers.2.weight", "middle_block.1.qkv.weight", "input_blocks.1.0.emb_layers.1.bias",
             "label_emb.weight", "time_embed.2.weight"]
+    grads = {}
+    for which, rec in (("first", recorded[0]), ("last", recorded[-1])):
+        for i, k in enumerate(gpick):
+            t = rec[k]
+            grads[f"mgrad_{which}_{i}"] = t if t.numel() <= 40000 else t.reshape(t.shape[0], -1)[:max(1, 40000 // t[0].numel())]
     save("edm_trainer_step", seed=seed, B=B, T=T, img=img, y=y,
          energy_keys=np.array(list(d_energy.keys())), energy_vals=np.array(list(d_energy.values()), dtype=np.float64),
          sampler_keys=np.array(list(d_sampler.keys())), sampler_vals=np.array(list(d_sampler.values()), dtype=np.float64),
          betas_for_q=trainer.betas_for_q, buffer_timestep=buf["timestep"], buffer_y=buf["y"], buffer_state_sum=buf["state"].double().sum(),
          lg_loss_scale_after=np.float64(mp.lg_loss_scale), log_betas_after=nsd["log_betas"].detach(),
-         delta_keys=np.array(pick), **{f"delta_{i}": (nsd[k].detach() - w0[k]) for i, k in enumerate(pick)})
+         delta_keys=np.array(pick), **{f"delta_{i}": (nsd[k].detach() - w0[k]) for i, k in enumerate(pick)},
+         mgrad_keys=np.array(gpick), n_opt_steps=np.int64(len(recorded)), **grads)
 
 
 GENS = {"schedule": gen_schedule, "unet": gen_unet_forward, "var_sampling": gen_var_sampling,
