@@ -532,6 +532,41 @@ def linear(x, pw, bias=None, pre_act=ACT_NONE, post_act=ACT_NONE, out=None):
     return out
 
 
+def _rows_as_map(t_f32, rows_pad):
+    """fp32 [P, K] -> bf16 [1, rows_pad / 16, 16, K] (zero rows appended): the pixel-GEMM operand form of a dense layer's rows."""
+    P, K = t_f32.shape
+    out = torch.zeros((rows_pad, K), dtype=torch.bfloat16, device=t_f32.device)
+    out[:P] = t_f32
+    return out.view(1, rows_pad // 16, 16, K)
+
+
+def linear_bwd(x, dy, pw_t, need_dx=True):
+    """Backward of y = x @ W^T + b for the small dense layers of the embedding graphs (temb MLP, temb_proj / emb_layers,
+    reference unet_small.py:296-299,123 and models/cm/unet.py:775-779,249) on the HIP kernels — no BLAS library call:
+      dx = dy @ W            dxmi_linear_fwd on the transposed pack (pw_t = pack_conv_weight(W, transpose_flip=True))
+      dW = dy^T @ x          dxmi_conv2d_wgrad with ksize 1: the rows are the 'pixels' of a 1x1 conv (zero rows pad the count)
+      db = column sums of dy
+    x [P, K], dy [P, M] fp32 (K, M multiples of 64) -> (dx [P, K] | None, dW [M, K], db [M]) fp32; bf16 MFMA operands as the
+    forward's."""
+    _need_cuda(x, dy)
+    P, K = x.shape
+    M = dy.shape[1]
+    assert dy.shape[0] == P and x.dtype == torch.float32 and dy.dtype == torch.float32
+    dy = dy.contiguous()
+    dx = linear(dy, pw_t) if need_dx else None
+    rows = 64
+    while rows < P:
+        rows *= 2
+    dw = conv2d_wgrad(_rows_as_map(x, rows), _rows_as_map(dy, rows), 1)          # [M, K, 1, 1]
+    return dx, dw.view(M, K), dy.sum(0)
+
+
+def silu_bwd(pre, g):
+    """g * d/dpre [pre * sigmoid(pre)] (elementwise, fp32)."""
+    sg = torch.sigmoid(pre)
+    return g * (sg * (1 + pre * (1 - sg)))
+
+
 def var_gather_sched(t, continuous_steps, xmul_tab, cmul_tab, log_betas_all, sigma_out=None):
     _need_cuda(t, continuous_steps, xmul_tab, cmul_tab, log_betas_all, sigma_out)
     assert t.dtype == torch.int64

@@ -252,18 +252,27 @@ class _UNetFn(torch.autograd.Function):
                 pkt["conv_in_t"] = ops.pack_conv_weight(net.conv_in.weight, transpose_flip=True)
             dx = ops.conv2d(g, pkt["conv_in_t"], out_nchw_f32=True)
 
-        # ---- temb MLP + all temb_proj layers: tiny dense graph, re-evaluated in fp32 with torch autograd
+        # ---- temb MLP + all temb_proj layers (reference unet_small.py:296-299, :123): dense backward on the HIP kernels
+        # (ops.linear_bwd: transposed-pack linear for dx, the 1x1 weight-gradient kernel for dW), pre-activations recomputed
         blocks = list(net._resblocks())
-        leaves = [net.temb.dense[0].weight, net.temb.dense[0].bias, net.temb.dense[1].weight, net.temb.dense[1].bias]
-        leaves += [b.temb_proj.weight for b in blocks] + [b.temb_proj.bias for b in blocks]
-        with torch.enable_grad():
-            lv = [p.detach().requires_grad_(True) for p in leaves]
-            nb = len(blocks)
-            s = F.silu(F.linear(F.silu(F.linear(ctx.emb, lv[0], lv[1])), lv[2], lv[3]))
-            tp = F.linear(s, torch.cat(lv[4:4 + nb], 0), torch.cat(lv[4 + nb:], 0))
-            gl = torch.autograd.grad(tp, lv, grad_outputs=d_tp)
-        for p, gp in zip(leaves, gl):
-            grads[p] = gp
+        d0, d1 = net.temb.dense
+        e0 = ops.linear(ctx.emb, pk["dense0"], d0.bias)                        # pre-activation of dense[0]
+        a0 = F.silu(e0)
+        e1 = ops.linear(a0, pk["dense1"], d1.bias)
+        s_t = F.silu(e1)
+        if "tproj_t" not in pkt:
+            pkt["tproj_t"] = ops.pack_conv_weight(torch.cat([b.temb_proj.weight for b in blocks], 0), transpose_flip=True)
+            pkt["dense1_t"] = ops.pack_conv_weight(d1.weight, transpose_flip=True)
+        ds, dw_cat, db_cat = ops.linear_bwd(s_t, d_tp, pkt["tproj_t"])
+        off = 0
+        for b in blocks:
+            grads[b.temb_proj.weight] = dw_cat[off:off + b.out_channels]
+            grads[b.temb_proj.bias] = db_cat[off:off + b.out_channels]
+            off += b.out_channels
+        de1 = ops.silu_bwd(e1, ds)
+        da0, grads[d1.weight], grads[d1.bias] = ops.linear_bwd(a0, de1, pkt["dense1_t"])
+        de0 = ops.silu_bwd(e0, da0)
+        _, grads[d0.weight], grads[d0.bias] = ops.linear_bwd(ctx.emb, de0, None, need_dx=False)
 
         out = [None, dx, None]
         for prm in net.parameters():

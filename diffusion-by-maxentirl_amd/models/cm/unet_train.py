@@ -275,23 +275,32 @@ class _EDMUNetFn(torch.autograd.Function):
                 pkt["conv_in_t"] = ops.pack_conv_weight(conv_in.weight, transpose_flip=True)
             dx = ops.conv2d(g, pkt["conv_in_t"], out_nchw_f32=True)
 
-        # ---- embedding graph: time_embed MLP, label embedding, every emb_layers Linear (tiny; torch fp32 autograd)
+        # ---- embedding graph (models/cm/unet.py:775-779, :249): time_embed MLP, label embedding, every emb_layers Linear as one
+        # operator — dense backward on the HIP kernels (ops.linear_bwd), pre-activations recomputed
         blocks = [m for m in net.modules() if isinstance(m, ResBlock)]
-        leaves = [net.time_embed[0].weight, net.time_embed[0].bias, net.time_embed[2].weight, net.time_embed[2].bias]
+        l0, l2 = net.time_embed[0], net.time_embed[2]
+        e0 = ops.linear(ctx.sinus, pk["te0"], l0.bias)
+        a0 = F.silu(e0)
+        emb = ops.linear(a0, pk["te2"], l2.bias)
         if net.num_classes is not None:
-            leaves.append(net.label_emb.weight)
-        nfix = len(leaves)
-        leaves += [b.emb_layers[1].weight for b in blocks] + [b.emb_layers[1].bias for b in blocks]
-        with torch.enable_grad():
-            lv = [p.detach().requires_grad_(True) for p in leaves]
-            emb = F.linear(F.silu(F.linear(ctx.sinus, lv[0], lv[1])), lv[2], lv[3])
-            if net.num_classes is not None:
-                emb = emb + F.embedding(ctx.y, lv[4])
-            nb = len(blocks)
-            ea = F.linear(F.silu(emb), torch.cat(lv[nfix:nfix + nb], 0), torch.cat(lv[nfix + nb:], 0))
-            gl = torch.autograd.grad(ea, lv, grad_outputs=d_emb_all)
-        for p, gp in zip(leaves, gl):
-            grads[p] = gp
+            emb = emb + net.label_emb.weight.detach()[ctx.y]
+        s_e = F.silu(emb)
+        if "emb_t" not in pkt:
+            pkt["emb_t"] = ops.pack_conv_weight(torch.cat([b.emb_layers[1].weight for b in blocks], 0), transpose_flip=True)
+            pkt["te2_t"] = ops.pack_conv_weight(l2.weight, transpose_flip=True)
+        ds, dw_cat, db_cat = ops.linear_bwd(s_e, d_emb_all, pkt["emb_t"])
+        off = 0
+        for b in blocks:
+            eo = b.emb_layers[1].out_features
+            grads[b.emb_layers[1].weight] = dw_cat[off:off + eo]
+            grads[b.emb_layers[1].bias] = db_cat[off:off + eo]
+            off += eo
+        d_emb = ops.silu_bwd(emb, ds)
+        if net.num_classes is not None:
+            grads[net.label_emb.weight] = torch.zeros_like(net.label_emb.weight).index_add_(0, ctx.y, d_emb)
+        da0, grads[l2.weight], grads[l2.bias] = ops.linear_bwd(a0, d_emb, pkt["te2_t"])
+        de0 = ops.silu_bwd(e0, da0)
+        _, grads[l0.weight], grads[l0.bias] = ops.linear_bwd(ctx.sinus, de0, None, need_dx=False)
 
         out = [None, dx, None, None]
         for prm in net.parameters():

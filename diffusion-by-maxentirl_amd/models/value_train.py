@@ -68,7 +68,7 @@ class _ValueNetFn(torch.autograd.Function):
             grads[net.linear.weight] = (dy_pre[:, None] * s).sum(0, keepdim=True)
             grads[net.linear.bias] = dy_pre.sum().reshape(1)
         if dw and net.learn_out_scale:
-            y_pre = s @ w + net.linear.bias
+            y_pre = (s * w).sum(1) + net.linear.bias         # [N, C] x [C]: elementwise + row sums (no BLAS call)
             grads[net.out_scale.weight] = (dy * y_pre).sum().reshape(1, 1)
             grads[net.out_scale.bias] = dy.sum().reshape(1)
         # dfeat is the gradient w.r.t. the last block's OUTPUT (post LeakyReLU)

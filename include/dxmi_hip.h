@@ -17,6 +17,10 @@
  *     every launch is asynchronous on it, so all calls are hipGraph-capturable.
  *   - activations between kernels: NHWC bf16.  Sampler state / network edges: NCHW fp32.
  *   - no exceptions cross the boundary; functions are re-entrant.
+ *   - NOT in this header: the gradient exchange of the data-parallel train step (reference: torch DDP wrappers,
+ *     train_cifar10.py:298-309).  The host stays PyTorch, so the collectives are issued through torch.distributed with the
+ *     "nccl" backend (= RCCL on ROCm) by dxmi_hip/dist.py (FlatGradSync: persistent flat buffer, ~32 MB buckets all-reduced
+ *     during the backward); this library only produces the gradients those buckets carry.  Generation needs no collective.
  */
 #ifndef DXMI_HIP_H
 #define DXMI_HIP_H

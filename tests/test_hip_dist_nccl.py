@@ -33,3 +33,23 @@ def test_trainer_step_under_rccl():
     assert line["backend"] == "nccl" and line["world"] == world
     assert line["rank_identical_parameters"] and line["finite"]
     assert line["flat_bytes"][0] == 5_134_595 * 4 and line["flat_bytes"][1] == (35_746_307 + 4) * 4
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_over_visible_gpus():
+    """`python bench.py --gpus N` through its self-launch path (fresh rank processes, RCCL process group, barrier +
+    max-over-ranks timing) with N = every visible GPU (1 on the driver's test box): one JSON line from rank 0 with the
+    whole-job rate and the train leg."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "2", "--warmup", "1", "--train-steps", "1",
+                        "--no-cpu-baseline", "--no-eager-reference", "--no-edm", "--no-events"], cwd=root, capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert line["n_gpus"] == n and line["steps"] == 2 and line["value"] > 0 and line["train_steps_per_sec"] > 0
+    assert line["scaling"] == "weak" and line["config"]["images_per_gpu_per_step"] == 256
