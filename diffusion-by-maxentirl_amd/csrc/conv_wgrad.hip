@@ -220,6 +220,178 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 3: the same 64 co x 64 ci x all-taps block per workgroup, WAVE-SPECIALISED: waves 0-3 run the MFMAs and never touch
+// global memory, waves 4-7 bring the tiles into LDS by DMA (`global_load_lds`: no staging registers, no ds_write pass) —
+// a DMA costs its wave ~190 cycles of issue (tools/dma_probe.hip), so the version of this kernel whose compute waves issued
+// their own ~11 DMAs per tile measured 1.5x SLOWER than the register-staged kernel above, while four dedicated loaders need
+// 11 x 190 = 2 100 cycles per tile against the tile's 2 304 cycles of MFMAs.
+//   * double-buffered, unpadded tile images: a pixel row is 128 B (64 channels); 16-byte slot j of row R sits at slot
+//     j ^ ((R & 2) << 1): the four rows x 64 B a 32-lane group of a transposing read touches then fall into four different
+//     quarter-sets of the banks for ANY four consecutive rows (a DMA writes 1 KiB linearly: no padding; source addresses are free);
+//   * a 1-KiB piece = 8 pixel rows; loader l moves pieces l, l + 4, ... of the dY tile (16 pieces) and of the X halo tile
+//     (<= 32): per lane the tile-relative source offset and border flags of its pieces are formed once per kernel, per tile the
+//     plan is a few scalar operations;
+//   * ONE barrier per tile: the loaders issue tile i + 1 right behind barrier i, wait for it (vmcnt(0)) and meet the MFMA
+//     waves at barrier i + 1;
+//   * MFMA waves: the transposing reads run four (k-step, tap) pairs ahead of the MFMAs through a rolling window of fragments
+//     (the double-buffered k-step of the kernel above needs 368 registers; eight waves per CU leave 256).
+// Scope: stride 1 (optionally nearest x2 upsampled input), tile rows of >= 8 pixels (maps >= 8x8); other shapes: the kernel above.
+#define WG_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define WG_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
+__device__ uint4 wg_zero16 = {0u, 0u, 0u, 0u};
+
+template <int KS>
+__global__ __launch_bounds__(512) void conv_wgrad_ws_kernel(WgradArgs p, const char* __restrict__ zero_page, int xpieces, int buf_bytes) {
+    constexpr int TAPS = KS * KS;
+    constexpr int TP = 128;
+    constexpr int DYB = TP * 128;          // dY tile bytes
+    constexpr int MAXXP = 8;               // X pieces per loader
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int cib = b % p.CIB; b /= p.CIB;
+    const int cob = b % p.COB; b /= p.COB;
+    const int split = b;
+    const int TW = 1 << p.TWl, TH = 1 << p.THl;
+    const int txn = p.OW >> p.TWl, tyn = p.OH >> p.THl;
+    const int ci0 = cib * 64, co0 = cob * 64;
+    const int ntile = split < p.PT ? (p.PT - 1 - split) / p.S + 1 : 0;      // tiles of this split
+
+    if (wave >= 4) {
+        // ============================================================ loaders
+        const int l = wave - 4;
+        const int HHW = p.HH * p.HWd, HPX = p.SUBS * HHW;
+        const bool first = ci0 < p.C0;
+        const bf16* const xsrc = (first ? p.x0 : p.x1) + (first ? ci0 : ci0 - p.C0);
+        const int Cs = first ? p.C0 : p.C1;
+        const bf16* const dysrc = p.dy + co0;
+        // row (lane >> 3) of a piece, LDS slot (lane & 7) holds channel piece slot ^ ((R & 2) << 1)
+        const int prow = lane >> 3, pslot = lane & 7;
+        int dy_rel[4], dy_sub[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int R = (l + 4 * k) * 8 + prow;                        // tile pixel
+            const int x = R & (TW - 1), y = (R >> p.TWl) & (TH - 1);
+            dy_sub[k] = R >> (p.TWl + p.THl);
+            dy_rel[k] = (((dy_sub[k] * p.OH + y) * p.OW + x) * p.Cout + ((pslot ^ ((R & 2) << 1)) << 3)) * 2;     // bytes
+        }
+        int x_rel[MAXXP];
+        unsigned x_flag[MAXXP];   // bits 0..3: row above / below / left / right of the tile, bit 4: beyond the halo image; bits 8..: sub-image
+#pragma unroll
+        for (int k = 0; k < MAXXP; ++k) {
+            const int R = (l + 4 * k) * 8 + prow;                        // halo pixel
+            const int sub = R / HHW, rem = R - sub * HHW;
+            const int hy = rem / p.HWd, hx = rem - hy * p.HWd;
+            const int dyy = hy - p.pad, dxx = hx - p.pad;                // offset from the tile origin in (upsampled) input pixels
+            x_rel[k] = (((sub * p.IH + (dyy >> p.ups)) * p.IW + (dxx >> p.ups)) * Cs + ((pslot ^ ((R & 2) << 1)) << 3)) * 2;
+            x_flag[k] = (unsigned)(dyy < 0) | ((unsigned)(dyy >= TH) << 1) | ((unsigned)(dxx < 0) << 2) | ((unsigned)(dxx >= TW) << 3) |
+                        ((unsigned)(R >= HPX) << 4) | ((unsigned)sub << 8);
+        }
+        const int nxw = (xpieces - l + 3) >> 2;                          // X pieces of this loader
+        auto issue_tile = [&](int pt, char* buf) {
+            const int tx = pt % txn, ty = (pt / txn) % tyn;
+            const int n0 = (pt / (txn * tyn)) * p.SUBS;
+            const int oy0 = ty << p.THl, ox0 = tx << p.TWl;
+            const char* const yb = reinterpret_cast<const char*>(dysrc + ((size_t)(n0 * p.OH + oy0) * p.OW + ox0) * p.Cout);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const char* src = n0 + dy_sub[k] < p.N ? yb + dy_rel[k] : zero_page;
+                __builtin_amdgcn_global_load_lds(WG_GPTR(src), WG_LPTR(buf + (l + 4 * k) * 1024), 16, 0, 0);
+            }
+            // border bits of this tile: rows above the map / below / left / right are zero padding
+            const unsigned edge = (unsigned)(oy0 == 0) | ((unsigned)(oy0 + TH == p.OH) << 1) | ((unsigned)(ox0 == 0) << 2) | ((unsigned)(ox0 + TW == p.OW) << 3) | 16u;
+            const char* const xb = reinterpret_cast<const char*>(xsrc + ((size_t)(n0 * p.IH + (oy0 >> p.ups)) * p.IW + (ox0 >> p.ups)) * Cs);
+#pragma unroll
+            for (int k = 0; k < MAXXP; ++k) {
+                if (k < nxw) {
+                    const char* src = ((x_flag[k] & edge & 31u) || n0 + (int)(x_flag[k] >> 8) >= p.N) ? zero_page : xb + x_rel[k];
+                    __builtin_amdgcn_global_load_lds(WG_GPTR(src), WG_LPTR(buf + DYB + (l + 4 * k) * 1024), 16, 0, 0);
+                }
+            }
+        };
+        if (ntile > 0) issue_tile(split, smem);
+        for (int it = 0; it < ntile; ++it) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                // B_it: tile it landed; the MFMA waves are done with tile it - 1
+            if (it + 1 < ntile) issue_tile(split + (it + 1) * p.S, smem + ((it + 1) & 1) * buf_bytes);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ================================================================ MFMA waves: 32 co x 32 ci x all taps each
+    const int wr = wave >> 1, wc = wave & 1;
+    const int Cin = p.C0 + p.C1;
+    // tr-read lane roles (see the kernel above)
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int ch_off = (16 * (g & 1) + 4 * pp) * 2;
+    const int krow = 8 * (g >> 1) + q;
+    // swizzled address of (row R, byte hc < 128 of the row): (R * 128 + hc) ^ ((R & 2) << 5)
+    auto saddr = [&](int R, int hc) -> int { return ((R << 7) + hc) ^ ((R & 2) << 5); };
+
+    f32x16 acc[TAPS];
+    float bsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int trow[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) trow[t] = (t / KS) * p.HWd + (t % KS);
+
+    constexpr int NK = TP / 16, STEPS = NK * TAPS, AH = TAPS > 1 ? 4 : 2, WIN = AH + 1;
+    constexpr int NA = TAPS > 1 ? 2 : 3;     // A fragments in flight: the one in use + those read ahead (1x1: every step has its own)
+    for (int it = 0; it < ntile; ++it) {
+        const char* const ydy = smem + (it & 1) * buf_bytes;
+        const char* const xim = ydy + DYB;
+        __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): this wave's reads of the previous tile are complete
+        __builtin_amdgcn_s_barrier();                    // B_it
+        if (p.bpart && cib == 0) {   // bias gradient rides along: this workgroup's 64 couts x 128 staged pixels
+            const int col = tid & 63, part = tid >> 6;
+#pragma unroll 8
+            for (int px = part * 32; px < part * 32 + 32; ++px) bsum += (float)*reinterpret_cast<const bf16*>(ydy + saddr(px, col * 2));
+        }
+        // flattened (k-step, tap) sequence: fragment i = kb * TAPS + t; reads run AH fragments ahead of the MFMAs
+        bf16x8 afr[NA], bwin[WIN];
+        int hr0 = 0;
+        auto read_frag = [&](int i) {
+            const int kb = i / TAPS, t = i % TAPS;
+            if (t == 0) {
+                const int plo = kb * 16 + krow;
+                const char* al = ydy + saddr(plo, wr * 64 + ch_off);
+                afr[kb % NA] = tr_frag(al, al + 512);                    // rows plo, plo + 4: same swizzle bit
+                const int xl = plo & (TW - 1), yl = (plo >> p.TWl) & (TH - 1), sl = plo >> (p.TWl + p.THl);
+                hr0 = (sl * p.HH + yl) * p.HWd + xl;                     // halo row of tap (0, 0); tile rows >= 8 pixels: plo + 4 is hr0 + 4
+            }
+            const char* bl = xim + saddr(hr0 + trow[t], wc * 64 + ch_off);
+            bwin[i % WIN] = tr_frag(bl, bl + 512);
+        };
+#pragma unroll
+        for (int i = 0; i < AH; ++i) read_frag(i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < STEPS; ++i) {
+            if (i + AH < STEPS) read_frag(i + AH);
+            acc[i % TAPS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[(i / TAPS) % NA], bwin[i % WIN], acc[i % TAPS], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (p.bpart && cib == 0) p.bpart[((size_t)split * 4 + (tid >> 6)) * p.Cout + co0 + (tid & 63)] = bsum;
+    const int h = lane >> 5;
+    float* pb = p.partial + (size_t)split * TAPS * p.Cout * Cin;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int ci = ci0 + wc * 32 + (lane & 31);
+            pb[((size_t)t * p.Cout + co) * Cin + ci] = acc[t][r];
+        }
+}
+
 // sum the S partials in a fixed order -> OIHW fp32 gradient (optionally accumulated)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S, int taps, int Cout,
                                     int Cin, int accumulate) {
@@ -345,7 +517,33 @@ static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, co
         if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<KS_, PF_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
         hipLaunchKernelGGL((conv_wgrad_kernel<KS_, PF_>), grid, block, lds, st, a);                                            \
     } while (0)
-    if (ksize == 3) { if (pf) DXMI_WG_LAUNCH(3, true); else DXMI_WG_LAUNCH(3, false); }
+    // wave-specialised DMA-staged kernel: stride 1, tile rows of >= 8 pixels, halo tile of <= 32 one-KiB pieces
+    static const int dma_env = getenv("DXMI_WGRAD_DMA") ? atoi(getenv("DXMI_WGRAD_DMA")) : 1;     // 0: register-staged kernels only
+    const int hpx = a.SUBS * a.HH * a.HWd;
+    const int xpieces = (hpx + 7) / 8;
+    const bool dma = dma_env && stride == 1 && TW >= 8 && xpieces <= 32 && (long)N * IH * IW * (C0 > C1 ? C0 : C1) * 2 < (1L << 31) &&
+                     (long)N * OH * OW * Cout * 2 < (1L << 31);
+    if (dma) {
+        static const void* zero_page = nullptr;
+        if (!zero_page) {
+            void* zp = nullptr;
+            if (hipGetSymbolAddress(&zp, HIP_SYMBOL(wg_zero16)) != hipSuccess || !zp) {
+                dxmi_set_error("dxmi_conv2d_wgrad: hipGetSymbolAddress(wg_zero16) failed");
+                return DXMI_EINVAL;
+            }
+            zero_page = zp;
+        }
+        const int buf_bytes = 128 * 128 + xpieces * 1024;
+        const size_t lds2 = 2 * (size_t)buf_bytes;
+#define DXMI_WG_DMA(KS_)                                                                                                       \
+    do {                                                                                                                      \
+        static bool attr = false;                                                                                             \
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_ws_kernel<KS_>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((conv_wgrad_ws_kernel<KS_>), grid, dim3(512), lds2, st, a, (const char*)zero_page, xpieces, buf_bytes);    \
+    } while (0)
+        if (ksize == 3) DXMI_WG_DMA(3); else DXMI_WG_DMA(1);
+#undef DXMI_WG_DMA
+    } else if (ksize == 3) { if (pf) DXMI_WG_LAUNCH(3, true); else DXMI_WG_LAUNCH(3, false); }
     else { if (pf) DXMI_WG_LAUNCH(1, true); else DXMI_WG_LAUNCH(1, false); }
 #undef DXMI_WG_LAUNCH
     DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad");
