@@ -392,20 +392,40 @@ __global__ __launch_bounds__(512) void conv_wgrad_ws_kernel(WgradArgs p, const c
         }
 }
 
-// sum the S partials in a fixed order -> OIHW fp32 gradient (optionally accumulated)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S, int taps, int Cout,
-                                    int Cin, int accumulate) {
+// sum the S partials in a fixed order -> OIHW fp32 gradient (optionally accumulated).  Four consecutive ci per thread (16-byte
+// loads of every partial); the trailing blocks of the same launch fold the bias-gradient partials (bpart [S*4][Cout]) in a
+// fixed order too, so a weight gradient with bias is two launches, not three.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S, int taps, int Cout,
+                                                           int Cin, int accumulate, const float* __restrict__ bpart, float* __restrict__ dbias,
+                                                           int wblocks) {
+    if ((int)blockIdx.x >= wblocks) {
+        // bias: one thread per cout, S * 4 partial rows
+        const int co = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
+        if (co < Cout) {
+            float t = 0.f;
+            for (int k = 0; k < S * 4; ++k) t += bpart[(size_t)k * Cout + co];
+            dbias[co] = accumulate ? dbias[co] + t : t;
+        }
+        return;
+    }
     const long total = (long)taps * Cout * Cin;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (idx >= total) return;
-    float s = 0.f;
-    for (int k = 0; k < S; ++k) s += partial[(size_t)k * total + idx];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < S; ++k) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (size_t)k * total + idx);
+        s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
     const int ci = idx % Cin;
     const long r = idx / Cin;
     const int co = r % Cout;
     const int t = (int)(r / Cout);
-    const long o = ((long)co * Cin + ci) * taps + t;
-    dw[o] = accumulate ? dw[o] + s : s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const long o = ((long)co * Cin + ci + e) * taps + t;
+        dw[o] = accumulate ? dw[o] + s[e] : s[e];
+    }
 }
 
 // column sums of a [P][C] bf16 matrix -> fp32 [C] (bias gradient); fixed-order two-level reduction
@@ -548,14 +568,11 @@ static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, co
 #undef DXMI_WG_LAUNCH
     DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad");
     const long total = (long)ksize * ksize * Cout * Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)workspace,
-                       dw_oihw, S, ksize * ksize, Cout, Cin, accumulate);
+    const int wblocks = (int)((total / 4 + 255) / 256);
+    const int bblocks = dbias ? (Cout + 255) / 256 : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, (const float*)workspace, dw_oihw, S,
+                       ksize * ksize, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks);
     DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad(reduce)");
-    if (dbias) {
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((Cout + 15) / 16), dim3(256), 0, st, (const float*)a.bpart, dbias, S * 4, Cout,
-                           accumulate);
-        DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad(bias reduce)");
-    }
     return DXMI_OK;
 }
 

@@ -26,6 +26,13 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class PackItem(ctypes.Structure):
+    """Mirror of struct dxmi_pack_item (include/dxmi_hip.h)."""
+
+    _fields_ = [("w", c_void_p), ("dst", c_void_p), ("Cout", c_int), ("Cin", c_int), ("ksize", c_int), ("transpose_flip", c_int),
+                ("k27", c_int)]
+
+
 # symbol -> (restype, argtypes); kept in one table so tests can check it against the header.
 SIGNATURES = {
     "dxmi_last_error": (ctypes.c_char_p, []),
@@ -40,6 +47,7 @@ SIGNATURES = {
     "dxmi_groupnorm_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dxmi_packed_conv_weight_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "dxmi_pack_conv_weights": (c_int, [ctypes.POINTER(PackItem), c_int, c_void_p]),
     "dxmi_pack_conv_weight": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_conv2d_wgrad_workspace_bytes": (c_int64, [c_int] * 6),
     "dxmi_conv2d_wgrad": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),

@@ -5,6 +5,7 @@ Every function launches asynchronously on torch's current stream and allocates i
 torch.empty unless `out=` is given (pass `out=` inside hipGraph capture to keep addresses fixed).
 """
 import ctypes
+import os
 
 import torch
 
@@ -44,8 +45,38 @@ class PackedConvWeight:
         self.buf, self.Cout, self.Cin, self.ksize, self.k27 = buf, Cout, Cin, ksize, k27
 
 
+_PACK_BATCH = None
+
+
+class pack_batch:
+    """`with ops.pack_batch():` — every pack_conv_weight() inside allocates its destination and is DEFERRED; on exit all of
+    them run as a few multi-tensor launches (dxmi_pack_conv_weights).  The nets' `_pack` / `_pack_t` use it: after an
+    optimiser step ~60 (CIFAR U-Net) to ~330 (ImageNet-64 EDM net) weights are refreshed."""
+
+    def __enter__(self):
+        global _PACK_BATCH
+        self.outer = _PACK_BATCH is not None or os.environ.get("DXMI_PACK_BATCH", "1") == "0"     # (=0: one launch per weight, A/B timing)
+        if not self.outer:
+            _PACK_BATCH = []
+        return self
+
+    def __exit__(self, *exc):
+        global _PACK_BATCH
+        if self.outer:
+            return False
+        items, _PACK_BATCH = _PACK_BATCH, None
+        if items and exc[0] is None:
+            arr = (_lib.PackItem * len(items))()
+            for i, (w, out, Cout, Cin, k, flip, k27) in enumerate(items):
+                arr[i].w, arr[i].dst = w.data_ptr(), out.data_ptr()
+                arr[i].Cout, arr[i].Cin, arr[i].ksize, arr[i].transpose_flip, arr[i].k27 = Cout, Cin, k, int(flip), int(k27)
+            check(load().dxmi_pack_conv_weights(arr, len(items), _stream()), "dxmi_pack_conv_weights")
+        return False
+
+
 def pack_conv_weight(w, transpose_flip=False, k27=False, out=None):
-    """w: fp32 [Cout, Cin, k, k] (or [M, K] for a linear layer) on the device."""
+    """w: fp32 [Cout, Cin, k, k] (or [M, K] for a linear layer) on the device.  Inside `with pack_batch():` the launch is
+    deferred to the end of the block (the returned buffer is filled then)."""
     _need_cuda(w)
     if w.dim() == 2:
         w = w[:, :, None, None]
@@ -57,8 +88,11 @@ def pack_conv_weight(w, transpose_flip=False, k27=False, out=None):
     if out is None:
         out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
     assert out.numel() == nbytes
-    check(lib.dxmi_pack_conv_weight(_ptr(w), _ptr(out), Cout, Cin, k, int(transpose_flip), int(k27), _stream()),
-          "dxmi_pack_conv_weight")
+    if _PACK_BATCH is not None:
+        _PACK_BATCH.append((w, out, Cout, Cin, k, transpose_flip, k27))      # (w is kept alive until the launch)
+    else:
+        check(lib.dxmi_pack_conv_weight(_ptr(w), _ptr(out), Cout, Cin, k, int(transpose_flip), int(k27), _stream()),
+              "dxmi_pack_conv_weight")
     return PackedConvWeight(out, Cout, Cin, k, k27)
 
 

@@ -176,32 +176,33 @@ class Model(nn.Module):
 
     def _pack(self):
         """(Re)build the bf16 MFMA weight fragments from the fp32 master parameters."""
-        pk = {}
-        dev = self.conv_in.weight.device
-        pk["dense0"] = ops.pack_conv_weight(self.temb.dense[0].weight)
-        pk["dense1"] = ops.pack_conv_weight(self.temb.dense[1].weight)
-        blocks = list(self._resblocks())
-        # every temb_proj of the net in ONE [sum(Cout), temb_ch] operator (reference :123)
-        pk["tproj"] = ops.pack_conv_weight(torch.cat([b.temb_proj.weight for b in blocks], 0))
-        pk["tproj_bias"] = torch.cat([b.temb_proj.bias for b in blocks], 0).detach().float().contiguous()
-        off = 0
-        for b in blocks:
-            pk[id(b), "toff"] = off
-            off += b.out_channels
-            pk[id(b), "conv1"] = ops.pack_conv_weight(b.conv1.weight)
-            pk[id(b), "conv2"] = ops.pack_conv_weight(b.conv2.weight)
-            if b.in_channels != b.out_channels:
-                sc = b.conv_shortcut if b.use_conv_shortcut else b.nin_shortcut
-                pk[id(b), "short"] = ops.pack_conv_weight(sc.weight)
-        for m in self.modules():
-            if isinstance(m, AttnBlock):
-                pk[id(m), "qkv"] = ops.pack_conv_weight(torch.cat([m.q.weight, m.k.weight, m.v.weight], 0))
-                pk[id(m), "qkv_bias"] = torch.cat([m.q.bias, m.k.bias, m.v.bias], 0).detach().float().contiguous()
-                pk[id(m), "proj"] = ops.pack_conv_weight(m.proj_out.weight)
-            elif isinstance(m, (Upsample, Downsample)):
-                pk[id(m), "conv"] = ops.pack_conv_weight(m.conv.weight)
-        pk["conv_in"] = ops.pack_conv_weight(self.conv_in.weight, k27=(self.in_channels == 3))
-        pk["conv_out"] = ops.pack_conv_weight(self.conv_out.weight)
+        with ops.pack_batch():            # every pack below runs in a few multi-tensor launches
+            pk = {}
+            dev = self.conv_in.weight.device
+            pk["dense0"] = ops.pack_conv_weight(self.temb.dense[0].weight)
+            pk["dense1"] = ops.pack_conv_weight(self.temb.dense[1].weight)
+            blocks = list(self._resblocks())
+            # every temb_proj of the net in ONE [sum(Cout), temb_ch] operator (reference :123)
+            pk["tproj"] = ops.pack_conv_weight(torch.cat([b.temb_proj.weight for b in blocks], 0))
+            pk["tproj_bias"] = torch.cat([b.temb_proj.bias for b in blocks], 0).detach().float().contiguous()
+            off = 0
+            for b in blocks:
+                pk[id(b), "toff"] = off
+                off += b.out_channels
+                pk[id(b), "conv1"] = ops.pack_conv_weight(b.conv1.weight)
+                pk[id(b), "conv2"] = ops.pack_conv_weight(b.conv2.weight)
+                if b.in_channels != b.out_channels:
+                    sc = b.conv_shortcut if b.use_conv_shortcut else b.nin_shortcut
+                    pk[id(b), "short"] = ops.pack_conv_weight(sc.weight)
+            for m in self.modules():
+                if isinstance(m, AttnBlock):
+                    pk[id(m), "qkv"] = ops.pack_conv_weight(torch.cat([m.q.weight, m.k.weight, m.v.weight], 0))
+                    pk[id(m), "qkv_bias"] = torch.cat([m.q.bias, m.k.bias, m.v.bias], 0).detach().float().contiguous()
+                    pk[id(m), "proj"] = ops.pack_conv_weight(m.proj_out.weight)
+                elif isinstance(m, (Upsample, Downsample)):
+                    pk[id(m), "conv"] = ops.pack_conv_weight(m.conv.weight)
+            pk["conv_in"] = ops.pack_conv_weight(self.conv_in.weight, k27=(self.in_channels == 3))
+            pk["conv_out"] = ops.pack_conv_weight(self.conv_out.weight)
         assert dev.type == "cuda"
         return pk
 

@@ -28,22 +28,23 @@ def _pack_t(net):
         return net._packed_t
     from .unet_small import AttnBlock, Downsample, Upsample
     pk = {}
-    for b in net._resblocks():
-        pk[id(b), "conv1"] = ops.pack_conv_weight(b.conv1.weight, transpose_flip=True)
-        pk[id(b), "conv2"] = ops.pack_conv_weight(b.conv2.weight, transpose_flip=True)
-        if b.in_channels != b.out_channels:
-            sc = b.conv_shortcut if b.use_conv_shortcut else b.nin_shortcut
-            pk[id(b), "short"] = sc.weight  # split per concat source at use time
-    for m in net.modules():
-        if isinstance(m, AttnBlock):
-            pk[id(m), "qkv"] = ops.pack_conv_weight(torch.cat([m.q.weight, m.k.weight, m.v.weight], 0), transpose_flip=True)
-            pk[id(m), "proj"] = ops.pack_conv_weight(m.proj_out.weight, transpose_flip=True)
-        elif isinstance(m, (Upsample, Downsample)):
-            pk[id(m), "conv"] = ops.pack_conv_weight(m.conv.weight, transpose_flip=True)
-    w = net.conv_out.weight
-    wpad = torch.zeros((64,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device)
-    wpad[: w.shape[0]] = w.detach()
-    pk["conv_out"] = ops.pack_conv_weight(wpad, transpose_flip=True)
+    with ops.pack_batch():            # a few multi-tensor launches instead of one per layer
+        for b in net._resblocks():
+            pk[id(b), "conv1"] = ops.pack_conv_weight(b.conv1.weight, transpose_flip=True)
+            pk[id(b), "conv2"] = ops.pack_conv_weight(b.conv2.weight, transpose_flip=True)
+            if b.in_channels != b.out_channels:
+                sc = b.conv_shortcut if b.use_conv_shortcut else b.nin_shortcut
+                pk[id(b), "short"] = sc.weight  # split per concat source at use time
+        for m in net.modules():
+            if isinstance(m, AttnBlock):
+                pk[id(m), "qkv"] = ops.pack_conv_weight(torch.cat([m.q.weight, m.k.weight, m.v.weight], 0), transpose_flip=True)
+                pk[id(m), "proj"] = ops.pack_conv_weight(m.proj_out.weight, transpose_flip=True)
+            elif isinstance(m, (Upsample, Downsample)):
+                pk[id(m), "conv"] = ops.pack_conv_weight(m.conv.weight, transpose_flip=True)
+        w = net.conv_out.weight
+        wpad = torch.zeros((64,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device)
+        wpad[: w.shape[0]] = w.detach()
+        pk["conv_out"] = ops.pack_conv_weight(wpad, transpose_flip=True)
     net._packed_t, net._packed_t_key = pk, key
     return pk
 

@@ -172,29 +172,30 @@ class UNetModel(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack(self):
-        pk = {"te0": ops.pack_conv_weight(self.time_embed[0].weight), "te2": ops.pack_conv_weight(self.time_embed[2].weight)}
-        blocks = [m for m in self.modules() if isinstance(m, ResBlock)]
-        pk["emb_w"] = ops.pack_conv_weight(torch.cat([b.emb_layers[1].weight for b in blocks], 0))
-        pk["emb_b"] = torch.cat([b.emb_layers[1].bias for b in blocks], 0).detach().float().contiguous()
-        off = 0
-        for b in blocks:
-            pk[id(b), "eoff"] = off
-            off += b.emb_layers[1].out_features
-            pk[id(b), "conv1"] = ops.pack_conv_weight(b.in_layers[2].weight)
-            pk[id(b), "conv2"] = ops.pack_conv_weight(b.out_layers[3].weight)
-            if not isinstance(b.skip_connection, nn.Identity):
-                pk[id(b), "skip"] = ops.pack_conv_weight(b.skip_connection.weight)
-        for m in self.modules():
-            if isinstance(m, AttentionBlock):
-                pk[id(m), "qkv"] = ops.pack_conv_weight(m.qkv.weight.reshape(3 * m.channels, m.channels, 1, 1))
-                pk[id(m), "proj"] = ops.pack_conv_weight(m.proj_out.weight.reshape(m.channels, m.channels, 1, 1))
-            elif isinstance(m, Upsample) and m.use_conv:
-                pk[id(m), "conv"] = ops.pack_conv_weight(m.conv.weight)
-            elif isinstance(m, Downsample) and m.use_conv:
-                pk[id(m), "conv"] = ops.pack_conv_weight(m.op.weight)
-        conv_in = self.input_blocks[0][0]
-        pk["conv_in"] = ops.pack_conv_weight(conv_in.weight, k27=(self.in_channels == 3))
-        pk["conv_out"] = ops.pack_conv_weight(self.out[2].weight)
+        with ops.pack_batch():            # every pack below runs in a few multi-tensor launches
+            pk = {"te0": ops.pack_conv_weight(self.time_embed[0].weight), "te2": ops.pack_conv_weight(self.time_embed[2].weight)}
+            blocks = [m for m in self.modules() if isinstance(m, ResBlock)]
+            pk["emb_w"] = ops.pack_conv_weight(torch.cat([b.emb_layers[1].weight for b in blocks], 0))
+            pk["emb_b"] = torch.cat([b.emb_layers[1].bias for b in blocks], 0).detach().float().contiguous()
+            off = 0
+            for b in blocks:
+                pk[id(b), "eoff"] = off
+                off += b.emb_layers[1].out_features
+                pk[id(b), "conv1"] = ops.pack_conv_weight(b.in_layers[2].weight)
+                pk[id(b), "conv2"] = ops.pack_conv_weight(b.out_layers[3].weight)
+                if not isinstance(b.skip_connection, nn.Identity):
+                    pk[id(b), "skip"] = ops.pack_conv_weight(b.skip_connection.weight)
+            for m in self.modules():
+                if isinstance(m, AttentionBlock):
+                    pk[id(m), "qkv"] = ops.pack_conv_weight(m.qkv.weight.reshape(3 * m.channels, m.channels, 1, 1))
+                    pk[id(m), "proj"] = ops.pack_conv_weight(m.proj_out.weight.reshape(m.channels, m.channels, 1, 1))
+                elif isinstance(m, Upsample) and m.use_conv:
+                    pk[id(m), "conv"] = ops.pack_conv_weight(m.conv.weight)
+                elif isinstance(m, Downsample) and m.use_conv:
+                    pk[id(m), "conv"] = ops.pack_conv_weight(m.op.weight)
+            conv_in = self.input_blocks[0][0]
+            pk["conv_in"] = ops.pack_conv_weight(conv_in.weight, k27=(self.in_channels == 3))
+            pk["conv_out"] = ops.pack_conv_weight(self.out[2].weight)
         return pk
 
     def packed(self):

@@ -29,22 +29,23 @@ def _pack_t(net):
         return net._packed_t
     from .unet import AttentionBlock, Downsample, ResBlock, Upsample
     pk = {}
-    for m in net.modules():
-        if isinstance(m, ResBlock):
-            pk[id(m), "conv1"] = ops.pack_conv_weight(m.in_layers[2].weight, transpose_flip=True)
-            pk[id(m), "conv2"] = ops.pack_conv_weight(m.out_layers[3].weight, transpose_flip=True)
-        elif isinstance(m, AttentionBlock):
-            C = m.channels
-            pk[id(m), "qkv"] = ops.pack_conv_weight(m.qkv.weight.reshape(3 * C, C, 1, 1), transpose_flip=True)
-            pk[id(m), "proj"] = ops.pack_conv_weight(m.proj_out.weight.reshape(C, C, 1, 1), transpose_flip=True)
-        elif isinstance(m, Upsample) and m.use_conv:
-            pk[id(m), "conv"] = ops.pack_conv_weight(m.conv.weight, transpose_flip=True)
-        elif isinstance(m, Downsample) and m.use_conv:
-            pk[id(m), "conv"] = ops.pack_conv_weight(m.op.weight, transpose_flip=True)
-    w = net.out[2].weight
-    wpad = torch.zeros((64,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device)
-    wpad[: w.shape[0]] = w.detach()
-    pk["conv_out"] = ops.pack_conv_weight(wpad, transpose_flip=True)
+    with ops.pack_batch():            # a few multi-tensor launches instead of one per layer
+        for m in net.modules():
+            if isinstance(m, ResBlock):
+                pk[id(m), "conv1"] = ops.pack_conv_weight(m.in_layers[2].weight, transpose_flip=True)
+                pk[id(m), "conv2"] = ops.pack_conv_weight(m.out_layers[3].weight, transpose_flip=True)
+            elif isinstance(m, AttentionBlock):
+                C = m.channels
+                pk[id(m), "qkv"] = ops.pack_conv_weight(m.qkv.weight.reshape(3 * C, C, 1, 1), transpose_flip=True)
+                pk[id(m), "proj"] = ops.pack_conv_weight(m.proj_out.weight.reshape(C, C, 1, 1), transpose_flip=True)
+            elif isinstance(m, Upsample) and m.use_conv:
+                pk[id(m), "conv"] = ops.pack_conv_weight(m.conv.weight, transpose_flip=True)
+            elif isinstance(m, Downsample) and m.use_conv:
+                pk[id(m), "conv"] = ops.pack_conv_weight(m.op.weight, transpose_flip=True)
+        w = net.out[2].weight
+        wpad = torch.zeros((64,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device)
+        wpad[: w.shape[0]] = w.detach()
+        pk["conv_out"] = ops.pack_conv_weight(wpad, transpose_flip=True)
     net._packed_t, net._packed_t_key = pk, key
     return pk
 

@@ -83,12 +83,13 @@ class IGEBMEncoderV2(nn.Module):
     def packed(self):
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._packed is None or key != self._packed_key:
-            pk = {"conv1": ops.pack_conv_weight(self.conv1.weight, k27=(self.in_chan == 3))}
-            for i, b in enumerate(self.blocks):
-                pk[i, "conv1"] = ops.pack_conv_weight(b.conv1.weight)
-                pk[i, "conv2"] = ops.pack_conv_weight(b.conv2.weight)
-                if b.skip is not None:
-                    pk[i, "skip"] = ops.pack_conv_weight(b.skip[0].weight)
+            with ops.pack_batch():             # one multi-tensor launch for the net's weights
+                pk = {"conv1": ops.pack_conv_weight(self.conv1.weight, k27=(self.in_chan == 3))}
+                for i, b in enumerate(self.blocks):
+                    pk[i, "conv1"] = ops.pack_conv_weight(b.conv1.weight)
+                    pk[i, "conv2"] = ops.pack_conv_weight(b.conv2.weight)
+                    if b.skip is not None:
+                        pk[i, "skip"] = ops.pack_conv_weight(b.skip[0].weight)
             self._packed, self._packed_key = pk, key
         return self._packed
 
@@ -97,11 +98,12 @@ class IGEBMEncoderV2(nn.Module):
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._packed_t is None or key != self._packed_t_key:
             pk = {}
-            for i, b in enumerate(self.blocks):
-                pk[i, "conv1"] = ops.pack_conv_weight(b.conv1.weight, transpose_flip=True)
-                pk[i, "conv2"] = ops.pack_conv_weight(b.conv2.weight, transpose_flip=True)
-                if b.skip is not None:
-                    pk[i, "skip"] = ops.pack_conv_weight(b.skip[0].weight, transpose_flip=True)
+            with ops.pack_batch():
+                for i, b in enumerate(self.blocks):
+                    pk[i, "conv1"] = ops.pack_conv_weight(b.conv1.weight, transpose_flip=True)
+                    pk[i, "conv2"] = ops.pack_conv_weight(b.conv2.weight, transpose_flip=True)
+                    if b.skip is not None:
+                        pk[i, "skip"] = ops.pack_conv_weight(b.skip[0].weight, transpose_flip=True)
             self._packed_t, self._packed_t_key = pk, key
         return self._packed_t
 

@@ -107,6 +107,17 @@ int64_t dxmi_packed_conv_weight_bytes(int32_t Cout, int32_t Cin, int32_t ksize, 
 int dxmi_pack_conv_weight(const float* w_oihw, void* dst, int32_t Cout, int32_t Cin,
                           int32_t ksize, int32_t transpose_flip, int32_t k27, void* stream);
 
+/* Multi-tensor form of dxmi_pack_conv_weight: `count` weights (a HOST array of descriptors; the library cuts it into launches
+ * of DXMI_PACK_MAX items passed by value) — after an optimiser step (trainer.py:264, :325, :389; fp16_util.py:204-223) every
+ * packed weight of a net is refreshed by a handful of launches instead of one per layer. */
+#define DXMI_PACK_MAX 32
+typedef struct dxmi_pack_item {
+    const float* w;          /* fp32 OIHW [Cout,Cin,k,k] (transpose_flip: the ORIGINAL tensor [Cin_logical][Cout_logical][k][k]) */
+    void*        dst;        /* dxmi_packed_conv_weight_bytes(Cout, Cin, ksize, k27) bytes */
+    int32_t Cout, Cin, ksize, transpose_flip, k27;
+} dxmi_pack_item;
+int dxmi_pack_conv_weights(const dxmi_pack_item* items, int32_t count, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Backward of the convolutions (training path: models/DxMI/trainer.py:261,322,387 call
  * .backward() through the value network and the U-Net).
