@@ -1,10 +1,10 @@
-"""Rebuild profiles/<tag>_* from the gpurun_out/ directories written by tools/r02_profile.sh:
-    python tools/refresh_profiles.py r02"""
-import glob, json, shutil, subprocess, sys
+"""Rebuild profiles/<tag>_* from the gpurun_out/ directories written by tools/r02_profile.sh / r03_profile.sh:
+    python tools/refresh_profiles.py r03"""
+import glob, json, os, shutil, subprocess, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 run = lambda *a: subprocess.run(["python", *a], capture_output=True, text=True).stdout
 print(run("tools/pmc_traffic.py", f"gpurun_out/{tag}_pmc_FETCH_SIZE", f"gpurun_out/{tag}_pmc_WRITE_SIZE", f"profiles/{tag}_pmc_traffic.json")[:1200])
-B = "python3 bench.py --no-cpu-baseline --no-eager-reference --no-events"
+B = "python3 bench.py --no-cpu-baseline --no-eager-reference --no-events" + (" --no-edm" if tag >= "r03" else "")
 open(f"profiles/{tag}_bench_kernel_stats_summary.txt", "w").write(
     f"# rocprofv3 --kernel-trace --stats summary, round {tag[1:]}\n"
     f"# command: rocprofv3 --kernel-trace --stats --output-format csv -- {B} --steps 5 --warmup 2 --train-steps 0   (1x MI355X)\n"
@@ -26,7 +26,7 @@ for d in (f"{tag}_pmc_sq1", f"{tag}_pmc_sq2"):
     keep = False
     for l in run("tools/pmc_summary.py", f"gpurun_out/{d}").split("\n"):
         if not l.startswith("    "):
-            keep = any(k in l for k in ("conv_ws_kernel", "conv_ws8_kernel", "conv_head_kernel", "conv_pipe_kernel<4, ", "conv1x1_rw_kernel", "conv1x1_stream_kernel", "conv_pipe_kernel<2, 6, 3", "gn_silu_kernel", "attention_kernel", "attention256_kernel"))
+            keep = any(k in l for k in ("conv_ws_kernel", "conv_ws8_kernel", "conv_sm_kernel", "conv_head_kernel", "conv_pipe_kernel<4, ", "conv1x1_rw_kernel", "conv1x1_stream_kernel", "conv_pipe_kernel<2, 6, 3", "gn_silu_kernel", "gn_apply_kernel", "attention_kernel", "attention256_kernel"))
         if keep:
             out += l + "\n"
 open(f"profiles/{tag}_pmc_sq_counters.txt", "w").write(out)
@@ -34,3 +34,27 @@ d = json.load(open(f"profiles/{tag}_bench_line.json"))
 r = d["roofline"]
 print(d["value"], d["ms_per_step"], d["train_steps_per_sec"], r["achieved"], r["frac"], r["traffic"], r["algorithmic_bytes_per_launch"], r["avg_launch_us"], r["kernel"], d["cpu_baseline"])
 print(d["reference_eager_gpu"])
+
+# ---- round 3 extras: train-leg PMC passes, EDM kernel statistics
+if os.path.isdir(f"gpurun_out/{tag}_pmc_train_FETCH_SIZE"):
+    print(run("tools/pmc_traffic.py", f"gpurun_out/{tag}_pmc_train_FETCH_SIZE", f"gpurun_out/{tag}_pmc_train_WRITE_SIZE", f"profiles/{tag}_pmc_train_traffic.json")[:1500])
+if os.path.isdir(f"gpurun_out/{tag}_pmc_train_sq1"):
+    out = ("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT\n"
+           f"# -- {B} --steps 1 --warmup 0 --train-steps 1 (train leg: backward kernels)\n\n")
+    keep = False
+    for l in run("tools/pmc_summary.py", f"gpurun_out/{tag}_pmc_train_sq1").split("\n"):
+        if not l.startswith("    "):
+            keep = any(k in l for k in ("conv_wgrad", "wgrad_reduce", "gn_silu_bwd", "gn_gen_bwd", "bgemm", "softmax_bwd"))
+        if keep:
+            out += l + "\n"
+    open(f"profiles/{tag}_pmc_train_sq_counters.txt", "w").write(out)
+for name, cmd in (("edm_in64", "tools/edm_bench.py imagenet64_T10 100"), ("edm_lsun", "tools/edm_bench.py lsun_bedroom_T4 16"),
+                  ("edm_train", "tools/edm_train_bench.py imagenet64_T10 16 2")):
+    d = f"gpurun_out/{tag}_prof_{name}"
+    if os.path.isdir(d):
+        head = open(f"gpurun_out/{tag}_prof_{name}.out").read().strip().split("\n")[-1]
+        open(f"profiles/{tag}_{name}_kernel_stats_summary.txt", "w").write(
+            f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 {cmd}   (1x MI355X; the run's own line, under the profiler:)\n# {head}\n\n"
+            + run("tools/kstats.py", d, "36"))
+if "edm" in d_line if (d_line := json.load(open(f"profiles/{tag}_bench_line.json"))) else False:
+    print({k: (v.get("images_per_sec"), v.get("train_steps_per_sec")) for k, v in d_line["edm"].items()})
