@@ -408,13 +408,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         return;
     }
+    // 64 positions (of four consecutive ci) x 4 slices of the S partials per block: a thread adds its slice's partials in
+    // order, the four slice sums are added in order through LDS (one thread per position looping over all S partials ran at
+    // 1.3 TB/s — too few loads in flight; round-3 train profile: 7 ms per step, as much as the weight-gradient kernel itself)
+    __shared__ f32x4 sm[3][64];
     const long total = (long)taps * Cout * Cin;
-    const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (idx >= total) return;
+    const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long idx = ((long)blockIdx.x * 64 + px) * 4;
+    const bool live = idx < total;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const int k0 = (S * sl) >> 2, k1 = (S * (sl + 1)) >> 2;
 #pragma unroll 4
-    for (int k = 0; k < S; ++k) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (size_t)k * total + idx);
+        for (int k = k0; k < k1; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (size_t)k * total + idx);
+            s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+        }
+    }
+    if (sl > 0) sm[sl - 1][px] = s;
+    __syncthreads();
+    if (sl != 0 || !live) return;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const f32x4 v = sm[j][px];
         s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
     const int ci = idx % Cin;
@@ -568,7 +584,7 @@ static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, co
 #undef DXMI_WG_LAUNCH
     DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad");
     const long total = (long)ksize * ksize * Cout * Cin;
-    const int wblocks = (int)((total / 4 + 255) / 256);
+    const int wblocks = (int)((total / 4 + 63) / 64);
     const int bblocks = dbias ? (Cout + 255) / 256 : 0;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, (const float*)workspace, dw_oihw, S,
                        ksize * ksize, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks);
