@@ -1125,14 +1125,18 @@ extern "C" int dxmi_groupnorm_apply(const void* in0, int32_t C0, const float* st
     a.ss = scale_shift; a.ss_ld = ss_ld;
     a.out = (bf16*)out; a.C0 = C0; a.C1 = C1; a.HW = HW; a.groups = groups; a.cpg = cpg; a.P0 = P0; a.P1 = P1;
     a.eps = eps; a.silu = apply_silu;
-    // a workgroup streams ~64 KB: four trips of U = 4 rows x (256 / (C/8)) row lanes
-    constexpr int U = 4;
+    // a workgroup streams ~32 KB: two trips of U = 4 rows x (256 / (C/8)) row lanes
+    static const int u_env = getenv("DXMI_GN_APPLY_U") ? atoi(getenv("DXMI_GN_APPLY_U")) : 4;            // tuning: loads in flight per thread
+    static const int trips_env = getenv("DXMI_GN_APPLY_TRIPS") ? atoi(getenv("DXMI_GN_APPLY_TRIPS")) : 2;      // (in-situ sweep: 2 trips of 4 = 32 KB per workgroup slightly ahead of 4)
+    const int U = u_env == 8 ? 8 : (u_env == 2 ? 2 : 4);
     const int rows_par = 256 / (C / 8);
-    int rpc = 4 * U * rows_par;
+    int rpc = trips_env * U * rows_par;
     if (rpc > HW) rpc = HW;
     a.chunks = (HW + rpc - 1) / rpc;
     a.rows_per_chunk = rpc;
-    hipLaunchKernelGGL(gn_apply_kernel<U>, dim3(N * a.chunks), dim3(256), 0, (hipStream_t)stream, a);
+    if (U == 8) hipLaunchKernelGGL(gn_apply_kernel<8>, dim3(N * a.chunks), dim3(256), 0, (hipStream_t)stream, a);
+    else if (U == 2) hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(N * a.chunks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(N * a.chunks), dim3(256), 0, (hipStream_t)stream, a);
     DXMI_CHECK_LAUNCH("dxmi_groupnorm_apply");
     return DXMI_OK;
 }
