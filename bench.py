@@ -87,8 +87,6 @@ def kernel_name(kid):
     """dxmi_conv2d_kernel_id -> the template instantiation name rocprofv3 prints."""
     if kid >= 600000:
         return "conv_head_kernel"
-    if kid >= 550000:
-        return f"conv1x1_ws_kernel<{(kid // 10) % 10}, {'true' if kid % 10 else 'false'}, {8 if (kid // 10) % 10 == 2 else 4}>"
     if kid >= 500000:
         return f"conv1x1_rw_kernel<{(kid // 1000) % 10}, {(kid // 10) % 100}, {'true' if kid % 10 else 'false'}>"
     if kid == 400008:
