@@ -168,12 +168,14 @@ __global__ __launch_bounds__(512) void gn_silu_kernel(GnArgs p) {
 // in a fixed order, then normalises its rows (second read mostly served by L2 / Infinity Cache).
 // Optional per-image scale/shift (ADM "scale-shift norm", models/cm/unet.py:252-256):
 //   y = (xh*gamma + beta) * (1 + scale[n,c]) + shift[n,c]   then SiLU.
-// row chunks per image of the generic kernels: ~256 pixel rows per workgroup, more (down to 64 rows) while the launch
-// would otherwise have fewer than ~1024 workgroups
+// row chunks per image of the generic kernels: ~256 pixel rows per workgroup.  The count depends on the map only, NOT on the
+// batch: the partial sums of an image are added in chunk order, and round 2's "more chunks while the launch is small" rule made
+// an image's statistics (hence its output bits) depend on the batch it rode in — the reason the EDM configs were only
+// batch-independent to 2e-2.
 static inline int gn_gen_chunks(int HW, int N) {
+    (void)N;
     if (HW < 256) return 1;
-    int c = HW / 256;
-    while ((long)N * c < 1024 && c < HW / 64) c *= 2;
+    const int c = HW / 256;
     return c > 64 ? 64 : c;
 }
 

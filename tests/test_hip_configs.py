@@ -151,7 +151,9 @@ def _edm(name):
 
 def test_c4_imagenet64_T10_batch100_sample():
     """BASELINE configs[3]: full-size ImageNet-64 EDM net (295.9M parameters), T=10, 100 images per rank, class-conditional,
-    through OpenAIDiffusion.sample: finite, reproducible, batch-independent, sigma ladder exact."""
+    through OpenAIDiffusion.sample: finite, reproducible, BITWISE batch-independent (round 3: the GroupNorm statistics of an
+    image no longer depend on the batch — block statistics per 128-pixel half tile from the conv epilogue, batch-independent
+    chunking in the generic path), sigma ladder exact."""
     net, s, _ = _edm("imagenet64_T10")
     assert sum(p.numel() for p in net.parameters()) == 295_899_267 + 10       # + log_betas[T]
     B, T = 100, 10
@@ -164,7 +166,7 @@ def test_c4_imagenet64_T10_batch100_sample():
         part = s.sample(7, device=DEV, i_class=y[40:47].contiguous(), noise=noise[:, 40:47].contiguous())
     assert len(d["l_sample"]) == T + 1 and d["sample"].shape == (B, 3, 64, 64) and torch.isfinite(d["sample"]).all()
     assert torch.equal(d["sample"], d2["sample"])
-    assert rel_l2(part["sample"].cpu(), d["sample"][40:47].cpu()) < 2e-2
+    assert torch.equal(part["sample"], d["sample"][40:47])
     assert torch.equal(d["y"], y)
     np.testing.assert_allclose(torch.stack(d["sigma"])[:, 0].cpu().numpy()[:-1],
                                np.array([35.9629364, 18.3089771, 8.63025856, 3.69350600, 1.39556587, 0.446370661, 0.112989359,
@@ -188,7 +190,7 @@ def test_c5_lsun256_T4_batch16_sample_and_first_level_vs_oracle():
         part = s.sample(2, device=DEV, noise=noise[:, 5:7].contiguous())
     assert d["sample"].shape == (B, 3, 256, 256) and torch.isfinite(d["sample"]).all() and d["y"] is None
     assert torch.equal(d["sample"], d2["sample"])
-    assert rel_l2(part["sample"].cpu(), d["sample"][5:7].cpu()) < 2e-2
+    assert torch.equal(part["sample"], d["sample"][5:7])                       # bitwise batch-independent
     np.testing.assert_allclose(torch.stack(d["sigma"])[:, 0].cpu().numpy(),
                                np.array([26.0551224, 6.38497114, 0.671041727, 1.99999753e-3], np.float32), rtol=2e-6)
     # first level vs oracle (B=2 of the batch, network input of step 0: c_in * x_T)
