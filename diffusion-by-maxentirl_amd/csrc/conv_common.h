@@ -23,6 +23,11 @@ struct ConvArgs {
     int stagger;             // conv_pipe: start delay (units of s_sleep 127 ~ 8k cycles) of the second resident half
     int RP, SP;              // conv_pipe: LDS pitch of a halo row / of a sub-image, bytes (bank-conflict-free choice)
     float* gn_stats;         // optional: GroupNorm block statistics of the OUTPUT, fp32 [N][P][Cout/2][2] (dxmi_conv_desc.gn_stats)
+    bf16* gn_out;            // optional: fused GroupNorm(+SiLU) of the output (dxmi_conv_desc.gn_out ...): conv_sm_kernel only
+    const float* gn_gamma;
+    const float* gn_beta;
+    float gn_eps;
+    int gn_flags;            // bit 0: SiLU, bit 1: skip the raw output
 };
 
 // Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15): every lane of the row ends with the row's total.  Each step adds

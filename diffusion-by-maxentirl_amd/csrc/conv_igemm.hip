@@ -369,6 +369,8 @@ int dispatch_conv(ConvArgs& a, int variant, hipStream_t st, int* kernel_id = nul
     }
     DXMI_CHECK_ARG(!a.gn_stats || kernel_id, "dxmi_conv2d_fwd: the kernel for this shape does not emit GroupNorm block statistics "
                                              "(dxmi_conv2d_gn_stats_partials returns 0 for it)");
+    DXMI_CHECK_ARG(!a.gn_out || kernel_id, "dxmi_conv2d_fwd: the kernel for this shape cannot fuse the GroupNorm of its output "
+                                           "(dxmi_conv2d_gn_fuse_supported returns 0 for it)");
     constexpr int CK = 32;
     a.tile_px = 256;
     a.stagger = 0;
@@ -434,6 +436,10 @@ static int conv2d_impl(const dxmi_conv_desc* d, void* stream, int* kernel_id) {
     a.in0 = (const bf16*)d->in0; a.in1 = (const bf16*)d->in1; a.w = (const bf16*)d->wpacked;
     a.bias = d->bias; a.addvec = d->addvec; a.residual = (const bf16*)d->residual; a.out = d->out;
     a.mask_src = (const bf16*)d->mask_src; a.mask_slope = d->mask_slope; a.gn_stats = d->gn_stats;
+    a.gn_out = (bf16*)d->gn_out; a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta; a.gn_eps = d->gn_eps; a.gn_flags = d->gn_flags;
+    DXMI_CHECK_ARG(!d->gn_out || (d->gn_gamma && d->gn_beta && d->gn_groups > 0 && d->Cout == 8 * d->gn_groups && d->variant == 0 &&
+                                  d->out_mode == DXMI_OUT_NHWC_BF16),
+                   "dxmi_conv2d_fwd: gn_out needs gamma / beta, 8 channels per group, the default variant and NHWC bf16 output");
     DXMI_CHECK_ARG(!d->gn_stats || (d->variant == 0 && d->out_mode == DXMI_OUT_NHWC_BF16 && d->Cout % 4 == 0),
                    "dxmi_conv2d_fwd: gn_stats needs the default variant, NHWC bf16 output and Cout%%4==0");
     a.N = d->N; a.IH = d->IH; a.IW = d->IW; a.C0 = d->C0; a.C1 = d->C1; a.OH = d->OH; a.OW = d->OW; a.Cout = d->Cout;
@@ -470,6 +476,17 @@ extern "C" int dxmi_conv2d_gn_stats_partials(const dxmi_conv_desc* d) {
     if (q.variant != 0 || q.out_mode != DXMI_OUT_NHWC_BF16) return 0;
     const int rc = conv2d_impl(&q, nullptr, &id);
     return rc == DXMI_OK ? gn_stats_partials_of(d, id) : 0;
+}
+
+extern "C" int dxmi_conv2d_gn_fuse_supported(const dxmi_conv_desc* d) {
+    int id = 0;
+    if (!d) return 0;
+    dxmi_conv_desc q = *d;
+    q.gn_stats = nullptr;
+    q.gn_out = nullptr;
+    if (q.variant != 0 || q.out_mode != DXMI_OUT_NHWC_BF16 || d->gn_groups <= 0 || d->Cout != 8 * d->gn_groups) return 0;
+    const int rc = conv2d_impl(&q, nullptr, &id);
+    return rc == DXMI_OK && id == 450432 ? 1 : 0;      // conv_sm_kernel<2, 8, 32>: eight whole 4x4 images x 32 couts per tile
 }
 
 // Which template instantiation dxmi_conv2d_fwd would launch for this descriptor (no launch):
@@ -558,7 +575,8 @@ extern "C" int dxmi_linear_fwd(const float* x, const void* wpacked, const float*
     }
     ConvArgs a;
     a.in0 = (const bf16*)x; a.in1 = nullptr; a.w = (const bf16*)wpacked; a.bias = bias; a.addvec = nullptr;
-    a.residual = nullptr; a.out = out; a.mask_src = nullptr; a.mask_slope = 0.f; a.gn_stats = nullptr;
+    a.residual = nullptr; a.out = out; a.mask_src = nullptr; a.mask_slope = 0.f; a.gn_stats = nullptr; a.gn_out = nullptr;
+    a.gn_gamma = a.gn_beta = nullptr; a.gn_eps = 0.f; a.gn_flags = 0;
     a.N = 1; a.IH = 1; a.IW = P; a.C0 = K; a.C1 = 0; a.OH = 1; a.OW = P; a.Cout = M;
     a.ksize = 1; a.stride = 1; a.pad = 0; a.ups = 0; a.act = post_act; a.addvec_ld = 0;
     a.in_mode = DXMI_IN_ROWS_F32; a.out_mode = DXMI_OUT_ROWS_F32; a.P = P; a.pre_act = pre_act;

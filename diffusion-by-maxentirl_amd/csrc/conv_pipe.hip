@@ -645,7 +645,14 @@ int conv_sm_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);      // con
 
 int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     {
-        int rc = conv_ws_try_launch(a, st, kernel_id);
+        int rc = 1;
+        if (a.gn_out) {          // only conv_sm_kernel fuses the GroupNorm of its output
+            rc = conv_sm_try_launch(a, st, kernel_id);
+            if (rc <= 0) return rc;
+            DXMI_CHECK_ARG(false, "dxmi_conv2d_fwd: the kernel for this shape cannot fuse the GroupNorm of its output "
+                                  "(dxmi_conv2d_gn_fuse_supported returns 0 for it)");
+        }
+        rc = conv_ws_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;
         // only the kernels tried above emit GroupNorm block statistics (dxmi_conv2d_gn_stats_partials says which shapes)
         DXMI_CHECK_ARG(!a.gn_stats || kernel_id, "dxmi_conv2d_fwd: the kernel for this shape does not emit GroupNorm block statistics "

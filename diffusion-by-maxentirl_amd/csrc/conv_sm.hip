@@ -229,6 +229,19 @@ __global__ __launch_bounds__(256 + 64 * NL) void conv_sm_kernel(ConvArgs p) {
         for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
     const float slope = dxmi_act_slope(p.act);
     const bool plain = p.act == DXMI_ACT_NONE;
+    // fused GroupNorm of the output (4x4 maps, 32-cout tiles): an image's 16 pixels are one DPP row, a group's 8 couts the two
+    // half-waves' 4 accumulator registers of one g.  The workgroup keeps its cout tile, so gamma / beta live in registers.
+    constexpr bool CAN_GN = ML == 2 && MT == 32;
+    const bool fuse_gn = CAN_GN && p.gn_out != nullptr;
+    f32x4 gam[4], bet[4];
+    if (fuse_gn) {
+        const int co0 = (q0 % p.CT) * MT + 4 * (lane >> 5);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            gam[g] = *reinterpret_cast<const f32x4*>(p.gn_gamma + co0 + 8 * g);
+            bet[g] = *reinterpret_cast<const f32x4*>(p.gn_beta + co0 + 8 * g);
+        }
+    }
     int c = 0, ti = 0;
     for (int gc = 0; gc < total; ++gc) {
         sm_barrier();                           // B_gc
@@ -289,7 +302,35 @@ __global__ __launch_bounds__(256 + 64 * NL) void conv_sm_kernel(ConvArgs p) {
                     bf16x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-                    if (n < p.N) *reinterpret_cast<bf16x4*>(orow + co) = o;
+                    if (n < p.N && !(fuse_gn && (p.gn_flags & 2))) *reinterpret_cast<bf16x4*>(orow + co) = o;
+                    if constexpr (CAN_GN) {
+                        if (fuse_gn) {
+                            // statistics of the ROUNDED output (what a separate GroupNorm launch would read), two-pass, in a
+                            // fixed order: 4 in-lane values, the 16 pixels of the DPP row, the other half-wave
+                            float x[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) x[e] = (float)o[e];
+                            float s = dxmi_row16_sum((x[0] + x[1]) + (x[2] + x[3]));
+                            s += __shfl_xor(s, 32);
+                            const float mean = s * (1.f / 128.f);
+                            float d[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) d[e] = x[e] - mean;
+                            float qv = dxmi_row16_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+                            qv += __shfl_xor(qv, 32);
+                            const float rstd = rsqrtf(qv * (1.f / 128.f) + p.gn_eps);
+                            bf16x4 y;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float ga = gam[g][e] * rstd;           // same form as groupnorm_silu_kernel
+                                float t = x[e] * ga + (bet[g][e] - mean * ga);
+                                if (p.gn_flags & 1) t = dxmi_silu_fast(t);
+                                y[e] = (bf16)t;
+                            }
+                            if (n < p.N)
+                                *reinterpret_cast<bf16x4*>(p.gn_out + ((size_t)n * HW + (px & (HW - 1))) * p.Cout + cot * MT + co) = y;
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[cb][4 * g + e] = 0.f;
                 }
@@ -315,6 +356,7 @@ int conv_sm_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     const int PT = (a.N + imgs - 1) / imgs;
     const int MT = (a.Cout % 64 == 0 && (long)PT * (a.Cout / 64) >= 256) ? 64 : 32;
     if (a.Cout % MT != 0 || a.C0 % 32 != 0 || a.C1 % 32 != 0) return 1;
+    if (a.gn_out && !(a.OW == 4 && MT == 32)) return 1;      // the fused GroupNorm needs whole images per DPP row
     const int nchunks = (a.C0 + a.C1) / 32;
     if (nchunks < 5) return 1;               // the residual / table buffers are refilled R - 1 chunks ahead of their tile's end
     if ((long)a.N * a.OH * a.OW * (a.C0 > a.C1 ? a.C0 : a.C1) * 2 >= (1L << 31)) return 1;

@@ -23,6 +23,7 @@ class ConvDesc(ctypes.Structure):
         ("ksize", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int), ("act", c_int),
         ("addvec_ld", c_int), ("in_mode", c_int), ("out_mode", c_int), ("variant", c_int),
         ("mask_src", c_void_p), ("mask_slope", c_float), ("gn_stats", c_void_p),
+        ("gn_out", c_void_p), ("gn_gamma", c_void_p), ("gn_beta", c_void_p), ("gn_eps", c_float), ("gn_groups", c_int), ("gn_flags", c_int),
     ]
 
 
@@ -41,6 +42,7 @@ SIGNATURES = {
     "dxmi_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
     "dxmi_conv2d_kernel_id": (c_int, [ctypes.POINTER(ConvDesc)]),
     "dxmi_conv2d_gn_stats_partials": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "dxmi_conv2d_gn_fuse_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
     "dxmi_gn_block_stats_partials": (c_int, [c_int]),
     "dxmi_gn_block_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dxmi_gn_stats_fold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -111,10 +111,13 @@ _STATS_P = {}
 
 
 def conv2d(x, pw, *, in1=None, bias=None, addvec=None, residual=None, stride=1, pad=None, pad_br=None, upsample=False,
-           act=ACT_NONE, out=None, out_nchw_f32=False, variant=0, mask_src=None, mask_slope=0.0, want_stats=False):
+           act=ACT_NONE, out=None, out_nchw_f32=False, variant=0, mask_src=None, mask_slope=0.0, want_stats=False, fuse_gn=None):
     """x: NHWC bf16 [N,IH,IW,C0] (or NCHW fp32 [N,3,H,W] when pw.k27).
     want_stats: return (out, BlockStats | None) — the output's GroupNorm block statistics written by the conv's own epilogue
-    where the selected kernel can (None otherwise: the caller falls back to block_stats() or the one-pass GroupNorm)."""
+    where the selected kernel can (None otherwise: the caller falls back to block_stats() or the one-pass GroupNorm).
+    fuse_gn = (gamma, beta, groups, eps, silu, keep_raw): return (out | None, y | None) with y = GroupNorm(+SiLU)(out) written
+    by the conv's own epilogue where the selected kernel can (4x4 maps; y None otherwise: the caller normalises `out` itself);
+    keep_raw False drops the un-normalised tensor (out None) when y is produced."""
     _need_cuda(x, in1, bias, addvec, residual, out)
     k = pw.ksize
     if pad is None:
@@ -173,10 +176,27 @@ def conv2d(x, pw, *, in1=None, bias=None, addvec=None, residual=None, stride=1, 
         if P > 0:
             stats = BlockStats(torch.empty((N, P, Cout // 2, 2), dtype=torch.float32, device=x.device), P)
             d.gn_stats = stats.buf.data_ptr()
+    d.gn_out, y = None, None
+    if fuse_gn is not None:
+        assert not want_stats
+        gamma, beta, groups, eps, silu, keep_raw = fuse_gn
+        d.gn_groups = groups
+        key = ("gn", N, IH, IW, C0, C1, OH, OW, Cout, k, stride, pad, int(upsample), act, d.in_mode, d.out_mode, variant,
+               residual is not None, mask_src is not None, groups)
+        ok = _STATS_P.get(key)
+        if ok is None:
+            ok = _STATS_P[key] = int(load().dxmi_conv2d_gn_fuse_supported(ctypes.byref(d)))
+        if ok:
+            assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == Cout and beta.numel() == Cout
+            y = torch.empty((N, OH, OW, Cout), dtype=torch.bfloat16, device=x.device)
+            d.gn_out, d.gn_gamma, d.gn_beta, d.gn_eps = y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps)
+            d.gn_flags = int(bool(silu)) | (0 if keep_raw else 2)
     if PROFILER is not None:
         PROFILER.launch_conv(d)
     else:
         check(load().dxmi_conv2d_fwd(ctypes.byref(d), _stream()), "dxmi_conv2d_fwd")
+    if fuse_gn is not None:
+        return (out if (y is None or fuse_gn[5]) else None), y
     if stats is not None and stats.P > MAX_APPLY_PARTIALS:
         stats = fold_stats(stats)
     return (out, stats) if want_stats else out
@@ -206,6 +226,8 @@ class OpProfiler:
         in_b = d.N * d.IH * d.IW * (d.C0 + d.C1) * (4 if d.in_mode == IN_NCHW_F32_K27 else 2)
         out_b = d.N * d.OH * d.OW * d.Cout * (4 if d.out_mode == OUT_NCHW_F32 else 2)
         res_b = out_b if d.residual else 0
+        if d.gn_out:                                  # fused GroupNorm: the normalised tensor out, the raw one only if kept
+            res_b += out_b if not (d.gn_flags & 2) else 0
         w_b = d.Cout * cin * 2
         cls = "conv_other" if kid >= 600000 else "conv1x1" if kid >= 500000 else "conv3x3" if kid >= 400000 else "conv_stem" if kid >= 300000 else ("conv1x1" if kid >= 200000 else ("conv3x3" if kid >= 30000 else "conv_other"))
         self.bracket(cls, kid, flops, in_b + out_b + res_b + w_b,

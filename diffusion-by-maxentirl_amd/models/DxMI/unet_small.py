@@ -81,6 +81,14 @@ class AttnBlock(nn.Module):
         self.proj_out = _conv(in_channels, in_channels, 1)
 
 
+class _Normed:
+    """A tensor's GroupNorm(+SiLU) for one specific reader, written by its producer's epilogue (ops.conv2d fuse_gn)."""
+    __slots__ = ("y", "norm")
+
+    def __init__(self, y, norm):
+        self.y, self.norm = y, norm
+
+
 class Model(nn.Module):
     def __init__(self, *, ch, out_ch, ch_mult=(1, 2, 4, 8), num_res_blocks, attn_resolutions, dropout=0.0,
                  resamp_with_conv=True, in_channels, resolution):
@@ -216,6 +224,7 @@ class Model(nn.Module):
     # Activations on maps of >= STREAM_GN_MIN_HW pixels travel as (tensor, BlockStats): the producing conv's epilogue writes the
     # GroupNorm block statistics of what it stores, so every Normalize() on them is one streaming read + write
     # (ops.groupnorm_apply).  Smaller maps (8x8, 4x4: 8 % of the GroupNorm bytes) keep the one-pass resident kernel.
+    FUSE_GN_SMALL = True              # norm2 of the 4x4 ResnetBlocks from conv1's epilogue (instance override: A-B timing)
     STREAM_GN_MIN_HW = 256            # instance attribute override (tests / A-B timing): 1 << 30 = one-pass GroupNorm everywhere
 
     def _conv_s(self, x, pw, **kw):
@@ -226,14 +235,28 @@ class Model(nn.Module):
             st = ops.block_stats(out)
         return out, st
 
-    def _resblock(self, pk, b, x0, x1, tp, s0=None, s1=None):
+    def _resblock(self, pk, b, x0, x1, tp, s0=None, s1=None, nxt=None):
         """GN+SiLU -> conv1(+bias+temb) -> GN+SiLU -> conv2(+bias+shortcut); x = [x0 | x1] virtual concat; s0 / s1 their block
-        statistics (None: one-pass GroupNorm).  Returns (h, BlockStats | None)."""
-        a = ops.groupnorm_silu(x0, b.norm1.weight, b.norm1.bias, in1=x1, eps=1e-6, silu=True, stats=(s0, s1))
+        statistics (None: one-pass GroupNorm) or, for s0, a _Normed(x0) some producer's epilogue already wrote for norm1.
+        nxt = (GroupNorm module, silu) of the ONLY-normalising next reader of the output: where conv2's kernel can, it writes that
+        normalisation too.  Returns (h, BlockStats | _Normed | None)."""
+        if isinstance(s0, _Normed):
+            assert s0.norm is b.norm1 and x1 is None
+            a0 = s0.y
+        else:
+            a0 = ops.groupnorm_silu(x0, b.norm1.weight, b.norm1.bias, in1=x1, eps=1e-6, silu=True, stats=(s0, s1))
         off = pk[id(b), "toff"]
         stream = x0.shape[1] * x0.shape[2] >= self.STREAM_GN_MIN_HW
-        h, sh = ops.conv2d(a, pk[id(b), "conv1"], bias=b.conv1.bias, addvec=tp[:, off:off + b.out_channels], want_stats=True)
-        a = ops.groupnorm_silu(h, b.norm2.weight, b.norm2.bias, eps=1e-6, silu=True, stats=(sh, None))
+        a = None
+        if not stream and self.FUSE_GN_SMALL:
+            # 4x4 maps: conv1's epilogue normalises its own output (whole images and groups per tile); h has no other reader
+            h, a = ops.conv2d(a0, pk[id(b), "conv1"], bias=b.conv1.bias, addvec=tp[:, off:off + b.out_channels],
+                              fuse_gn=(b.norm2.weight, b.norm2.bias, 32, 1e-6, True, False))
+            sh = None
+        else:
+            h, sh = ops.conv2d(a0, pk[id(b), "conv1"], bias=b.conv1.bias, addvec=tp[:, off:off + b.out_channels], want_stats=True)
+        if a is None:
+            a = ops.groupnorm_silu(h, b.norm2.weight, b.norm2.bias, eps=1e-6, silu=True, stats=(sh, None))
         if b.in_channels != b.out_channels:
             sc_mod = b.conv_shortcut if b.use_conv_shortcut else b.nin_shortcut
             sc = ops.conv2d(x0, pk[id(b), "short"], in1=x1, bias=sc_mod.bias)
@@ -242,11 +265,19 @@ class Model(nn.Module):
             sc = x0
         if stream:
             return self._conv_s(a, pk[id(b), "conv2"], bias=b.conv2.bias, residual=sc)
+        if nxt is not None and self.FUSE_GN_SMALL:
+            h, y = ops.conv2d(a, pk[id(b), "conv2"], bias=b.conv2.bias, residual=sc,
+                              fuse_gn=(nxt[0].weight, nxt[0].bias, 32, 1e-6, nxt[1], True))
+            return h, (None if y is None else _Normed(y, nxt[0]))
         return ops.conv2d(a, pk[id(b), "conv2"], bias=b.conv2.bias, residual=sc), None
 
     def _attn(self, pk, m, x, sx=None):
         N, H, W, C = x.shape
-        hn = ops.groupnorm_silu(x, m.norm.weight, m.norm.bias, eps=1e-6, silu=False, stats=(sx, None))
+        if isinstance(sx, _Normed):
+            assert sx.norm is m.norm
+            hn = sx.y
+        else:
+            hn = ops.groupnorm_silu(x, m.norm.weight, m.norm.bias, eps=1e-6, silu=False, stats=(sx, None))
         qkv = ops.conv2d(hn, pk[id(m), "qkv"], bias=pk[id(m), "qkv_bias"])
         a = ops.attention(qkv.view(N, H * W, 3 * C), heads=1, scale=float(int(C) ** (-0.5)))
         if H * W >= self.STREAM_GN_MIN_HW:
@@ -300,7 +331,15 @@ class Model(nn.Module):
         tr("conv_in", h)
         for i_level, lvl in enumerate(self.down):
             for i_block, blk in enumerate(lvl.block):
-                h, sh = self._resblock(pk, blk, hs[-1][0], None, tp, s0=hs[-1][1])
+                # the output's next normalising reader (the skip connection reads it raw): the level's next block, or
+                # mid.block_1 after the last level
+                nxt = None
+                if len(lvl.attn) == 0:
+                    if i_block + 1 < len(lvl.block):
+                        nxt = (lvl.block[i_block + 1].norm1, True)
+                    elif i_level == self.num_resolutions - 1:
+                        nxt = (self.mid.block_1.norm1, True)
+                h, sh = self._resblock(pk, blk, hs[-1][0], None, tp, s0=hs[-1][1], nxt=nxt)
                 tr(f"down.{i_level}.block.{i_block}", h)
                 if len(lvl.attn) > 0:
                     h, sh = self._attn(pk, lvl.attn[i_block], h, sh)
@@ -312,7 +351,7 @@ class Model(nn.Module):
                 tr(f"down.{i_level}.downsample", hs[-1][0])
 
         h, sh = hs[-1]
-        h, sh = self._resblock(pk, self.mid.block_1, h, None, tp, s0=sh)
+        h, sh = self._resblock(pk, self.mid.block_1, h, None, tp, s0=sh, nxt=(self.mid.attn_1.norm, False))
         tr("mid.block_1", h)
         h, sh = self._attn(pk, self.mid.attn_1, h, sh)
         tr("mid.attn_1", h)
@@ -323,6 +362,8 @@ class Model(nn.Module):
             lvl = self.up[i_level]
             for i_block, blk in enumerate(lvl.block):
                 skip, sskip = hs.pop()
+                if isinstance(sskip, _Normed):      # normalised for the down path's reader: the concat's norm1 takes the raw tensor
+                    sskip = None
                 h, sh = self._resblock(pk, blk, h, skip, tp, s0=sh, s1=sskip)  # cat(h, skip) is never materialised
                 tr(f"up.{i_level}.block.{i_block}", h)
                 if len(lvl.attn) > 0:

@@ -90,9 +90,22 @@ typedef struct dxmi_conv_desc {
                                 values over the pixels of partial p of the image, per PAIR of consecutive channels, summed in a
                                 fixed order inside the conv's epilogue (bitwise reproducible).  P = dxmi_conv2d_gn_stats_partials(d);
                                 NULL = not wanted.  Setting it for a shape whose kernel cannot produce them is DXMI_EINVAL. */
+    /* optional: GroupNorm(+SiLU) of the conv's OUTPUT fused into its epilogue, for shapes whose workgroup tile holds whole
+       images and whole groups (the 4x4 maps of the U-Net: Normalize()+nonlinearity of the next layer, unet_small.py:119-126):
+       gn_out = silu?(group_norm(round_bf16(out))) with statistics in fp32 (two-pass, from registers), bitwise independent of
+       the batch.  gn_out NULL = off.  dxmi_conv2d_gn_fuse_supported(d) says whether the selected kernel can; setting it for a
+       shape that cannot is DXMI_EINVAL. */
+    void*        gn_out;     /* NHWC bf16 [N,OH,OW,Cout] */
+    const float* gn_gamma;   /* [Cout] */
+    const float* gn_beta;    /* [Cout] */
+    float        gn_eps;
+    int32_t      gn_groups;  /* Cout / gn_groups must be 8 */
+    int32_t      gn_flags;   /* bit 0: SiLU after the affine; bit 1: do not write `out` (the raw tensor has no other reader) */
 } dxmi_conv_desc;
 
 int dxmi_conv2d_fwd(const dxmi_conv_desc* d, void* stream);
+/* 1 when the kernel dxmi_conv2d_fwd would launch for `d` can fuse the GroupNorm of its output (gn_out ...), else 0. */
+int dxmi_conv2d_gn_fuse_supported(const dxmi_conv_desc* d);
 /* Partials per image (P above) the kernel dxmi_conv2d_fwd would launch for `d` writes into d->gn_stats; 0 = that kernel
  * does not produce block statistics (use dxmi_gn_block_stats on its output, or the one-pass dxmi_groupnorm_silu_fwd). */
 int dxmi_conv2d_gn_stats_partials(const dxmi_conv_desc* d);

@@ -259,3 +259,70 @@ def test_groupnorm_apply_scale_shift_and_fold(ops):
     f = ops.fold_stats(ops.BlockStats(raw, 512))
     assert f.P == 1 and torch.allclose(f.buf[:, 0], raw.sum(1), rtol=1e-5, atol=1e-4)
     assert torch.equal(f.buf, ops.fold_stats(ops.BlockStats(raw, 512)).buf)
+
+
+# -------------------------------------------------------------------------- GroupNorm of the conv's output from its own epilogue
+@pytest.mark.parametrize("N,C0,C1,res,silu", [(37, 256, 0, False, True), (8, 256, 256, True, False), (300, 256, 0, True, True)])
+def test_conv_sm_fused_groupnorm(ops, N, C0, C1, res, silu):
+    """dxmi_conv_desc.gn_out: GroupNorm(+SiLU) of a 4x4 conv's output from conv_sm_kernel's epilogue (Normalize() + nonlinearity
+    of the next layer, reference unet_small.py:119-126) against the separate GroupNorm launch and torch fp32."""
+    Cout = 256
+    g = torch.Generator().manual_seed(11 + N)
+    x0 = torch.randn(N, 4, 4, C0, generator=g).to(torch.bfloat16).to(DEV)
+    x1 = torch.randn(N, 4, 4, C1, generator=g).to(torch.bfloat16).to(DEV) if C1 else None
+    w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) * 0.03).to(DEV)
+    pw = ops.pack_conv_weight(w)
+    bv = torch.randn(Cout, generator=g).to(DEV)
+    tv = torch.randn(N, Cout, generator=g).to(DEV)
+    r = torch.randn(N, 4, 4, Cout, generator=g).to(torch.bfloat16).to(DEV) if res else None
+    gamma = (1 + 0.3 * torch.randn(Cout, generator=g)).to(DEV)
+    beta = (0.3 * torch.randn(Cout, generator=g)).to(DEV)
+    kw = dict(in1=x1, bias=bv, addvec=tv, residual=r)
+    raw = ops.conv2d(x0, pw, **kw)
+    out, y = ops.conv2d(x0, pw, fuse_gn=(gamma, beta, 32, 1e-6, silu, True), **kw)
+    assert y is not None and torch.equal(out, raw)                  # the raw tensor is unchanged by the fusion
+    none, y2 = ops.conv2d(x0, pw, fuse_gn=(gamma, beta, 32, 1e-6, silu, False), **kw)
+    assert none is None and torch.equal(y, y2)
+    # against the separate launch on the same stored tensor: same formula, statistics summed in another order -> bf16 ulps
+    sep = ops.groupnorm_silu(raw, gamma, beta, groups=32, eps=1e-6, silu=silu)
+    d = (y.float() - sep.float()).abs()
+    assert d.max().item() <= 2 ** -6 * max(1.0, sep.float().abs().max().item()) and (d > 0).float().mean().item() < 0.02
+    # against torch fp32 on the stored tensor
+    ref = F.group_norm(raw.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-6)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    assert ((y.float() - ref).norm() / ref.norm()).item() < 3e-3
+    # bitwise independent of the batch
+    for i in {0, N // 2, N - 1}:
+        _, one = ops.conv2d(x0[i:i + 1].contiguous(), pw, in1=None if x1 is None else x1[i:i + 1].contiguous(), bias=bv,
+                            addvec=tv[i:i + 1].contiguous(), residual=None if r is None else r[i:i + 1].contiguous(),
+                            fuse_gn=(gamma, beta, 32, 1e-6, silu, False))
+        assert torch.equal(one[0], y[i]), i
+
+
+def test_conv_fused_groupnorm_unsupported_shape(ops):
+    """8x8 maps (an image spans two DPP rows ... and conv_ws8 serves them): ops returns y None; the raw C-ABI call is an error."""
+    import ctypes
+    from dxmi_hip import _lib
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 8, 8, 256, generator=g).to(torch.bfloat16).to(DEV)
+    pw = ops.pack_conv_weight((torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(DEV))
+    gamma, beta = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
+    out, y = ops.conv2d(x, pw, fuse_gn=(gamma, beta, 32, 1e-6, True, False))
+    assert y is None and out is not None
+    d = _lib.ConvDesc()
+    yb = torch.empty_like(out)
+    d.in0, d.wpacked, d.out = x.data_ptr(), pw.buf.data_ptr(), out.data_ptr()
+    d.N, d.IH, d.IW, d.C0, d.C1, d.OH, d.OW, d.Cout = 4, 8, 8, 256, 0, 8, 8, 256
+    d.ksize, d.stride, d.pad = 3, 1, 1
+    d.gn_out, d.gn_gamma, d.gn_beta, d.gn_eps, d.gn_groups, d.gn_flags = yb.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-6, 32, 1
+    lib = _lib.load()
+    assert lib.dxmi_conv2d_gn_fuse_supported(ctypes.byref(d)) == 0
+    assert lib.dxmi_conv2d_fwd(ctypes.byref(d), None) != 0
+    assert b"GroupNorm" in lib.dxmi_last_error()
+    d.gn_groups = 16          # 16 channels per group: not the fused layout either
+    d.IH = d.IW = d.OH = d.OW = 4
+    assert lib.dxmi_conv2d_gn_fuse_supported(ctypes.byref(d)) == 0
+    d.gn_groups = 32
+    assert lib.dxmi_conv2d_gn_fuse_supported(ctypes.byref(d)) == 1
