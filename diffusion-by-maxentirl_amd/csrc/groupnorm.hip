@@ -339,9 +339,12 @@ struct GnApplyArgs {
     int silu;
 };
 
+constexpr int GN_APPLY_MAXP = 8;        // partials per image the prologue keeps in flight (ops.MAX_APPLY_PARTIALS folds larger P)
+
 template <int U>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
     __shared__ float mean_s[32], rstd_s[32];
+    __shared__ float2 pair_s[1024];                 // C <= 2048
     const int C = p.C0 + p.C1, c8n = C >> 3;
     const int n = blockIdx.x / p.chunks, chunk = blockIdx.x - n * p.chunks;
     const int tid = threadIdx.x;
@@ -365,20 +368,47 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
             if (rr < row1) v[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)rr * Cs);
         }
     }
+    // statistics prologue, one memory latency deep: every thread sums the <= GN_APPLY_MAXP partials of one channel pair (all
+    // loads in flight together, added in partial order), then 32 threads add each group's pairs in channel order through LDS
+    auto pair_sums = [&](const float* st, int P, int nbs, int off) {        // uniform base + 32-bit lane offsets
+        const float2* const base = reinterpret_cast<const float2*>(st) + (size_t)n * P * nbs;
+        for (int b = tid; b < nbs; b += 256) {
+            float2 t[GN_APPLY_MAXP];
+#pragma unroll
+            for (int k = 0; k < GN_APPLY_MAXP; ++k)
+                if (k < P) t[k] = base[(unsigned)(k * nbs + b)];
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int k = 0; k < GN_APPLY_MAXP; ++k)
+                if (k < P) {
+                    s += t[k].x;
+                    q += t[k].y;
+                }
+            for (int k = GN_APPLY_MAXP; k < P; ++k) {       // more partials than the host folds to: correct, just serial
+                const float2 tk = base[(unsigned)(k * nbs + b)];
+                s += tk.x;
+                q += tk.y;
+            }
+            pair_s[off + b] = make_float2(s, q);
+        }
+    };
+    pair_sums(p.st0, p.P0, p.C0 >> 1, 0);
+    if (p.C1) pair_sums(p.st1, p.P1, p.C1 >> 1, p.C0 >> 1);
+    __syncthreads();
+    // gamma / beta are requested before the group reduction (the partials' registers are free again)
+    f32x4 g0, g1, b0, b1;
+    if (active) {
+        g0 = *reinterpret_cast<const f32x4*>(p.gamma + c);
+        g1 = *reinterpret_cast<const f32x4*>(p.gamma + c + 4);
+        b0 = *reinterpret_cast<const f32x4*>(p.beta + c);
+        b1 = *reinterpret_cast<const f32x4*>(p.beta + c + 4);
+    }
     if (tid < p.groups) {
-        // group tid = channel pairs [tid*cpg/2, (tid+1)*cpg/2) of the virtual concat, each from one source's statistics
-        const int bpg = p.cpg >> 1, nb0 = p.C0 >> 1;
+        const int bpg = p.cpg >> 1;
         float s = 0.f, q = 0.f;
         for (int b = tid * bpg; b < (tid + 1) * bpg; ++b) {
-            const bool f0 = b < nb0;
-            const float* st = f0 ? p.st0 : p.st1;
-            const int P = f0 ? p.P0 : p.P1, nbs = f0 ? nb0 : (p.C1 >> 1), bl = f0 ? b : b - nb0;
-            const float2* sp = reinterpret_cast<const float2*>(st) + (size_t)n * P * nbs + bl;
-            for (int k = 0; k < P; ++k) {
-                const float2 t = sp[(size_t)k * nbs];
-                s += t.x;
-                q += t.y;
-            }
+            s += pair_s[b].x;
+            q += pair_s[b].y;
         }
         const float cnt = (float)p.HW * (float)p.cpg;
         const float m = s / cnt;
@@ -389,8 +419,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
     if (!active) return;
     float A[8], Bv[8];
     {
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gamma + c), g1 = *reinterpret_cast<const f32x4*>(p.gamma + c + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.beta + c), b1 = *reinterpret_cast<const f32x4*>(p.beta + c + 4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int g = (c + e) / p.cpg;
