@@ -395,31 +395,48 @@ __global__ __launch_bounds__(512) void conv_wgrad_ws_kernel(WgradArgs p, const c
 // sum the S partials in a fixed order -> OIHW fp32 gradient (optionally accumulated).  Four consecutive ci per thread (16-byte
 // loads of every partial); the trailing blocks of the same launch fold the bias-gradient partials (bpart [S*4][Cout]) in a
 // fixed order too, so a weight gradient with bias is two launches, not three.
+// SL: slices of the S partials per block (a block handles 256 / SL positions): 4 for the U-Net layers (S <= 64, thousands of
+// positions), 16 for the 64-channel value-network layers, where S = 256 partials of only 36 864 positions left 145 workgroups
+// adding 64 partials per thread in sequence (round-3 train trace: 60 us per launch, 12 % of all weight-gradient time).
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S, int taps, int Cout,
                                                            int Cin, int accumulate, const float* __restrict__ bpart, float* __restrict__ dbias,
                                                            int wblocks) {
+    constexpr int NP = 256 / SL;
     if ((int)blockIdx.x >= wblocks) {
-        // bias: one thread per cout, S * 4 partial rows
-        const int co = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
+        // bias: 16 couts x 16 slices of the S * 4 partial rows per block; slice sums added in slice order through LDS (one
+        // thread per cout walking all rows in sequence was the long pole of the whole launch: S * 4 dependent L2 latencies)
+        __shared__ float bs[15][16];
+        const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+        const int co = ((int)blockIdx.x - wblocks) * 16 + cl;
+        const int K = S * 4;
+        float t = 0.f;
         if (co < Cout) {
-            float t = 0.f;
-            for (int k = 0; k < S * 4; ++k) t += bpart[(size_t)k * Cout + co];
+            const int k0 = (K * sl) >> 4, k1 = (K * (sl + 1)) >> 4;
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k) t += bpart[(size_t)k * Cout + co];
+        }
+        if (sl > 0) bs[sl - 1][cl] = t;
+        __syncthreads();
+        if (sl == 0 && co < Cout) {
+#pragma unroll
+            for (int j = 0; j < 15; ++j) t += bs[j][cl];
             dbias[co] = accumulate ? dbias[co] + t : t;
         }
         return;
     }
-    // 64 positions (of four consecutive ci) x 4 slices of the S partials per block: a thread adds its slice's partials in
-    // order, the four slice sums are added in order through LDS (one thread per position looping over all S partials ran at
-    // 1.3 TB/s — too few loads in flight; round-3 train profile: 7 ms per step, as much as the weight-gradient kernel itself)
-    __shared__ f32x4 sm[3][64];
+    // NP positions (of four consecutive ci) x SL slices of the S partials per block: a thread adds its slice's partials in
+    // order, the slice sums are added in order through LDS (one thread per position looping over all S partials ran at
+    // 1.3 TB/s — too few loads in flight)
+    __shared__ f32x4 sm[SL - 1][NP];
     const long total = (long)taps * Cout * Cin;
-    const int px = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const long idx = ((long)blockIdx.x * 64 + px) * 4;
+    const int px = threadIdx.x % NP, sl = threadIdx.x / NP;
+    const long idx = ((long)blockIdx.x * NP + px) * 4;
     const bool live = idx < total;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (live) {
-        const int k0 = (S * sl) >> 2, k1 = (S * (sl + 1)) >> 2;
-#pragma unroll 4
+        const int k0 = (S * sl) / SL, k1 = (S * (sl + 1)) / SL;
+#pragma unroll 8
         for (int k = k0; k < k1; ++k) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (size_t)k * total + idx);
             s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
@@ -429,7 +446,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     __syncthreads();
     if (sl != 0 || !live) return;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < SL - 1; ++j) {
         const f32x4 v = sm[j][px];
         s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
@@ -584,10 +601,16 @@ static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, co
 #undef DXMI_WG_LAUNCH
     DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad");
     const long total = (long)ksize * ksize * Cout * Cin;
-    const int wblocks = (int)((total / 4 + 63) / 64);
-    const int bblocks = dbias ? (Cout + 255) / 256 : 0;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, (const float*)workspace, dw_oihw, S,
-                       ksize * ksize, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks);
+    const bool wide = S >= 64;                 // 16 slices of the partials per block (value-network layers)
+    const int np = wide ? 16 : 64;
+    const int wblocks = (int)((total / 4 + np - 1) / np);
+    const int bblocks = dbias ? (Cout + 15) / 16 : 0;
+    if (wide)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, (const float*)workspace, dw_oihw, S,
+                           ksize * ksize, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, (const float*)workspace, dw_oihw, S,
+                           ksize * ksize, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks);
     DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad(reduce)");
     return DXMI_OK;
 }
