@@ -16,7 +16,7 @@
 //
 // Reference: AttnBlock.forward models/DxMI/unet_small.py:175-187 (scale C^-0.5, softmax over
 // keys); QKVAttentionLegacy models/cm/unet.py:413-441.
-#include "common.h"
+#include "conv_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -30,6 +30,11 @@ struct AttnArgs {
     int N, T, C, heads;
     int q_off, k_off, v_off, head_stride;  // channel offsets inside the 3C-wide row
     float scale;
+    // attention256_kernel<true>: proj_out (1x1 conv 256 -> 256) + bias + residual fused behind the attention
+    const bf16* wproj;      // packed by dxmi_pack_attn_proj_weight: [8 cout blocks][16 k-steps][64 lanes][8]
+    const float* pbias;     // [256]
+    const bf16* res;        // [N,256,256] (the AttnBlock's input x)
+    float* gn_stats;        // optional: GroupNorm block statistics of the output, [N][8][128][2] (a partial per 32 tokens)
 };
 
 template <int D>
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
 __device__ __forceinline__ void at_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int at_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
+template <bool PROJ>
 __global__ __launch_bounds__(512, 1) void attention256_kernel(AttnArgs p) {
     constexpr int SLOT = 64 * 512;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -252,6 +258,8 @@ __global__ __launch_bounds__(512, 1) void attention256_kernel(AttnArgs p) {
             __builtin_amdgcn_global_load_lds(AT_GPTR(g), AT_LPTR(smem + slot * SLOT + (wave * 4 + i) * 1024), 16, 0, 0);
         }
     };
+    if (PROJ && wave == 0)      // bias[256] -> LDS behind the ring (1 KiB, oldest DMA of wave 0)
+        __builtin_amdgcn_global_load_lds(AT_GPTR(p.pbias + lane * 4), AT_LPTR(smem + 4 * SLOT), 16, 0, 0);
 #pragma unroll
     for (int b = 0; b < 4; ++b) issue_block(b, b);
     AT_WAIT_VM(0);
@@ -324,12 +332,27 @@ __global__ __launch_bounds__(512, 1) void attention256_kernel(AttnArgs p) {
     const int trg = lane >> 4, trq = (lane & 15) >> 2, trp = lane & 3;
     const int tr_krow = 4 * (trg >> 1) + trq;
     const int tr_c = 2 * (trg & 1) + (trp >> 1), tr_sub = 8 * (trp & 1);
+    // PROJ: the first half of the packed proj_out weights (cout blocks 0..3: 64 one-KiB fragments) follows V(0), V(1) into
+    // their slots; wave w moves fragments 4w..4w+3 of a slot
+    auto issue_w = [&](int half, int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = wave * 4 + i;
+            const char* g = reinterpret_cast<const char*>(p.wproj) + (size_t)((half * 2 + slot) * 32 + f) * 1024 + lane * 16;
+            __builtin_amdgcn_global_load_lds(AT_GPTR(g), AT_LPTR(smem + slot * SLOT + f * 1024), 16, 0, 0);
+        }
+    };
 #pragma unroll
     for (int vb = 0; vb < 4; ++vb) {
-        if (vb == 0) AT_WAIT_VM(12);
-        else if (vb == 1) AT_WAIT_VM(8);
-        else if (vb == 2) AT_WAIT_VM(4);
-        else AT_WAIT_VM(0);
+        if (PROJ) {             // younger than V(vb): V(vb+1..3) and the weight fragments issued so far
+            if (vb == 3) AT_WAIT_VM(8);
+            else AT_WAIT_VM(12);
+        } else {
+            if (vb == 0) AT_WAIT_VM(12);
+            else if (vb == 1) AT_WAIT_VM(8);
+            else if (vb == 2) AT_WAIT_VM(4);
+            else AT_WAIT_VM(0);
+        }
         at_barrier();
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
@@ -348,8 +371,129 @@ __global__ __launch_bounds__(512, 1) void attention256_kernel(AttnArgs p) {
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[vb * 4 + st], o[db], 0, 0, 0);
             }
         }
+        if (PROJ && vb < 2) {
+            at_barrier();       // every wave is done with V(vb): its slot takes weight fragments
+            issue_w(0, vb);
+        }
     }
     at_barrier();       // every wave is done with the V images: the ring becomes the output tile
+    if constexpr (PROJ) {
+        // ---- Y^T[cout][query] = Wp . O^T (+ bias + x): O^T stays in registers as the B operand — k-step j of the product takes
+        // the lane's accumulator registers 8 (j & 1) .. + 7 of o[j >> 1] as they stand (channels 16 j + 8 (i >> 2) + 4 h + (i & 3)),
+        // and the packed weights carry the same channel order (dxmi_pack_attn_proj_weight).  Two halves of 128 couts: weights in
+        // slots 0-1, the residual / output tile of the half (wave-private 32 rows x 256 B, swizzled like the Q / K / V rows) in
+        // slots 2-3.  Same values as the unfused path: O rounded to bf16, fp32 accumulation, one rounding of y + bias + x.
+        const float inv = 1.f / l;
+        char* const rbase = smem + 2 * SLOT + wave * 8192;
+        const bf16* const xrows = p.res + ((size_t)n * 256 + wave * 32) * 256;
+        bf16* const orows = p.out + ((size_t)n * 256 + wave * 32) * 256;
+        const int rrow = lane >> 4, rslot = lane & 15;
+        auto issue_res = [&](int half) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = 4 * i + rrow;
+                const bf16* g = xrows + (size_t)r * 256 + half * 128 + ((rslot ^ at_swz(r)) << 3);
+                __builtin_amdgcn_global_load_lds(AT_GPTR(g), AT_LPTR(rbase + i * 1024), 16, 0, 0);
+            }
+        };
+        issue_res(0);
+        bf16x8 of[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) of[j][i] = (bf16)(o[j >> 1][8 * (j & 1) + i] * inv);
+        const int r = lane & 31, sw = at_swz(r);
+        const float* const bias_s = reinterpret_cast<const float*>(smem + 4 * SLOT);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // in-order retirement: weights of this half are older than the 8 residual DMAs (+ 8 row stores of half 0)
+            if (half == 0) AT_WAIT_VM(8);
+            else if (p.gn_stats) AT_WAIT_VM(18);        // + the two statistics stores of half 0
+            else AT_WAIT_VM(16);
+            at_barrier();
+            f32x16 y[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) y[cb][q] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + (cb * 16 + j) * 1024 + lane * 16);
+                    y[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, of[j], y[cb], 0, 0, 0);
+                }
+            }
+            if (half == 0) {
+                at_barrier();       // every wave is done with the first half of the weights
+                issue_w(1, 0);
+                issue_w(1, 1);
+                AT_WAIT_VM(8);      // the residual rows of half 0 are older than those 8
+            } else {
+                AT_WAIT_VM(0);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    char* const a = rbase + r * 256 + (((cb * 4 + g) ^ sw) << 4) + 8 * h;
+                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_s + half * 128 + cb * 32 + g * 8 + 4 * h);
+                    bf16x4 ov;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = (bf16)(y[cb][4 * g + e] + (bv[e] + (float)rv[e]));
+                    *reinterpret_cast<bf16x4*>(a) = ov;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            {
+                bf16x8 v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const bf16x8*>(rbase + i * 1024 + lane * 16);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int rr = 4 * i + rrow;
+                    *reinterpret_cast<bf16x8*>(orows + (size_t)rr * 256 + half * 128 + ((rslot ^ at_swz(rr)) << 3)) = v[i];
+                }
+            }
+            if (p.gn_stats) {
+                // block statistics of the stored values: lane (16-byte piece sp, row group rg) adds its piece over 8 rows, the
+                // four row groups are added in a fixed order; one partial per wave (32 tokens)
+                const int sp = lane & 15, rg = lane >> 4;
+                float st[4][4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) st[k][e] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int rr = rg * 8 + t;
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(rbase + rr * 256 + ((sp ^ at_swz(rr)) << 4));
+                    const bf16x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+                    dxmi_stats4(lo, st[t & 1 ? 2 : 0]);
+                    dxmi_stats4(hi, st[t & 1 ? 3 : 1]);
+                }
+                float tot[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    tot[e] = st[0][e] + st[2][e];
+                    tot[4 + e] = st[1][e] + st[3][e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    tot[e] += __shfl_xor(tot[e], 16, 64);
+                    tot[e] += __shfl_xor(tot[e], 32, 64);
+                }
+                if (lane < 16) {
+                    float* sd = p.gn_stats + (((size_t)n * 8 + wave) * 128 + half * 64 + sp * 4) * 2;
+                    *reinterpret_cast<f32x4*>(sd) = f32x4{tot[0], tot[1], tot[2], tot[3]};
+                    *reinterpret_cast<f32x4*>(sd + 4) = f32x4{tot[4], tot[5], tot[6], tot[7]};
+                }
+            }
+            if (half == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the rows are in registers: the region takes half 1's x
+                issue_res(1);
+            }
+        }
+        return;
+    }
 
     // ---- O / l -> bf16 -> LDS rows (query-major, same swizzle) -> whole-row stores
     const float inv = 1.f / l;
@@ -385,12 +529,26 @@ __global__ __launch_bounds__(512, 1) void attention256_kernel(AttnArgs p) {
 int launch_attn256(const AttnArgs& a, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention256_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention256_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention256_kernel, dim3(a.N), dim3(512), (size_t)4 * 64 * 512, st, a);
+    if (a.wproj) hipLaunchKernelGGL(attention256_kernel<true>, dim3(a.N), dim3(512), (size_t)4 * 64 * 512 + 1024, st, a);
+    else hipLaunchKernelGGL(attention256_kernel<false>, dim3(a.N), dim3(512), (size_t)4 * 64 * 512, st, a);
     DXMI_CHECK_LAUNCH("dxmi_attention_fwd(256x256)");
     return DXMI_OK;
+}
+
+// proj_out weight [256 cout][256 cin] fp32 -> bf16 MFMA A fragments in the channel order attention256_kernel<true> holds O^T in:
+// fragment (cb, j), lane l, element i = W[32 cb + (l & 31)][16 j + 8 (i >> 2) + 4 (l >> 5) + (i & 3)]
+__global__ __launch_bounds__(256) void pack_attn_proj_kernel(const float* __restrict__ w, bf16* __restrict__ dst) {
+    const int t = blockIdx.x * 256 + threadIdx.x;       // one (fragment, lane) per thread: 8 * 16 * 64 threads
+    const int l = t & 63, j = (t >> 6) & 15, cb = t >> 10;
+    const float* row = w + (size_t)(32 * cb + (l & 31)) * 256 + 16 * j + 4 * (l >> 5);
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (bf16)row[8 * (i >> 2) + (i & 3)];
+    *reinterpret_cast<bf16x8*>(dst + (size_t)t * 8) = o;
 }
 
 template <int D>
@@ -410,6 +568,27 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int dxmi_pack_attn_proj_weight(const float* w, void* dst, void* stream) {
+    DXMI_CHECK_ARG(w && dst, "dxmi_pack_attn_proj_weight: null pointer");
+    hipLaunchKernelGGL(pack_attn_proj_kernel, dim3(32), dim3(256), 0, (hipStream_t)stream, w, (bf16*)dst);
+    DXMI_CHECK_LAUNCH("dxmi_pack_attn_proj_weight");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_attention_proj_supported(int32_t T, int32_t C, int32_t heads) { return T == 256 && C == 256 && heads == 1 ? 1 : 0; }
+
+extern "C" int dxmi_attention_proj_fwd(const void* qkv, const void* wproj_packed, const float* bias, const void* residual, void* out,
+                                       float* gn_stats, int32_t N, int32_t T, int32_t C, int32_t heads, float scale, void* stream) {
+    DXMI_CHECK_ARG(qkv && wproj_packed && bias && residual && out, "dxmi_attention_proj_fwd: null pointer");
+    DXMI_CHECK_ARG(N > 0 && dxmi_attention_proj_supported(T, C, heads),
+                   "dxmi_attention_proj_fwd: only the single-head 256-token x 256-channel block (N=%d T=%d C=%d heads=%d)", N, T, C, heads);
+    AttnArgs a;
+    a.qkv = (const bf16*)qkv; a.out = (bf16*)out; a.N = N; a.T = T; a.C = C; a.heads = heads;
+    a.q_off = 0; a.k_off = C; a.v_off = 2 * C; a.head_stride = C; a.scale = scale;
+    a.wproj = (const bf16*)wproj_packed; a.pbias = bias; a.res = (const bf16*)residual; a.gn_stats = gn_stats;
+    return launch_attn256(a, (hipStream_t)stream);
+}
+
 extern "C" int dxmi_attention_fwd(const void* qkv, void* out, int32_t N, int32_t T, int32_t C, int32_t heads,
                                   float scale, void* stream) {
     DXMI_CHECK_ARG(qkv && out, "dxmi_attention_fwd: null pointer");
@@ -418,6 +597,7 @@ extern "C" int dxmi_attention_fwd(const void* qkv, void* out, int32_t N, int32_t
     AttnArgs a;
     a.qkv = (const bf16*)qkv; a.out = (bf16*)out; a.N = N; a.T = T; a.C = C; a.heads = heads;
     a.q_off = 0; a.k_off = C; a.v_off = 2 * C; a.head_stride = D; a.scale = scale;
+    a.wproj = nullptr; a.pbias = nullptr; a.res = nullptr; a.gn_stats = nullptr;
     hipStream_t st = (hipStream_t)stream;
     static const int v1 = getenv("DXMI_ATTN_GENERIC") ? atoi(getenv("DXMI_ATTN_GENERIC")) : 0;   // 1: generic kernel for every shape
     if (D == 256 && T == 256 && heads == 1 && !v1) return launch_attn256(a, st);

@@ -486,7 +486,9 @@ extern "C" int dxmi_conv2d_gn_fuse_supported(const dxmi_conv_desc* d) {
     q.gn_out = nullptr;
     if (q.variant != 0 || q.out_mode != DXMI_OUT_NHWC_BF16 || d->gn_groups <= 0 || d->Cout != 8 * d->gn_groups) return 0;
     const int rc = conv2d_impl(&q, nullptr, &id);
-    return rc == DXMI_OK && id == 450432 ? 1 : 0;      // conv_sm_kernel<2, 8, 32>: eight whole 4x4 images x 32 couts per tile
+    if (rc != DXMI_OK) return 0;
+    if (id == 450432) return 1;                        // conv_sm_kernel<2, 8, 32>: eight whole 4x4 images x 32 couts per tile
+    return id == 400008 && (d->gn_flags & 2) ? 1 : 0;  // conv_ws8_kernel: a whole 8x8 image per wave, instead of the raw output
 }
 
 // Which template instantiation dxmi_conv2d_fwd would launch for this descriptor (no launch):

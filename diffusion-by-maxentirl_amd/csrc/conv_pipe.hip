@@ -646,8 +646,10 @@ int conv_sm_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);      // con
 int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     {
         int rc = 1;
-        if (a.gn_out) {          // only conv_sm_kernel fuses the GroupNorm of its output
+        if (a.gn_out) {          // conv_sm_kernel (4x4 maps) and conv_ws8_kernel (8x8, instead of the raw output) fuse the GroupNorm of their output
             rc = conv_sm_try_launch(a, st, kernel_id);
+            if (rc <= 0) return rc;
+            rc = conv_ws8_try_launch(a, st, kernel_id);
             if (rc <= 0) return rc;
             DXMI_CHECK_ARG(false, "dxmi_conv2d_fwd: the kernel for this shape cannot fuse the GroupNorm of its output "
                                   "(dxmi_conv2d_gn_fuse_supported returns 0 for it)");

@@ -65,6 +65,10 @@ struct W8Tile {
     int cot, n0;
 };
 
+// GN: GroupNorm(+SiLU) of the output written INSTEAD of the raw output (dxmi_conv_desc.gn_out with gn_flags bit 1): MFMA wave w
+// holds all 64 pixels of its image for the tile's 64 couts = eight whole groups of 8 channels, so the statistics are 16
+// in-lane values, one DPP row sum and one exchange with lane ^ 16 per group.
+template <bool GN>
 __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const halo0 = smem;
@@ -132,6 +136,15 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
         read_b(0, 0, Bx);
         for (;;) {
             const bool more = q + qstride < ntiles;
+            f32x4 gam[4], bet[4];
+            if constexpr (GN) {          // this tile's affine parameters: in flight under the K loop
+                const int co0 = (q % p.CT) * 64 + 4 * kg;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    gam[cb] = *reinterpret_cast<const f32x4*>(p.gn_gamma + co0 + cb * 16);
+                    bet[cb] = *reinterpret_cast<const f32x4*>(p.gn_beta + co0 + cb * 16);
+                }
+            }
             for (int c = 0; c < nchunks; c += 2) {
 #pragma unroll
                 for (int u = 0; u < 18; ++u) {
@@ -181,9 +194,52 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
                         bf16x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-                        *reinterpret_cast<bf16x4*>(a0 + nb * 2048) = o;
+                        if constexpr (GN) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[cb][nb][e] = 0.f;
+                            for (int e = 0; e < 4; ++e) acc[cb][nb][e] = (float)o[e];     // the value a separate launch would read
+                        } else {
+                            *reinterpret_cast<bf16x4*>(a0 + nb * 2048) = o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[cb][nb][e] = 0.f;
+                        }
+                    }
+                    if constexpr (GN) {
+                        // group = couts cb * 16 + 8 (kg >> 1) .. + 7 over the image's 64 pixels: two-pass statistics, fixed order
+                        float s = 0.f;
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) s += (acc[cb][nb][0] + acc[cb][nb][1]) + (acc[cb][nb][2] + acc[cb][nb][3]);
+                        s = dxmi_row16_sum(s);
+                        s += __shfl_xor(s, 16, 64);
+                        const float mean = s * (1.f / 512.f);
+                        float qv = 0.f;
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) {
+                            float d[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) d[e] = acc[cb][nb][e] - mean;
+                            qv += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+                        }
+                        qv = dxmi_row16_sum(qv);
+                        qv += __shfl_xor(qv, 16, 64);
+                        const float rstd = rsqrtf(qv * (1.f / 512.f) + p.gn_eps);
+                        float ga[4], be[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ga[e] = gam[cb][e] * rstd;               // same form as groupnorm_silu_kernel
+                            be[e] = bet[cb][e] - mean * ga[e];
+                        }
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) {
+                            bf16x4 y;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float t = acc[cb][nb][e] * ga[e] + be[e];
+                                if (p.gn_flags & 1) t = dxmi_silu_fast(t);
+                                y[e] = (bf16)t;
+                                acc[cb][nb][e] = 0.f;
+                            }
+                            *reinterpret_cast<bf16x4*>(a0 + nb * 2048) = y;
+                        }
                     }
                 }
             }
@@ -420,6 +476,7 @@ int conv_ws8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     if (nchunks < 4 || nchunks % 2 != 0 || (9 * nchunks) % W8_RING != 0) return 1;
     // no batch-size condition: an image's result must not depend on the batch it rides in (the kernels differ in summation order)
     if ((long)a.N * 64 * (a.C0 > a.C1 ? a.C0 : a.C1) * 2 >= (1L << 31)) return 1;   // 32-bit byte offsets inside either input part
+    if (a.gn_out && !(a.gn_flags & 2)) return 1;     // the fused GroupNorm replaces the raw output (one output tile in LDS)
     if (kernel_id) {
         *kernel_id = 400008;    // conv_ws8_kernel
         return DXMI_OK;
@@ -444,10 +501,16 @@ int conv_ws8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     if (grid > 256) grid = 256;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ws8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ws8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ws8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_ws8_kernel, dim3(grid), dim3(512), lds, st, b);
+    if (a.gn_out) {
+        b.out = a.gn_out;       // the movers drain the (normalised) tile to the fused output
+        hipLaunchKernelGGL(conv_ws8_kernel<true>, dim3(grid), dim3(512), lds, st, b);
+    } else {
+        hipLaunchKernelGGL(conv_ws8_kernel<false>, dim3(grid), dim3(512), lds, st, b);
+    }
     DXMI_CHECK_LAUNCH("dxmi_conv2d_fwd(ws8)");
     return DXMI_OK;
 }

@@ -64,6 +64,9 @@ SIGNATURES = {
     "dxmi_groupnorm_silu_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                         c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dxmi_attention_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "dxmi_attention_proj_supported": (c_int, [c_int, c_int, c_int]),
+    "dxmi_pack_attn_proj_weight": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "dxmi_attention_proj_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dxmi_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "dxmi_linear_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_var_step_fwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_void_p]),

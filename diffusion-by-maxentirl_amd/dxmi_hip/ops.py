@@ -181,8 +181,9 @@ def conv2d(x, pw, *, in1=None, bias=None, addvec=None, residual=None, stride=1, 
         assert not want_stats
         gamma, beta, groups, eps, silu, keep_raw = fuse_gn
         d.gn_groups = groups
+        d.gn_flags = int(bool(silu)) | (0 if keep_raw else 2)
         key = ("gn", N, IH, IW, C0, C1, OH, OW, Cout, k, stride, pad, int(upsample), act, d.in_mode, d.out_mode, variant,
-               residual is not None, mask_src is not None, groups)
+               residual is not None, mask_src is not None, groups, bool(keep_raw))
         ok = _STATS_P.get(key)
         if ok is None:
             ok = _STATS_P[key] = int(load().dxmi_conv2d_gn_fuse_supported(ctypes.byref(d)))
@@ -190,7 +191,6 @@ def conv2d(x, pw, *, in1=None, bias=None, addvec=None, residual=None, stride=1, 
             assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == Cout and beta.numel() == Cout
             y = torch.empty((N, OH, OW, Cout), dtype=torch.bfloat16, device=x.device)
             d.gn_out, d.gn_gamma, d.gn_beta, d.gn_eps = y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), float(eps)
-            d.gn_flags = int(bool(silu)) | (0 if keep_raw else 2)
     if PROFILER is not None:
         PROFILER.launch_conv(d)
     else:
@@ -564,6 +564,38 @@ def attention(qkv, heads, scale, out=None):
     _prof("attention", f"T{T}_D{C // heads}", 4.0 * N * T * T * C, 2.0 * N * T * 4 * C, lambda: check(
         load().dxmi_attention_fwd(_ptr(qkv), _ptr(out), N, T, C, heads, float(scale), _stream()), "dxmi_attention_fwd"))
     return out
+
+
+def attention_proj_supported(T, C, heads):
+    return bool(load().dxmi_attention_proj_supported(T, C, heads))
+
+
+def pack_attn_proj_weight(w):
+    """proj_out weight [256, 256(, 1, 1)] fp32 -> the 128 KiB bf16 fragment image dxmi_attention_proj_fwd reads."""
+    _need_cuda(w)
+    w2 = w.detach().float().reshape(w.shape[0], -1).contiguous()
+    assert tuple(w2.shape) == (256, 256)
+    dst = torch.empty(256 * 256, dtype=torch.bfloat16, device=w.device)
+    check(load().dxmi_pack_attn_proj_weight(_ptr(w2), _ptr(dst), _stream()), "dxmi_pack_attn_proj_weight")
+    return dst
+
+
+def attention_proj(qkv, wproj_packed, bias, residual, heads, scale, out=None, want_stats=False):
+    """x + proj_out(attention(qkv)) + bias in one launch (see include/dxmi_hip.h).  qkv [N,T,3C], residual [N,T,C] bf16.
+    want_stats: -> (out, BlockStats of out) from the same launch."""
+    _need_cuda(qkv, wproj_packed, bias, residual, out)
+    N, T, C3 = qkv.shape
+    C = C3 // 3
+    assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous() and residual.dtype == torch.bfloat16 and residual.is_contiguous()
+    assert residual.numel() == N * T * C and bias.dtype == torch.float32 and bias.numel() == C
+    if out is None:
+        out = torch.empty((N, T, C), dtype=torch.bfloat16, device=qkv.device)
+    stats = BlockStats(torch.empty((N, 8, C // 2, 2), dtype=torch.float32, device=qkv.device), 8) if want_stats else None
+    _prof("attention", f"T{T}_D{C // heads}_proj", 4.0 * N * T * T * C + 2.0 * N * T * C * C, 2.0 * N * T * 5 * C, lambda: check(
+        load().dxmi_attention_proj_fwd(_ptr(qkv), _ptr(wproj_packed), _ptr(bias), _ptr(residual), _ptr(out),
+                                       stats.buf.data_ptr() if want_stats else None, N, T, C, heads, float(scale), _stream()),
+        "dxmi_attention_proj_fwd"))
+    return (out, stats) if want_stats else out
 
 
 def timestep_embedding(t, dim, order=0, max_period=10000.0, out=None):

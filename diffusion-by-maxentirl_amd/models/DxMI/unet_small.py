@@ -207,6 +207,8 @@ class Model(nn.Module):
                     pk[id(m), "qkv"] = ops.pack_conv_weight(torch.cat([m.q.weight, m.k.weight, m.v.weight], 0))
                     pk[id(m), "qkv_bias"] = torch.cat([m.q.bias, m.k.bias, m.v.bias], 0).detach().float().contiguous()
                     pk[id(m), "proj"] = ops.pack_conv_weight(m.proj_out.weight)
+                    if m.in_channels == 256:      # the 16x16 blocks: proj_out fused behind the attention (ops.attention_proj)
+                        pk[id(m), "proj_attn"] = ops.pack_attn_proj_weight(m.proj_out.weight)
                 elif isinstance(m, (Upsample, Downsample)):
                     pk[id(m), "conv"] = ops.pack_conv_weight(m.conv.weight)
             pk["conv_in"] = ops.pack_conv_weight(self.conv_in.weight, k27=(self.in_channels == 3))
@@ -224,6 +226,7 @@ class Model(nn.Module):
     # Activations on maps of >= STREAM_GN_MIN_HW pixels travel as (tensor, BlockStats): the producing conv's epilogue writes the
     # GroupNorm block statistics of what it stores, so every Normalize() on them is one streaming read + write
     # (ops.groupnorm_apply).  Smaller maps (8x8, 4x4: 8 % of the GroupNorm bytes) keep the one-pass resident kernel.
+    FUSE_ATTN_PROJ = True             # proj_out + residual of the 16x16 AttnBlocks behind the attention kernel
     FUSE_GN_SMALL = True              # norm2 of the 4x4 ResnetBlocks from conv1's epilogue (instance override: A-B timing)
     STREAM_GN_MIN_HW = 256            # instance attribute override (tests / A-B timing): 1 << 30 = one-pass GroupNorm everywhere
 
@@ -279,6 +282,10 @@ class Model(nn.Module):
         else:
             hn = ops.groupnorm_silu(x, m.norm.weight, m.norm.bias, eps=1e-6, silu=False, stats=(sx, None))
         qkv = ops.conv2d(hn, pk[id(m), "qkv"], bias=pk[id(m), "qkv_bias"])
+        if self.FUSE_ATTN_PROJ and (id(m), "proj_attn") in pk and ops.attention_proj_supported(H * W, C, 1):
+            out, st = ops.attention_proj(qkv.view(N, H * W, 3 * C), pk[id(m), "proj_attn"], m.proj_out.bias, x, heads=1,
+                                         scale=float(int(C) ** (-0.5)), want_stats=True)
+            return out.view(N, H, W, C), (st if H * W >= self.STREAM_GN_MIN_HW else None)
         a = ops.attention(qkv.view(N, H * W, 3 * C), heads=1, scale=float(int(C) ** (-0.5)))
         if H * W >= self.STREAM_GN_MIN_HW:
             return self._conv_s(a.view(N, H, W, C), pk[id(m), "proj"], bias=m.proj_out.bias, residual=x)

@@ -91,7 +91,8 @@ typedef struct dxmi_conv_desc {
                                 fixed order inside the conv's epilogue (bitwise reproducible).  P = dxmi_conv2d_gn_stats_partials(d);
                                 NULL = not wanted.  Setting it for a shape whose kernel cannot produce them is DXMI_EINVAL. */
     /* optional: GroupNorm(+SiLU) of the conv's OUTPUT fused into its epilogue, for shapes whose workgroup tile holds whole
-       images and whole groups (the 4x4 maps of the U-Net: Normalize()+nonlinearity of the next layer, unet_small.py:119-126):
+       images and whole groups (the 4x4 maps of the U-Net, and the 8x8 maps when gn_flags bit 1 drops the raw output:
+       Normalize()+nonlinearity of the next layer, unet_small.py:119-126):
        gn_out = silu?(group_norm(round_bf16(out))) with statistics in fp32 (two-pass, from registers), bitwise independent of
        the batch.  gn_out NULL = off.  dxmi_conv2d_gn_fuse_supported(d) says whether the selected kernel can; setting it for a
        shape that cannot is DXMI_EINVAL. */
@@ -238,6 +239,19 @@ int dxmi_groupnorm_apply(const void* in0, int32_t C0, const float* stats0, int32
  * ---------------------------------------------------------------------------------------- */
 int dxmi_attention_fwd(const void* qkv, void* out, int32_t N, int32_t T, int32_t C,
                        int32_t heads, float scale, void* stream);
+
+/* AttnBlock tail fused behind the attention (reference unet_small.py:187-190: h_ = proj_out(h_); return x + h_), for the
+ * single-head 256-token x 256-channel block of the CIFAR-10 net (dxmi_attention_proj_supported): the attention output never
+ * leaves the CU — it stays in registers as the MFMA operand of the 1x1 projection — and out = x + proj_out(attention) + bias is
+ * written once.  Same arithmetic as dxmi_attention_fwd followed by dxmi_conv2d_fwd (attention output rounded to bf16, fp32
+ * accumulation, one rounding of the sum).  wproj_packed: 128 KiB from dxmi_pack_attn_proj_weight (fp32 [256][256] OI weight).
+ * Inference path only: training keeps the two launches (the projection's weight gradient needs the attention output). */
+int dxmi_attention_proj_supported(int32_t T, int32_t C, int32_t heads);
+int dxmi_pack_attn_proj_weight(const float* w_oi, void* dst, void* stream);
+int dxmi_attention_proj_fwd(const void* qkv, const void* wproj_packed, const float* bias, const void* residual, void* out,
+                            float* gn_stats, int32_t N, int32_t T, int32_t C, int32_t heads, float scale, void* stream);
+/* gn_stats (optional): GroupNorm block statistics of `out`, fp32 [N][8][C/2][2] — one partial per 32 tokens, the layout
+ * dxmi_groupnorm_apply reads (P = 8). */
 
 /* ------------------------------------------------------------------------------------------
  * Timestep-embedding path.

@@ -302,14 +302,14 @@ def test_conv_sm_fused_groupnorm(ops, N, C0, C1, res, silu):
 
 
 def test_conv_fused_groupnorm_unsupported_shape(ops):
-    """8x8 maps (an image spans two DPP rows ... and conv_ws8 serves them): ops returns y None; the raw C-ABI call is an error."""
+    """8x8 maps with the raw output kept (conv_ws8 has one output tile): ops returns y None; the raw C-ABI call is an error."""
     import ctypes
     from dxmi_hip import _lib
     g = torch.Generator().manual_seed(3)
     x = torch.randn(4, 8, 8, 256, generator=g).to(torch.bfloat16).to(DEV)
     pw = ops.pack_conv_weight((torch.randn(256, 256, 3, 3, generator=g) * 0.03).to(DEV))
     gamma, beta = torch.ones(256, device=DEV), torch.zeros(256, device=DEV)
-    out, y = ops.conv2d(x, pw, fuse_gn=(gamma, beta, 32, 1e-6, True, False))
+    out, y = ops.conv2d(x, pw, fuse_gn=(gamma, beta, 32, 1e-6, True, True))      # 8x8: only INSTEAD of the raw output
     assert y is None and out is not None
     d = _lib.ConvDesc()
     yb = torch.empty_like(out)
@@ -326,3 +326,76 @@ def test_conv_fused_groupnorm_unsupported_shape(ops):
     assert lib.dxmi_conv2d_gn_fuse_supported(ctypes.byref(d)) == 0
     d.gn_groups = 32
     assert lib.dxmi_conv2d_gn_fuse_supported(ctypes.byref(d)) == 1
+
+
+# -------------------------------------------------------------------------- proj_out + residual fused behind the attention
+@pytest.mark.parametrize("N", [1, 5])
+def test_attention_proj_fused(ops, N):
+    """dxmi_attention_proj_fwd (AttnBlock tail, reference unet_small.py:175-190) against the two launches it replaces and
+    against torch fp32."""
+    g = torch.Generator().manual_seed(21 + N)
+    T = C = 256
+    qkv = (torch.randn(N, T, 3 * C, generator=g) * 1.5).to(torch.bfloat16).to(DEV)
+    x = torch.randn(N, T, C, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(C, C, 1, 1, generator=g) * 0.06).to(DEV)
+    b = torch.randn(C, generator=g).to(DEV)
+    scale = float(C) ** -0.5
+    assert ops.attention_proj_supported(T, C, 1) and not ops.attention_proj_supported(16, C, 1)
+    y = ops.attention_proj(qkv, ops.pack_attn_proj_weight(w), b, x, heads=1, scale=scale)
+    # the unfused pair
+    a = ops.attention(qkv, heads=1, scale=scale)
+    sep = ops.conv2d(a.view(N, 16, 16, C), ops.pack_conv_weight(w), bias=b, residual=x.view(N, 16, 16, C)).view(N, T, C)
+    d = (y.float() - sep.float()).abs()
+    assert d.max().item() <= 2 ** -6 * max(1.0, sep.float().abs().max().item()), d.max().item()
+    assert (d > 0).float().mean().item() < 0.02          # same operands; only the order inside a 16-channel MFMA step differs
+    # torch fp32 on the same bf16 inputs
+    q, k, v = (t.float() for t in qkv.split(C, dim=2))
+    att = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * scale, dim=2)
+    o = torch.bmm(att, v)
+    ref = x.float() + o @ w.view(C, C).t() + b
+    assert ((y.float() - ref).norm() / ref.norm()).item() < 4e-3
+    # block statistics of the stored output from the same launch (and the output unchanged by asking for them)
+    y2, st = ops.attention_proj(qkv, ops.pack_attn_proj_weight(w), b, x, heads=1, scale=scale, want_stats=True)
+    assert torch.equal(y, y2) and st.P == 8 and tuple(st.buf.shape) == (N, 8, C // 2, 2)
+    want = _torch_block_stats(y.view(N, 16, 16, C)).to(DEV)
+    got = st.buf.double().sum(1)
+    assert ((got - want).abs() <= 1e-4 * (1 + want.abs())).all()
+    want8 = torch.stack([_torch_block_stats(y[:, 32 * k:32 * k + 32].reshape(N, 2, 16, C)) for k in range(8)], 1).to(DEV)
+    assert ((st.buf.double() - want8).abs() <= 1e-4 * (1 + want8.abs())).all()
+    # bitwise reproducible and independent of the batch
+    assert torch.equal(y, ops.attention_proj(qkv, ops.pack_attn_proj_weight(w), b, x, heads=1, scale=scale))
+    i = N - 1
+    one = ops.attention_proj(qkv[i:i + 1].contiguous(), ops.pack_attn_proj_weight(w), b, x[i:i + 1].contiguous(), heads=1, scale=scale)
+    assert torch.equal(one[0], y[i])
+
+
+@pytest.mark.parametrize("N,C0,C1,res,silu", [(37, 256, 0, False, True), (6, 256, 256, True, False), (256, 256, 0, False, True)])
+def test_conv_ws8_fused_groupnorm(ops, N, C0, C1, res, silu):
+    """8x8 maps: conv_ws8_kernel<true> writes GroupNorm(+SiLU) of its output instead of the raw output."""
+    Cout = 256
+    g = torch.Generator().manual_seed(17 + N)
+    x0 = torch.randn(N, 8, 8, C0, generator=g).to(torch.bfloat16).to(DEV)
+    x1 = torch.randn(N, 8, 8, C1, generator=g).to(torch.bfloat16).to(DEV) if C1 else None
+    w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) * 0.03).to(DEV)
+    pw = ops.pack_conv_weight(w)
+    bv = torch.randn(Cout, generator=g).to(DEV)
+    tv = torch.randn(N, Cout, generator=g).to(DEV)
+    r = torch.randn(N, 8, 8, Cout, generator=g).to(torch.bfloat16).to(DEV) if res else None
+    gamma = (1 + 0.3 * torch.randn(Cout, generator=g)).to(DEV)
+    beta = (0.3 * torch.randn(Cout, generator=g)).to(DEV)
+    kw = dict(in1=x1, bias=bv, addvec=tv, residual=r)
+    raw = ops.conv2d(x0, pw, **kw)
+    none, y = ops.conv2d(x0, pw, fuse_gn=(gamma, beta, 32, 1e-6, silu, False), **kw)
+    assert none is None and y is not None
+    sep = ops.groupnorm_silu(raw, gamma, beta, groups=32, eps=1e-6, silu=silu)
+    d = (y.float() - sep.float()).abs()
+    assert d.max().item() <= 2 ** -6 * max(1.0, sep.float().abs().max().item()) and (d > 0).float().mean().item() < 0.02
+    ref = F.group_norm(raw.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-6)
+    if silu:
+        ref = F.silu(ref)
+    assert ((y.float() - ref.permute(0, 2, 3, 1)).norm() / ref.norm()).item() < 3e-3
+    for i in {0, N // 2, N - 1}:
+        _, one = ops.conv2d(x0[i:i + 1].contiguous(), pw, in1=None if x1 is None else x1[i:i + 1].contiguous(), bias=bv,
+                            addvec=tv[i:i + 1].contiguous(), residual=None if r is None else r[i:i + 1].contiguous(),
+                            fuse_gn=(gamma, beta, 32, 1e-6, silu, False))
+        assert torch.equal(one[0], y[i]), i
