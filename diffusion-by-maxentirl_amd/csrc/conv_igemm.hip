@@ -460,12 +460,15 @@ static int conv2d_impl(const dxmi_conv_desc* d, void* stream, int* kernel_id) {
 extern "C" int dxmi_conv2d_fwd(const dxmi_conv_desc* d, void* stream) { return conv2d_impl(d, stream, nullptr); }
 
 // Partials per image of the GroupNorm block statistics the selected kernel writes (0: it writes none).
+int conv_pipe_stats_tile(int id, int OH, int OW, int Cout);     // conv_pipe.hip
+
 static int gn_stats_partials_of(const dxmi_conv_desc* d, int id) {
     if (id >= 400000 && id < 400100) {            // conv_ws_kernel<TW>: (pixel tile, pixel half) of the image
         const int TW = id - 400000, TH = 256 / TW;
         return (d->OH / TH) * (d->OW / TW) * 2;
     }
-    return 0;
+    const int tile = conv_pipe_stats_tile(id, d->OH, d->OW, d->Cout);     // stem / conv_pipe / 1x1 stream kernels: one partial per tile
+    return tile ? d->OH * d->OW / tile : 0;
 }
 
 extern "C" int dxmi_conv2d_gn_stats_partials(const dxmi_conv_desc* d) {

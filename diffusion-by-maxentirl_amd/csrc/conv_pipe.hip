@@ -85,6 +85,9 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&ac
         }
     };
     res_load(0);
+    // optional GroupNorm block statistics of the stored tile (p.gn_stats: one image per tile, full cout tiles — host-checked):
+    // every thread owns ONE 8-channel piece over its pixels of all passes
+    float gst[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
 #pragma unroll
@@ -140,9 +143,31 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&ac
                     for (int e = 0; e < 8; ++e) ov[e] = (bf16)dxmi_act_lin(v[e], slope);
                 }
                 *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + o) = ov;
+                if (p.gn_stats) {
+                    const bf16x4 lo4 = {ov[0], ov[1], ov[2], ov[3]}, hi4 = {ov[4], ov[5], ov[6], ov[7]};
+                    dxmi_stats4(lo4, gst[0]);
+                    dxmi_stats4(hi4, gst[1]);
+                }
             }
         }
         if (pass + 1 < NP) res_load(pass + 1);
+        lds_barrier();
+    }
+    if (p.gn_stats) {
+        // the 16 pixel lanes of a piece are added in lane order through the (free) slab: one partial per tile
+        float* const sl = reinterpret_cast<float*>(eb) + ((tid >> 4) * 16 + pc) * 8;
+        *reinterpret_cast<f32x4*>(sl) = f32x4{gst[0][0], gst[0][1], gst[0][2], gst[0][3]};
+        *reinterpret_cast<f32x4*>(sl + 4) = f32x4{gst[1][0], gst[1][1], gst[1][2], gst[1][3]};
+        lds_barrier();
+        if (tid < 128) {
+            const int j = tid & 7, c8 = tid >> 3;          // float j of piece c8
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += reinterpret_cast<const float*>(eb)[(r * 16 + c8) * 8 + j];
+            const int part = (oy0 >> p.THl) * (p.OW >> p.TWl) + (ox0 >> p.TWl);
+            const int P = (p.OH >> p.THl) * (p.OW >> p.TWl);
+            p.gn_stats[(((size_t)n0 * P + part) * (p.Cout >> 1) + cot * 64) * 2 + tid] = t;
+        }
         lds_barrier();
     }
 }
@@ -643,7 +668,30 @@ int conv_head_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);    // con
 int conv_ws8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);     // conv_ws8.hip
 int conv_sm_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);      // conv_sm.hip
 
+// Pixels per tile of the kernels whose epilogue (conv_epilogue_lds) can emit GroupNorm block statistics, 0 for the others:
+// conv_stem_kernel (300000), conv_pipe_kernel (k NB pmax = 10000 k + 100 NB + pmax) and conv1x1_stream_kernel (200000), for
+// tiles inside one image and full 128-cout tiles.
+int conv_pipe_stats_tile(int id, int OH, int OW, int Cout) {
+    int tile = 0;
+    if (id == 300000) tile = 128;
+    else if (id == 200000) tile = 64;
+    else if ((id >= 10000 && id < 20000) || (id >= 30000 && id < 40000)) tile = 32 * ((id % 10000) / 100);
+    if (tile == 0 || Cout % 128 != 0 || OH * OW < tile || (OH * OW) % tile != 0) return 0;
+    return tile;
+}
+
 int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
+    if (a.gn_stats && !kernel_id) {
+        // the statistics request must not change which kernel runs: select without it, then check that kernel can
+        ConvArgs q = a;
+        q.gn_stats = nullptr;
+        int id = 0;
+        const int rc = conv_pipe_try_launch(q, st, &id);
+        if (rc < 0) return rc;
+        DXMI_CHECK_ARG(rc == 0 && ((id >= 400000 && id < 400100) || conv_pipe_stats_tile(id, a.OH, a.OW, a.Cout) > 0),
+                       "dxmi_conv2d_fwd: the kernel for this shape does not emit GroupNorm block statistics "
+                       "(dxmi_conv2d_gn_stats_partials returns 0 for it)");
+    }
     {
         int rc = 1;
         if (a.gn_out) {          // conv_sm_kernel (4x4 maps) and conv_ws8_kernel (8x8, instead of the raw output) fuse the GroupNorm of their output
@@ -656,9 +704,8 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
         }
         rc = conv_ws_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;
-        // only the kernels tried above emit GroupNorm block statistics (dxmi_conv2d_gn_stats_partials says which shapes)
-        DXMI_CHECK_ARG(!a.gn_stats || kernel_id, "dxmi_conv2d_fwd: the kernel for this shape does not emit GroupNorm block statistics "
-                                                 "(dxmi_conv2d_gn_stats_partials returns 0 for it)");
+        // besides conv_ws_kernel only the stem / conv_pipe kernels below emit GroupNorm block statistics, for one-image tiles
+        // (dxmi_conv2d_gn_stats_partials says which shapes); the other small-map kernels are skipped for such a request
         rc = conv1x1_rw_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;
         rc = conv_head_try_launch(a, st, kernel_id);

@@ -510,6 +510,29 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     }
 }
 
+// out[b][c] = sum_n in[b][n][c] (fp32): 16 channels x 16 row slices per workgroup, slice sums added in slice order through LDS
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C) {
+    __shared__ float bs[15][16];
+    const int cblocks = (C + 15) / 16;
+    const int b = blockIdx.x / cblocks, cb = blockIdx.x - b * cblocks;
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = cb * 16 + cl;
+    float t = 0.f;
+    if (c < C) {
+        const float* src = in + (size_t)b * N * C + c;
+        const int k0 = (N * sl) >> 4, k1 = (N * (sl + 1)) >> 4;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) t += src[(size_t)k * C];
+    }
+    if (sl > 0) bs[sl - 1][cl] = t;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+#pragma unroll
+        for (int j = 0; j < 15; ++j) t += bs[j][cl];
+        out[(size_t)b * C + c] = t;
+    }
+}
+
 int ilog2w(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -652,6 +675,14 @@ extern "C" int dxmi_colsum_bf16(const void* x, float* out, void* workspace, int6
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 15) / 16), dim3(256), 0, st, (const float*)workspace, out, nblocks, C,
                        accumulate);
     DXMI_CHECK_LAUNCH("dxmi_colsum_bf16(final)");
+    return DXMI_OK;
+}
+
+// out[b][c] = sum_n in[b][n][c], fp32 (the per-image d(gamma) / d(beta) partials of the GroupNorm backward): fixed order.
+extern "C" int dxmi_colsum_f32(const float* in, float* out, int32_t B, int32_t N, int32_t C, void* stream) {
+    DXMI_CHECK_ARG(in && out && B > 0 && N > 0 && C > 0, "dxmi_colsum_f32: bad arguments");
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3(B * ((C + 15) / 16)), dim3(256), 0, (hipStream_t)stream, in, out, N, C);
+    DXMI_CHECK_LAUNCH("dxmi_colsum_f32");
     return DXMI_OK;
 }
 

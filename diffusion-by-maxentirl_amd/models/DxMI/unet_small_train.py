@@ -197,8 +197,7 @@ class _UNetFn(torch.autograd.Function):
             d_a = ops.conv2d(g, pkt[id(m), "proj"])
             d_qkv = ops.attention_bwd(qkv.view(Nn, Hh * Ww, 3 * C), d_a.view(Nn, Hh * Ww, C), 1, float(int(C) ** (-0.5)))
             d_qkv = d_qkv.view(Nn, Hh, Ww, 3 * C)
-            wq = ops.conv2d_wgrad(hn, d_qkv, 1)
-            bq = ops.colsum(d_qkv)
+            wq, bq = ops.conv2d_wgrad(hn, d_qkv, 1, with_bias=True)       # the bias gradient from the dY tiles the kernel stages anyway
             for j, conv in enumerate((m.q, m.k, m.v)):
                 grads[conv.weight] = wq[j * C:(j + 1) * C].contiguous()
                 grads[conv.bias] = bq[j * C:(j + 1) * C].contiguous()

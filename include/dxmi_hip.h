@@ -162,6 +162,9 @@ int dxmi_colsum_bf16(const void* x, float* out, void* workspace, int64_t P, int3
 /* out[b][c] = sum of rows [b*rows_per_block, (b+1)*rows_per_block) of x[P][C] (per-image channel sums). */
 int dxmi_colsum_blocks_bf16(const void* x, float* out, int64_t P, int32_t C, int32_t rows_per_block,
                             void* stream);
+/* out[b][c] = sum_n in[b][n][c], fp32, fixed order (the [2][N][C] per-image d(gamma) / d(beta) partials of
+ * dxmi_groupnorm_silu_bwd -> [2][C]). */
+int dxmi_colsum_f32(const float* in, float* out, int32_t B, int32_t N, int32_t C, void* stream);
 
 /* Backward of GroupNorm(+SiLU) (training path).  x = [in0 | in1] and dy (gradient w.r.t. the forward
  * kernel's output, one dense [N,HW,C0+C1] tensor) -> dx0 [N,HW,C0], dx1 [N,HW,C1] (+ add0/add1 fused:

@@ -399,3 +399,37 @@ def test_conv_ws8_fused_groupnorm(ops, N, C0, C1, res, silu):
                             addvec=tv[i:i + 1].contiguous(), residual=None if r is None else r[i:i + 1].contiguous(),
                             fuse_gn=(gamma, beta, 32, 1e-6, silu, False))
         assert torch.equal(one[0], y[i]), i
+
+
+def test_stem_and_stride2_conv_block_stats(ops):
+    """conv_stem_kernel and the stride-2 conv_pipe_kernel (Downsample) emit the block statistics of what they store (one partial
+    per tile), the output is bitwise that of a launch without statistics, and an image's rows do not depend on the batch."""
+    g = torch.Generator().manual_seed(77)
+    N = 5
+    # stem: NCHW fp32 image -> NHWC bf16 [N,32,32,128]
+    x = torch.randn(N, 3, 32, 32, generator=g).to(DEV)
+    pw = ops.pack_conv_weight((torch.randn(128, 3, 3, 3, generator=g) * 0.2).to(DEV), k27=True)
+    b = torch.randn(128, generator=g).to(DEV)
+    y, st = ops.conv2d(x, pw, bias=b, want_stats=True)
+    assert st is not None and st.P == 8 and torch.equal(y, ops.conv2d(x, pw, bias=b))
+    ref = _torch_block_stats(y)
+    assert (st.buf.double().sum(1) - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    # a partial is one 4-row band of the image
+    band = _torch_block_stats(y[:, 8:12])
+    assert (st.buf[:, 2].double() - band).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    y1, st1 = ops.conv2d(x[2:3].contiguous(), pw, bias=b, want_stats=True)
+    assert torch.equal(st1.buf[0], st.buf[2]) and torch.equal(y1[0], y[2])
+    # Downsample: k3 s2, pad (0, 1): 32x32 -> 16x16, 128 channels
+    x2 = torch.randn(N, 32, 32, 128, generator=g).to(torch.bfloat16).to(DEV)
+    pw2 = ops.pack_conv_weight((torch.randn(128, 128, 3, 3, generator=g) * 0.03).to(DEV))
+    kw = dict(bias=b, stride=2, pad=0, pad_br=1)
+    y2, st2 = ops.conv2d(x2, pw2, want_stats=True, **kw)
+    assert st2 is not None and st2.P == 4 and tuple(y2.shape) == (N, 16, 16, 128) and torch.equal(y2, ops.conv2d(x2, pw2, **kw))
+    ref2 = _torch_block_stats(y2)
+    assert (st2.buf.double().sum(1) - ref2).abs().max().item() <= 2e-6 * ref2.abs().max().item()
+    y3, st3 = ops.conv2d(x2[4:5].contiguous(), pw2, want_stats=True, **kw)
+    assert torch.equal(st3.buf[0], st2.buf[4])
+    # 8x8 output (a 64-pixel tile would hold one image, the kernel picked packs several): no statistics, None
+    x4 = torch.randn(N, 16, 16, 128, generator=g).to(torch.bfloat16).to(DEV)
+    y4, st4 = ops.conv2d(x4, pw2, want_stats=True, **kw)
+    assert st4 is None or (st4.buf.double().sum(1) - _torch_block_stats(y4)).abs().max().item() <= 1e-3
