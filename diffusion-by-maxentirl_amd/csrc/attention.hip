@@ -37,7 +37,7 @@ struct AttnArgs {
     float* gn_stats;        // optional: GroupNorm block statistics of the output, [N][8][128][2] (a partial per 32 tokens)
 };
 
-template <int D>
+template <int D, bool PF>
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     constexpr int KB = 64;               // keys per block
     constexpr int DK = D / 16;           // k-steps over d
@@ -86,7 +86,6 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     float m = -INFINITY, l = 0.f;
 
     const int nkb = (p.T + KB - 1) / KB;
-    constexpr bool PF = D >= 128;
     constexpr int PIECES = KB * (D / 8);   // 16-byte pieces per operand block
     constexpr int NP = PIECES / 256;
     bf16x8 kreg[NP], vreg[NP];
@@ -551,9 +550,9 @@ __global__ __launch_bounds__(256) void pack_attn_proj_kernel(const float* __rest
     *reinterpret_cast<bf16x8*>(dst + (size_t)t * 8) = o;
 }
 
-template <int D>
-int launch_attn(const AttnArgs& a, hipStream_t st) {
-    auto kern = attention_kernel<D>;
+template <int D, bool PF>
+int launch_attn_pf(const AttnArgs& a, hipStream_t st) {
+    auto kern = attention_kernel<D, PF>;
     const size_t lds = 64 * (D * 2 + 16) + 64 * (D * 2 + 64);
     static bool attr_set = false;
     if (!attr_set) {
@@ -564,6 +563,15 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(a.N * a.heads * qblocks), dim3(256), lds, st, a);
     DXMI_CHECK_LAUNCH("dxmi_attention_fwd");
     return DXMI_OK;
+}
+
+// PF: key block kb + 1 is fetched into registers while block kb is computed.  Wide heads (one wave per SIMD) always; narrow heads
+// (D = 64: four workgroups per CU hide part of the latency themselves) by measurement — DXMI_ATTN_PF overrides (0 / 1).
+template <int D>
+int launch_attn(const AttnArgs& a, hipStream_t st) {
+    static const int pf_env = getenv("DXMI_ATTN_PF") ? atoi(getenv("DXMI_ATTN_PF")) : -1;
+    const bool pf = pf_env >= 0 ? pf_env != 0 : D >= 128;
+    return pf ? launch_attn_pf<D, true>(a, st) : launch_attn_pf<D, false>(a, st);
 }
 
 }  // namespace

@@ -337,9 +337,23 @@ struct GnApplyArgs {
     int C0, C1, HW, groups, cpg, chunks, rows_per_chunk, P0, P1, ss_ld;
     float eps;
     int silu;
+    int nt;        // tuning (DXMI_GN_APPLY_NT): bit 0 non-temporal loads of x, bit 1 non-temporal stores of the output
 };
 
 constexpr int GN_APPLY_MAXP = 8;        // partials per image the prologue keeps in flight (ops.MAX_APPLY_PARTIALS folds larger P)
+
+typedef int gn_i4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 gn_ld(const bf16* ptr, bool nt) {
+    const gn_i4* q = reinterpret_cast<const gn_i4*>(ptr);
+    const gn_i4 t = nt ? __builtin_nontemporal_load(q) : *q;
+    return __builtin_bit_cast(bf16x8, t);
+}
+__device__ __forceinline__ void gn_st(bf16* ptr, const bf16x8& v, bool nt) {
+    gn_i4* q = reinterpret_cast<gn_i4*>(ptr);
+    const gn_i4 t = __builtin_bit_cast(gn_i4, v);
+    if (nt) __builtin_nontemporal_store(t, q);
+    else *q = t;
+}
 
 template <int U>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int rr = r + u * rows_par;
-            if (rr < row1) v[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)rr * Cs);
+            if (rr < row1) v[u] = gn_ld(src + (size_t)rr * Cs, p.nt & 1);
         }
     }
     // statistics prologue, one memory latency deep: every thread sums the <= GN_APPLY_MAXP partials of one channel pair (all
@@ -445,7 +459,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
                     if (p.silu) y = dxmi_silu_fast(y);
                     o[e] = (bf16)y;
                 }
-                *reinterpret_cast<bf16x8*>(dst + (size_t)rr * C) = o;
+                gn_st(dst + (size_t)rr * C, o, p.nt & 2);
             }
         }
         r += U * rows_par;
@@ -453,7 +467,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int rr = r + u * rows_par;
-            if (rr < row1) v[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)rr * Cs);
+            if (rr < row1) v[u] = gn_ld(src + (size_t)rr * Cs, p.nt & 1);
         }
     }
 }
@@ -1155,6 +1169,8 @@ extern "C" int dxmi_groupnorm_apply(const void* in0, int32_t C0, const float* st
     a.ss = scale_shift; a.ss_ld = ss_ld;
     a.out = (bf16*)out; a.C0 = C0; a.C1 = C1; a.HW = HW; a.groups = groups; a.cpg = cpg; a.P0 = P0; a.P1 = P1;
     a.eps = eps; a.silu = apply_silu;
+    static const int nt_env = getenv("DXMI_GN_APPLY_NT") ? atoi(getenv("DXMI_GN_APPLY_NT")) : 0;
+    a.nt = nt_env;
     // a workgroup streams ~32 KB: two trips of U = 4 rows x (256 / (C/8)) row lanes
     static const int u_env = getenv("DXMI_GN_APPLY_U") ? atoi(getenv("DXMI_GN_APPLY_U")) : 4;            // tuning: loads in flight per thread
     static const int trips_env = getenv("DXMI_GN_APPLY_TRIPS") ? atoi(getenv("DXMI_GN_APPLY_TRIPS")) : 2;      // (in-situ sweep: 2 trips of 4 = 32 KB per workgroup slightly ahead of 4)

@@ -1,6 +1,7 @@
 # Round-3 profile passes (run on the GPU box through gpurun; writes under gpurun_out/).  rocprofv3 is given the program
 # itself (python3 ...), counters in their own passes without trace domains, as MI355X_MICROARCH.md prescribes.
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
+rm -rf gpurun_out/r03_prof_* gpurun_out/r03_pmc_*
 B="python3 bench.py --no-cpu-baseline --no-eager-reference --no-events --no-edm"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03_prof_bench -- $B --steps 5 --warmup 2 --train-steps 0 > gpurun_out/r03_prof_bench.json 2> gpurun_out/r03_prof_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r03_prof_train -- $B --steps 1 --warmup 1 --train-steps 3 > gpurun_out/r03_prof_train.json 2> gpurun_out/r03_prof_train.err
