@@ -192,6 +192,25 @@ struct GnGenArgs {
     int silu;
 };
 
+// (sum, sum of squares) of one group over the image's row chunks, added in chunk order with eight chunks' loads in flight (a
+// plain loop is one L2 round trip per chunk: 16 of them in front of every workgroup on a 64x64 map)
+__device__ __forceinline__ void gn_chunk_sums(const float* part, int groups, int chunks, float& s, float& q) {
+    s = 0.f;
+    q = 0.f;
+    for (int k0 = 0; k0 < chunks; k0 += 8) {
+        float2 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < chunks) t[u] = *reinterpret_cast<const float2*>(part + (size_t)(k0 + u) * groups * 2);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + u < chunks) {
+                s += t[u].x;
+                q += t[u].y;
+            }
+    }
+}
+
 __global__ __launch_bounds__(256) void gn_gen_stats_kernel(GnGenArgs p) {
     // threads = (256 / c8n) rows x c8n pieces: every thread keeps the running sum / sum of squares of its 8 channels
     // over its rows, then one thread per group adds the per-channel partials in a fixed order (bitwise reproducible).
@@ -253,11 +272,8 @@ __global__ __launch_bounds__(256) void gn_gen_apply_kernel(GnGenArgs p) {
     const int n = blockIdx.x / p.chunks, chunk = blockIdx.x % p.chunks;
     const int tid = threadIdx.x;
     if (tid < p.groups) {
-        float s = 0.f, q = 0.f;
-        for (int k = 0; k < p.chunks; ++k) {
-            s += p.part[(((size_t)n * p.chunks + k) * p.groups + tid) * 2 + 0];
-            q += p.part[(((size_t)n * p.chunks + k) * p.groups + tid) * 2 + 1];
-        }
+        float s, q;
+        gn_chunk_sums(p.part + (size_t)n * p.chunks * p.groups * 2 + tid * 2, p.groups, p.chunks, s, q);
         const float cnt = (float)p.HW * p.cpg;
         const float m = s / cnt;
         const float var = fmaxf(q / cnt - m * m, 0.f);
@@ -871,11 +887,8 @@ struct GnGenBwdArgs {
 __device__ __forceinline__ void gn_gen_group_stats(const GnGenBwdArgs& p, int n, float* mean_s, float* rstd_s) {
     const int tid = threadIdx.x;
     if (tid < p.groups) {
-        float s = 0.f, q = 0.f;
-        for (int k = 0; k < p.chunks; ++k) {
-            s += p.part[(((size_t)n * p.chunks + k) * p.groups + tid) * 2 + 0];
-            q += p.part[(((size_t)n * p.chunks + k) * p.groups + tid) * 2 + 1];
-        }
+        float s, q;
+        gn_chunk_sums(p.part + (size_t)n * p.chunks * p.groups * 2 + tid * 2, p.groups, p.chunks, s, q);
         const float cnt = (float)p.HW * p.cpg;
         const float m = s / cnt;
         mean_s[tid] = m;
@@ -919,15 +932,27 @@ __global__ __launch_bounds__(256) void gn_gen_bwd_reduce_kernel(GnGenBwdArgs p) 
         const bf16* dyp = p.dy + (size_t)n * p.HW * C + c;
         const int row0 = chunk * p.rows_per_chunk;
         const int row1 = min(row0 + p.rows_per_chunk, p.HW);
-        for (int r = row0 + rl; r < row1; r += rows_par) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)r * Cs);
-            const bf16x8 d = *reinterpret_cast<const bf16x8*>(dyp + (size_t)r * C);
+        // four rows per trip, loads issued together (same row order of the sums as one row per trip)
+        for (int r = row0 + rl; r < row1; r += 4 * rows_par) {
+            bf16x8 v[4], d[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float xh = ((float)v[e] - mu[e]) * rs[e];
-                float dyy = (float)d[e];
-                if (p.silu) dyy *= gn_dsilu(xh * A[e] + Bv[e]);
-                s0[e] += dyy; s1[e] += dyy * xh;
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + u * rows_par;
+                if (rr < row1) {
+                    v[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)rr * Cs);
+                    d[u] = *reinterpret_cast<const bf16x8*>(dyp + (size_t)rr * C);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (r + u * rows_par >= row1) break;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = ((float)v[u][e] - mu[e]) * rs[e];
+                    float dyy = (float)d[u][e];
+                    if (p.silu) dyy *= gn_dsilu(xh * A[e] + Bv[e]);
+                    s0[e] += dyy; s1[e] += dyy * xh;
+                }
             }
         }
 #pragma unroll
@@ -955,7 +980,15 @@ __global__ __launch_bounds__(256) void gn_gen_bwd_apply_kernel(GnGenBwdArgs p) {
     for (int i = tid; i < 2 * C; i += 256) {
         const int w = i / C, cc = i % C;
         float t = 0.f;
-        for (int k = 0; k < p.chunks; ++k) t += p.gpart[(((size_t)n * p.chunks + k) * C + cc) * 2 + w];
+        for (int k0 = 0; k0 < p.chunks; k0 += 8) {
+            float tk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u < p.chunks) tk[u] = p.gpart[(((size_t)n * p.chunks + k0 + u) * C + cc) * 2 + w];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + u < p.chunks) t += tk[u];
+        }
         gsum[w][cc] = t;
         if (chunk == 0) p.g_out[((size_t)w * p.N + n) * C + cc] = t;
     }
@@ -1000,22 +1033,33 @@ __global__ __launch_bounds__(256) void gn_gen_bwd_apply_kernel(GnGenBwdArgs p) {
     const bf16* dyp = p.dy + (size_t)n * p.HW * C + c;
     const int row0 = chunk * p.rows_per_chunk;
     const int row1 = min(row0 + p.rows_per_chunk, p.HW);
-    for (int r = row0 + rl; r < row1; r += rows_par) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + (size_t)r * Cs);
-        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dyp + (size_t)r * C);
-        bf16x8 av;
-        if (add) av = *reinterpret_cast<const bf16x8*>(add + (size_t)r * Cs);
-        bf16x8 o;
+    for (int r = row0 + rl; r < row1; r += 4 * rows_par) {
+        bf16x8 v[4], d[4], av[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float xh = ((float)v[e] - mu[e]) * rs[e];
-            float dyy = (float)d[e];
-            if (p.silu) dyy *= gn_dsilu(xh * A[e] + Bv[e]);
-            float dx = rs[e] * (A[e] * dyy - m1[e] - xh * m2[e]);
-            if (add) dx += (float)av[e];
-            o[e] = (bf16)dx;
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * rows_par;
+            if (rr < row1) {
+                v[u] = *reinterpret_cast<const bf16x8*>(src + (size_t)rr * Cs);
+                d[u] = *reinterpret_cast<const bf16x8*>(dyp + (size_t)rr * C);
+                if (add) av[u] = *reinterpret_cast<const bf16x8*>(add + (size_t)rr * Cs);
+            }
         }
-        *reinterpret_cast<bf16x8*>(dst + (size_t)r * Cs) = o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * rows_par;
+            if (rr >= row1) break;
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = ((float)v[u][e] - mu[e]) * rs[e];
+                float dyy = (float)d[u][e];
+                if (p.silu) dyy *= gn_dsilu(xh * A[e] + Bv[e]);
+                float dx = rs[e] * (A[e] * dyy - m1[e] - xh * m2[e]);
+                if (add) dx += (float)av[u][e];
+                o[e] = (bf16)dx;
+            }
+            *reinterpret_cast<bf16x8*>(dst + (size_t)rr * Cs) = o;
+        }
     }
 }
 
