@@ -542,7 +542,7 @@ extern "C" int dxmi_conv2d_kernel_id(const dxmi_conv_desc* d) {
 
 // Small dense layers (timestep-embedding MLP, temb_proj / emb_layers: P = batch rows, K <= 2048): the conv kernel gives
 // such a GEMM 1-22 workgroups walking K chunk by chunk (~100 us, pure latency).  Here every wave owns one 32-row x 32-col
-// output tile, reads its weight fragments and its fp32 rows straight from global memory (no LDS, no barrier) with four
+// output tile, reads its weight fragments and its fp32 rows straight from global memory (no LDS, no barrier) with eight
 // k16 steps of loads in flight, so the launch is P/32 x M/128 workgroups of independent MFMA chains.
 namespace {
 __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, const bf16* __restrict__ w,
@@ -562,18 +562,19 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int ksteps = K / 16;
-    for (int k0 = 0; k0 < ksteps; k0 += 4) {
-        bf16x8 a[4];
-        f32x4 lo[4], hi[4];
+    constexpr int LU = 8;           // k16 steps of loads in flight (4: K = 768 was twelve dependent round trips per wave)
+    for (int k0 = 0; k0 < ksteps; k0 += LU) {
+        bf16x8 a[LU];
+        f32x4 lo[LU], hi[LU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < LU; ++u) {
             const int ks = k0 + u < ksteps ? k0 + u : ksteps - 1;
             a[u] = wf[ks * wstep];
             lo[u] = *reinterpret_cast<const f32x4*>(xr + ks * 16);
             hi[u] = *reinterpret_cast<const f32x4*>(xr + ks * 16 + 4);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < LU; ++u) {
             if (k0 + u < ksteps) {
                 bf16x8 b;
 #pragma unroll

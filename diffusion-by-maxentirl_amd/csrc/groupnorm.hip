@@ -174,9 +174,12 @@ __global__ __launch_bounds__(512) void gn_silu_kernel(GnArgs p) {
 // batch-independent to 2e-2.
 static inline int gn_gen_chunks(int HW, int N) {
     (void)N;
-    if (HW < 256) return 1;
-    const int c = HW / 256;
-    return c > 64 ? 64 : c;
+    if (HW >= 16384) return HW / 256 > 64 ? 64 : HW / 256;      // LSUN-size maps: 256-row chunks, at most 64
+    // 64-row chunks, at most 16 per image: at batch 16 a 32x32 map is 256 workgroups instead of 64 and a 16x16 map 64 instead
+    // of 16 (the EDM train step runs these launches on a fraction of the chip); every workgroup re-reads its image's partials
+    // (2 C x chunks floats in the backward), which bounds the count
+    const int c = HW / 64;
+    return c < 1 ? 1 : (c > 16 ? 16 : c);
 }
 
 struct GnGenArgs {
@@ -192,18 +195,18 @@ struct GnGenArgs {
     int silu;
 };
 
-// (sum, sum of squares) of one group over the image's row chunks, added in chunk order with eight chunks' loads in flight (a
+// (sum, sum of squares) of one group over the image's row chunks, added in chunk order with sixteen chunks' loads in flight (a
 // plain loop is one L2 round trip per chunk: 16 of them in front of every workgroup on a 64x64 map)
 __device__ __forceinline__ void gn_chunk_sums(const float* part, int groups, int chunks, float& s, float& q) {
     s = 0.f;
     q = 0.f;
-    for (int k0 = 0; k0 < chunks; k0 += 8) {
-        float2 t[8];
+    for (int k0 = 0; k0 < chunks; k0 += 16) {
+        float2 t[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
             if (k0 + u < chunks) t[u] = *reinterpret_cast<const float2*>(part + (size_t)(k0 + u) * groups * 2);
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < 16; ++u)
             if (k0 + u < chunks) {
                 s += t[u].x;
                 q += t[u].y;
@@ -980,13 +983,13 @@ __global__ __launch_bounds__(256) void gn_gen_bwd_apply_kernel(GnGenBwdArgs p) {
     for (int i = tid; i < 2 * C; i += 256) {
         const int w = i / C, cc = i % C;
         float t = 0.f;
-        for (int k0 = 0; k0 < p.chunks; k0 += 8) {
-            float tk[8];
+        for (int k0 = 0; k0 < p.chunks; k0 += 16) {
+            float tk[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (k0 + u < p.chunks) tk[u] = p.gpart[(((size_t)n * p.chunks + k0 + u) * C + cc) * 2 + w];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 16; ++u)
                 if (k0 + u < p.chunks) t += tk[u];
         }
         gsum[w][cc] = t;
