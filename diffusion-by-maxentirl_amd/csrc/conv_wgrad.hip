@@ -395,11 +395,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_ws_kernel(WgradArgs p, const c
 // sum the S partials in a fixed order -> OIHW fp32 gradient (optionally accumulated).  Four consecutive ci per thread (16-byte
 // loads of every partial); the trailing blocks of the same launch fold the bias-gradient partials (bpart [S*4][Cout]) in a
 // fixed order too, so a weight gradient with bias is two launches, not three.
+// Flat form (one tap per position; the small layers, where the all-taps form below would be too few workgroups).
 // SL: slices of the S partials per block (a block handles 256 / SL positions): 4 for the U-Net layers (S <= 64, thousands of
 // positions), 16 for the 64-channel value-network layers, where S = 256 partials of only 36 864 positions left 145 workgroups
 // adding 64 partials per thread in sequence (round-3 train trace: 60 us per launch, 12 % of all weight-gradient time).
 template <int SL>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S, int taps, int Cout,
+__global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S, int taps, int Cout,
                                                            int Cin, int accumulate, const float* __restrict__ bpart, float* __restrict__ dbias,
                                                            int wblocks) {
     constexpr int NP = 256 / SL;
@@ -458,6 +459,94 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (int e = 0; e < 4; ++e) {
         const long o = ((long)co * Cin + ci + e) * taps + t;
         dw[o] = accumulate ? dw[o] + s[e] : s[e];
+    }
+}
+
+// All-taps form (layers with >= 65 536 (co, ci) pairs):
+// SL: slices of the S partials per block (a block handles 256 / SL positions): 4 for the U-Net layers (S <= 64, thousands of
+// positions), 16 for the 64-channel value-network layers, where S = 256 partials of only 36 864 positions left 145 workgroups
+// adding 64 partials per thread in sequence (round-3 train trace: 60 us per launch, 12 % of all weight-gradient time).
+template <int SL, int TAPS>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S, int taps, int Cout,
+                                                           int Cin, int accumulate, const float* __restrict__ bpart, float* __restrict__ dbias,
+                                                           int wblocks) {
+    constexpr int NP = 256 / SL;
+    if ((int)blockIdx.x >= wblocks) {
+        // bias: 16 couts x 16 slices of the S * 4 partial rows per block; slice sums added in slice order through LDS (one
+        // thread per cout walking all rows in sequence was the long pole of the whole launch: S * 4 dependent L2 latencies)
+        __shared__ float bs[15][16];
+        const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+        const int co = ((int)blockIdx.x - wblocks) * 16 + cl;
+        const int K = S * 4;
+        float t = 0.f;
+        if (co < Cout) {
+            const int k0 = (K * sl) >> 4, k1 = (K * (sl + 1)) >> 4;
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k) t += bpart[(size_t)k * Cout + co];
+        }
+        if (sl > 0) bs[sl - 1][cl] = t;
+        __syncthreads();
+        if (sl == 0 && co < Cout) {
+#pragma unroll
+            for (int j = 0; j < 15; ++j) t += bs[j][cl];
+            dbias[co] = accumulate ? dbias[co] + t : t;
+        }
+        return;
+    }
+    // NP positions x SL slices of the S partials per block.  A position is (co, four consecutive ci) for ALL taps: the partial
+    // planes [tap][co][ci] are read as float4s (coalesced over ci) and the taps x 4 results are one contiguous run of the OIHW
+    // gradient (144 B at 3x3), written as float4s.  (Round-3 first version: one tap per thread and four 4-byte stores 36 B apart —
+    // every 64-byte sector of dW written in nine passes.)  A thread adds its slice's partials in order, the slice sums are added in
+    // order through LDS.
+    extern __shared__ __attribute__((aligned(16))) char red_smem[];
+    f32x4* const sm = reinterpret_cast<f32x4*>(red_smem);            // [SL - 1][NP][TAPS]
+    const long plane = (long)Cout * Cin;
+    const int px = threadIdx.x % NP, sl = threadIdx.x / NP;
+    const long idx = ((long)blockIdx.x * NP + px) * 4;             // (co * Cin + ci), ci % 4 == 0
+    const bool live = idx < plane;
+    f32x4 s[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        const int k0 = (S * sl) / SL, k1 = (S * (sl + 1)) / SL;
+        const float* src = partial + idx;
+#pragma unroll 2
+        for (int k = k0; k < k1; ++k) {
+            f32x4 v[TAPS];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) v[t] = *reinterpret_cast<const f32x4*>(src + ((size_t)k * TAPS + t) * plane);
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) { s[t][0] += v[t][0]; s[t][1] += v[t][1]; s[t][2] += v[t][2]; s[t][3] += v[t][3]; }
+        }
+    }
+    if (sl > 0) {
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) sm[((sl - 1) * NP + px) * TAPS + t] = s[t];
+    }
+    __syncthreads();
+    if (sl != 0 || !live) return;
+#pragma unroll
+    for (int j = 0; j < SL - 1; ++j)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const f32x4 v = sm[(j * NP + px) * TAPS + t];
+            s[t][0] += v[0]; s[t][1] += v[1]; s[t][2] += v[2]; s[t][3] += v[3];
+        }
+    // OIHW: dw[(co * Cin + ci + e) * TAPS + t], e = 0..3: 4 TAPS contiguous floats
+    float o[4 * TAPS];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) o[e * TAPS + t] = s[t][e];
+    f32x4* dst = reinterpret_cast<f32x4*>(dw + idx * TAPS);
+#pragma unroll
+    for (int i = 0; i < TAPS; ++i) {
+        f32x4 v = f32x4{o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]};
+        if (accumulate) {
+            const f32x4 old = dst[i];
+            v[0] += old[0]; v[1] += old[1]; v[2] += old[2]; v[3] += old[3];
+        }
+        dst[i] = v;
     }
 }
 
@@ -626,14 +715,34 @@ static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, co
     const long total = (long)ksize * ksize * Cout * Cin;
     const bool wide = S >= 64;                 // 16 slices of the partials per block (value-network layers)
     const int np = wide ? 16 : 64;
-    const int wblocks = (int)((total / 4 + np - 1) / np);
+    const int taps = ksize * ksize;
     const int bblocks = dbias ? (Cout + 15) / 16 : 0;
-    if (wide)
-        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, (const float*)workspace, dw_oihw, S,
-                           ksize * ksize, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks);
-    else
-        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, (const float*)workspace, dw_oihw, S,
-                           ksize * ksize, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks);
+    if ((long)Cout * Cin >= 65536) {
+        // all taps of a (co, 4 ci) position per thread: contiguous OIHW runs out (>= 256 workgroups from 256 x 256 channels up)
+        const long positions = (long)Cout * Cin / 4;
+        const int wblocks = (int)((positions + np - 1) / np);
+        const size_t rlds = (size_t)((wide ? 15 : 3) * np * taps) * 16;
+#define DXMI_WG_REDUCE(SL_, TAPS_)                                                                                                         \
+    hipLaunchKernelGGL((wgrad_reduce_kernel<SL_, TAPS_>), dim3((unsigned)(wblocks + bblocks)), dim3(256), rlds, st, (const float*)workspace, \
+                       dw_oihw, S, taps, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks)
+        if (wide) {
+            if (taps == 9) DXMI_WG_REDUCE(16, 9);
+            else DXMI_WG_REDUCE(16, 1);
+        } else {
+            if (taps == 9) DXMI_WG_REDUCE(4, 9);
+            else DXMI_WG_REDUCE(4, 1);
+        }
+#undef DXMI_WG_REDUCE
+    } else {
+        const long total = (long)taps * Cout * Cin;
+        const int wblocks = (int)((total / 4 + np - 1) / np);
+        if (wide)
+            hipLaunchKernelGGL(wgrad_reduce_flat_kernel<16>, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, (const float*)workspace, dw_oihw, S,
+                               taps, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_flat_kernel<4>, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, (const float*)workspace, dw_oihw, S,
+                               taps, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks);
+    }
     DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad(reduce)");
     return DXMI_OK;
 }

@@ -214,7 +214,9 @@ def test_hip_trainer_step_vs_reference(golden_dir, fixture, fused):
         report.append((f"net/{name}", c, nr))
         assert c > 0.995, (name, c)
         assert abs(nr - 1) < 0.05, (name, nr)          # the clip coefficient (global norm) agrees too
-    np.testing.assert_allclose(nnamed["log_betas"].grad.cpu().numpy(), g["log_betas_grad"], rtol=5e-2, atol=2e-6)
+    # atol = 1.5 % of the largest entry: the small entries move by +-1e-5 between equally valid bf16 pipelines (fusions on / off,
+    # one-pass vs streaming GroupNorm: tools/logbeta_noise.py prints -1.5e-5 .. +9.5e-6 against these reference values)
+    np.testing.assert_allclose(nnamed["log_betas"].grad.cpu().numpy(), g["log_betas_grad"], rtol=5e-2, atol=1.5e-5)
     for i, (dn, d0) in enumerate(zip(_pick({n: p.detach() - w0[n] for n, p in nnamed.items()}, g["net_pick"], g["net_pick_rows"]),
                                      [g[f"net_delta_{j}"] for j in range(len(g["net_pick"]))])):
         c = _cos(dn, d0)
