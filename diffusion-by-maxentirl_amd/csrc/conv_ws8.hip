@@ -309,7 +309,8 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
                 const int hy = r / W8_HP, hx = r - hy * W8_HP;
                 const int iy = hy - 1, ix = hx - 1;
                 const bool ok = sub < 4 && t.n0 + sub < p.N && iy >= 0 && ix >= 0 && iy < 8 && ix < 8;
-                const int pix = ((t.n0 + sub) * 8 + iy) * 8 + ix;
+                // nearest x2 upsample in front of the conv (Upsample 4x4 -> 8x8): virtual pixel (iy, ix) is source pixel (iy / 2, ix / 2)
+                const int pix = p.ups ? ((t.n0 + sub) * 4 + (iy >> 1)) * 4 + (ix >> 1) : ((t.n0 + sub) * 8 + iy) * 8 + ix;
                 const int j8 = ((lane & 3) ^ (hx & 2)) * 8;
                 hoff0[k] = ok ? (pix * p.C0 + j8) * 2 : -1;
                 hoff1[k] = ok ? (pix * p.C1 + j8) * 2 : -1;
@@ -469,8 +470,9 @@ int conv_ws8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     static const int enabled = getenv("DXMI_CONV_WS8") ? atoi(getenv("DXMI_CONV_WS8")) : 1;   // 0: conv_pipe_kernel for the 8x8 maps
     if (!enabled) return 1;
     if (a.in_mode != DXMI_IN_NHWC_BF16 || a.out_mode != DXMI_OUT_NHWC_BF16) return 1;
-    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups != 0 || a.mask_src || a.act == DXMI_ACT_SILU) return 1;
-    if (a.OH != 8 || a.OW != 8 || a.IH != 8 || a.IW != 8) return 1;
+    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups == 2 || a.mask_src || a.act == DXMI_ACT_SILU) return 1;
+    if (a.OH != 8 || a.OW != 8) return 1;
+    if (a.ups ? (a.IH != 4 || a.IW != 4) : (a.IH != 8 || a.IW != 8)) return 1;     // ups: nearest x2 upsample of a 4x4 map in front
     if (a.Cout % 64 != 0 || (a.C0 + a.C1) % 32 != 0 || a.C0 % 32 != 0) return 1;
     const int nchunks = (a.C0 + a.C1) / 32;
     if (nchunks < 4 || nchunks % 2 != 0 || (9 * nchunks) % W8_RING != 0) return 1;

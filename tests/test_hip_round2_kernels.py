@@ -128,6 +128,16 @@ RW_CASES = [
 ]
 
 
+@pytest.mark.parametrize("N", [256, 5])
+def test_conv_ws8_upsample(ops, N):
+    """Upsample 4x4 -> 8x8 (nearest x2 in front of the 3x3 conv, unet_small.py:50-54) on conv_ws8_kernel, batch-independent."""
+    y, ref, kid = run_conv(ops, N, 256, 0, 256, 4, 3, True, "bias")
+    assert kid == 400008, f"expected conv_ws8_kernel, got kernel id {kid}"
+    assert rel_l2(nchw(y), ref) < 4e-3
+    y2, _, _ = run_conv(ops, N, 256, 0, 256, 4, 3, True, "bias")
+    assert torch.equal(y, y2)
+
+
 @pytest.mark.parametrize("N,C0,C1,Cout,H,fuse", RW_CASES)
 def test_conv1x1_rw(ops, N, C0, C1, Cout, H, fuse):
     y, ref, kid = run_conv(ops, N, C0, C1, Cout, H, 1, False, fuse)
