@@ -89,8 +89,8 @@ def kernel_name(kid):
         return "conv_head_kernel"
     if kid >= 500000:
         return f"conv1x1_rw_kernel<{(kid // 1000) % 10}, {(kid // 10) % 100}, {'true' if kid % 10 else 'false'}>"
-    if kid == 400008:
-        return "conv_ws8_kernel"
+    if kid in (400008, 400009):      # 400009: OpProfiler's tag for a launch with the fused GroupNorm output (gn_out)
+        return "conv_ws8_kernel<true>" if kid == 400009 else "conv_ws8_kernel<false>"
     if kid >= 450000:
         return f"conv_sm_kernel<{2 if (kid - 450000) // 100 == 4 else 3}, 8, {kid % 100}>"
     if kid >= 400000:

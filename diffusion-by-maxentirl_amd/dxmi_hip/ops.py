@@ -230,6 +230,8 @@ class OpProfiler:
             res_b += out_b if not (d.gn_flags & 2) else 0
         w_b = d.Cout * cin * 2
         cls = "conv_other" if kid >= 600000 else "conv1x1" if kid >= 500000 else "conv3x3" if kid >= 400000 else "conv_stem" if kid >= 300000 else ("conv1x1" if kid >= 200000 else ("conv3x3" if kid >= 30000 else "conv_other"))
+        if kid == 400008 and d.gn_out:
+            kid = 400009                                  # conv_ws8_kernel<true> (bench.py kernel_name)
         self.bracket(cls, kid, flops, in_b + out_b + res_b + w_b,
                      lambda: check(lib.dxmi_conv2d_fwd(ctypes.byref(d), _stream()), "dxmi_conv2d_fwd"))
 
