@@ -502,8 +502,11 @@ def main():
             "events": "two extra steps after the timed region, every launch bracketed on its stream",
         }
         line["roofline_classes"] = class_rooflines(gen_summ, step_s)
+        # per conv kernel: time, rate, algorithmic bytes per launch and the HBM-side bytes per launch of the committed PMC passes
         line["conv_kernels"] = {kernel_name(k[1]): {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in convs.items()}
+                                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                                                    "algorithmic_bytes_per_launch": round(v["bytes"] / v["launches"]),
+                                                    "traffic": pmc_traffic(kernel_name(k[1]))[0]} for k, v in convs.items()}
     if train_summ:
         line["train_roofline_classes"] = class_rooflines(train_summ, t_train_step)
     if world == 1 and not args.no_edm:
