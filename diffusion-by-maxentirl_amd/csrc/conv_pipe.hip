@@ -667,7 +667,6 @@ int conv1x1_rw_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);   // con
 int conv_head_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);    // conv_head.hip
 int conv_ws8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);     // conv_ws8.hip
 int conv_sm_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);      // conv_sm.hip
-int conv_c64_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);     // conv_c64.hip
 
 // Pixels per tile of the kernels whose epilogue (conv_epilogue_lds) can emit GroupNorm block statistics, 0 for the others:
 // conv_stem_kernel (300000), conv_pipe_kernel (k NB pmax = 10000 k + 100 NB + pmax) and conv1x1_stream_kernel (200000), for
@@ -714,8 +713,6 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
         rc = conv_sm_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;
         rc = conv_ws8_try_launch(a, st, kernel_id);
-        if (rc <= 0) return rc;
-        rc = conv_c64_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;
     }
     if (a.in_mode == DXMI_IN_NCHW_F32_K27 && a.out_mode == DXMI_OUT_NHWC_BF16 && a.Cout % 64 == 0) return conv_stem_launch(a, st, kernel_id);

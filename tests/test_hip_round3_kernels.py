@@ -433,46 +433,3 @@ def test_stem_and_stride2_conv_block_stats(ops):
     x4 = torch.randn(N, 16, 16, 128, generator=g).to(torch.bfloat16).to(DEV)
     y4, st4 = ops.conv2d(x4, pw2, want_stats=True, **kw)
     assert st4 is None or (st4.buf.double().sum(1) - _torch_block_stats(y4)).abs().max().item() <= 1e-3
-
-
-# -------------------------------------------------------------------------- 64 -> 64 conv with register-resident weights (value net)
-@pytest.mark.parametrize("N,H,res,mask,act", [(5, 32, False, False, True), (3, 16, True, False, False), (4, 32, False, True, False),
-                                              (256, 32, False, False, True), (7, 16, True, True, True)])
-def test_conv_c64(ops, N, H, res, mask, act):
-    """conv_c64_kernel (IGEBMEncoderV2's 64 -> 64 ResBlockV2 convs, models/modules.py:39-101, forward and data gradient): against
-    torch fp32, bitwise reproducible and independent of the batch."""
-    g = torch.Generator().manual_seed(31 + N + H)
-    x = torch.randn(N, H, H, 64, generator=g).to(torch.bfloat16).to(DEV)
-    w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(DEV)
-    pw = ops.pack_conv_weight(w)
-    b = torch.randn(64, generator=g).to(DEV)
-    r = torch.randn(N, H, H, 64, generator=g).to(torch.bfloat16).to(DEV) if res else None
-    m = torch.randn(N, H, H, 64, generator=g).to(torch.bfloat16).to(DEV) if mask else None
-    kw = dict(bias=b, residual=r, mask_src=m, mask_slope=0.2, act=ops.ACT_LEAKY02 if act else ops.ACT_NONE)
-    prof = ops.OpProfiler()
-    ops.PROFILER = prof
-    try:
-        y = ops.conv2d(x, pw, **kw)
-    finally:
-        ops.PROFILER = None
-    torch.cuda.synchronize()
-    assert [k[1] for k in prof.summary()] == [460000 + (32 if H == 32 else 16)]
-    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), b, padding=1)
-    if res:
-        ref = ref + r.float().permute(0, 3, 1, 2)
-    if mask:
-        ref = ref * torch.where(m.float().permute(0, 3, 1, 2) > 0, 1.0, 0.2)
-    if act:
-        ref = F.leaky_relu(ref, 0.2)
-    ref = ref.permute(0, 2, 3, 1)
-    assert ((y.float() - ref).norm() / ref.norm()).item() < 4e-3
-    assert torch.equal(y, ops.conv2d(x, pw, **kw))
-    i = N // 2
-    one = ops.conv2d(x[i:i + 1].contiguous(), pw, bias=b, residual=None if r is None else r[i:i + 1].contiguous(),
-                     mask_src=None if m is None else m[i:i + 1].contiguous(), mask_slope=0.2, act=kw["act"])
-    assert torch.equal(one[0], y[i])
-    # the transposed-flipped pack (data gradient) through the same kernel
-    pwt = ops.pack_conv_weight(w, transpose_flip=True)
-    yt = ops.conv2d(x, pwt)
-    reft = F.conv_transpose2d(x.float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), padding=1).permute(0, 2, 3, 1)
-    assert ((yt.float() - reft).norm() / reft.norm()).item() < 4e-3
