@@ -397,7 +397,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_ws_kernel(WgradArgs p, const c
 // fixed order too, so a weight gradient with bias is two launches, not three.
 // Flat form (one tap per position; the small layers, where the all-taps form below would be too few workgroups).
 // SL: slices of the S partials per block (a block handles 256 / SL positions): 4 for the U-Net layers (S <= 64, thousands of
-// positions), 16 for the 64-channel value-network layers, where S = 256 partials of only 36 864 positions left 145 workgroups
+// positions), 16 for layers that are one or two 64 x 64 blocks, where S = 256 partials of only 36 864 positions left 145 workgroups
 // adding 64 partials per thread in sequence (round-3 train trace: 60 us per launch, 12 % of all weight-gradient time).
 template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S, int taps, int Cout,
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_flat_kernel(const float* __r
 
 // All-taps form (layers with >= 65 536 (co, ci) pairs):
 // SL: slices of the S partials per block (a block handles 256 / SL positions): 4 for the U-Net layers (S <= 64, thousands of
-// positions), 16 for the 64-channel value-network layers, where S = 256 partials of only 36 864 positions left 145 workgroups
+// positions), 16 for layers that are one or two 64 x 64 blocks, where S = 256 partials of only 36 864 positions left 145 workgroups
 // adding 64 partials per thread in sequence (round-3 train trace: 60 us per launch, 12 % of all weight-gradient time).
 template <int SL, int TAPS>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int S, int taps, int Cout,
@@ -722,7 +722,7 @@ static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, co
 #undef DXMI_WG_LAUNCH
     DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad");
     const long total = (long)ksize * ksize * Cout * Cin;
-    const bool wide = S >= 64;                 // 16 slices of the partials per block (value-network layers)
+    const bool wide = S >= 64;                 // 16 slices of the partials per block (layers of one or two 64 x 64 blocks)
     const int np = wide ? 16 : 64;
     const int taps = ksize * ksize;
     const int bblocks = dbias ? (Cout + 15) / 16 : 0;
