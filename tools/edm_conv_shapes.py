@@ -1,4 +1,4 @@
-"""GPU box: every conv shape of one EDM U-Net forward (ImageNet-64 net, B=100) with its kernel id, launch count and graph-captured
+"""GPU box: every conv shape of one U-Net forward (EDM nets, or `cifar10 256` for the DDPM net) with its kernel id, launch count and graph-captured
 time: where the 1x1 / small-kernel time goes.   python tools/edm_conv_shapes.py imagenet64_T10 100 [ksize]"""
 import os, sys, ctypes, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,14 +11,20 @@ from dxmi_hip import ops
 
 name, B = sys.argv[1], int(sys.argv[2])
 only_k = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-cfg = configs_builtin.get(name)
 torch.manual_seed(0)
-net, diffusion = create_model_and_diffusion(**cfg.diffusion)
-for n, p in net.named_parameters():
-    if p.abs().max() == 0:
-        torch.nn.init.normal_(p, std=0.02)
-s = OpenAIDiffusion(net, diffusion, **cfg.sampler)
-net.to("cuda:0").eval()
+if name == "cifar10":         # the DDPM U-Net of BASELINE configs[1] behind the VARSampler
+    sys.path.insert(0, ROOT)
+    import bench
+    s = bench.build_sampler("cuda:0", 10)
+    net = s.net
+else:
+    cfg = configs_builtin.get(name)
+    net, diffusion = create_model_and_diffusion(**cfg.diffusion)
+    for n, p in net.named_parameters():
+        if p.abs().max() == 0:
+            torch.nn.init.normal_(p, std=0.02)
+    s = OpenAIDiffusion(net, diffusion, **cfg.sampler)
+    net.to("cuda:0").eval()
 shapes = collections.Counter()
 orig = ops.conv2d
 
