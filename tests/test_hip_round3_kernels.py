@@ -433,3 +433,32 @@ def test_stem_and_stride2_conv_block_stats(ops):
     x4 = torch.randn(N, 16, 16, 128, generator=g).to(torch.bfloat16).to(DEV)
     y4, st4 = ops.conv2d(x4, pw2, want_stats=True, **kw)
     assert st4 is None or (st4.buf.double().sum(1) - _torch_block_stats(y4)).abs().max().item() <= 1e-3
+
+
+def test_multi_tensor_pack_equals_per_weight_pack(ops):
+    """dxmi_pack_conv_weights (one thread per fragment lane, all taps; contiguous-run fast path and guarded generic path) writes
+    bitwise the images of dxmi_pack_conv_weight for 3x3 / 1x1 / stem / transposed-flipped / ragged shapes."""
+    g = torch.Generator().manual_seed(3)
+    cases = [((128, 128, 3, 3), False, False), ((256, 384, 3, 3), False, False), ((192, 192, 3, 3), False, False),
+             ((768, 256, 1, 1), False, False), ((128, 3, 3, 3), False, True), ((256, 128, 3, 3), True, False),
+             ((96, 72, 3, 3), False, False), ((40, 24, 1, 1), False, False), ((3, 128, 3, 3), False, False), ((128, 256, 1, 1), True, False)]
+    ws = [(torch.randn(*shape, generator=g).to(DEV), tf, k27) for shape, tf, k27 in cases]
+    single = [ops.pack_conv_weight(w, transpose_flip=tf, k27=k27) for w, tf, k27 in ws]
+    with ops.pack_batch():
+        batched = [ops.pack_conv_weight(w, transpose_flip=tf, k27=k27) for w, tf, k27 in ws]
+    torch.cuda.synchronize()
+    for (shape, tf, k27), a, b in zip(cases, single, batched):
+        assert (a.Cout, a.Cin, a.ksize) == (b.Cout, b.Cin, b.ksize)
+        assert torch.equal(a.buf, b.buf), (shape, tf, k27)
+
+
+def test_colsum_f32(ops):
+    g = torch.Generator().manual_seed(4)
+    for B, N, C in ((2, 256, 128), (2, 7, 384), (1, 100, 40), (3, 16, 2304)):
+        x = torch.randn(B, N, C, generator=g).to(DEV)
+        got = ops.colsum_f32(x)
+        assert tuple(got.shape) == (B, C)
+        assert (got.double() - x.double().sum(1)).abs().max().item() <= 1e-5 * N ** 0.5 * 4
+        assert torch.equal(got, ops.colsum_f32(x))
+    x2 = torch.randn(33, 64, generator=g).to(DEV)
+    assert (ops.colsum_f32(x2).double() - x2.double().sum(0)).abs().max().item() <= 1e-4
