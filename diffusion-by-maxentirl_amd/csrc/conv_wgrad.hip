@@ -40,6 +40,7 @@ struct WgradArgs {
 
 constexpr int WG_PITCH = 192;  // bytes per LDS pixel row (64 channels bf16 + 64 pad)
 
+
 __device__ __forceinline__ bf16x8 tr_frag(const char* row_lo, const char* row_hi) {
     // two transposing reads: k (pixel) 0..3 and 4..7 of this lane's channel
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(row_lo));
@@ -392,6 +393,145 @@ __global__ __launch_bounds__(512) void conv_wgrad_ws_kernel(WgradArgs p, const c
         }
 }
 
+// 1x1 weight gradient with a 128 co x 128 ci block per workgroup.  The 64 x 64 block of the kernel above moves 32 KB of dY and X per
+// 128-pixel tile for ONE MFLOP (8 MFMAs per wave against 8 DMAs per loader) through a two-deep buffer: one tile in flight per
+// workgroup, so every tile pays its memory latency (q|k|v 256 -> 768: 24 tiles x ~3 us = the 77 us the launch takes, 20 GB/s per CU).
+// With TAPS = 1 the accumulators are small, so a workgroup takes 128 x 128 (half the operand re-reads) and the tiles are 64 pixels
+// deep in a ring of FOUR 32 KB slots — three tiles (96 KB) in flight per CU: four 64-channel sub-tiles per tile (dY 0 / 1, X 0 / 1,
+// each in the row layout and swizzle of the kernel above), eight loader waves with counted in-order vmcnt waits, one workgroup per
+// CU; MFMA wave (wr, wc) owns cout half wr of both dY sub-tiles x ci half wc of both X sub-tiles (four 32 x 32 blocks).
+// A 1x1 conv's dY and X rows share their pixel index: a tile is 64 consecutive rows of the flat [N*H*W][C] tensors.
+// Scope: stride 1, no upsample, Cin % 128 == 0 (both concat parts), Cout % 128 == 0, N*H*W % 64 == 0.
+__global__ __launch_bounds__(768) void conv_wgrad1x1_b128_kernel(WgradArgs p) {
+    constexpr int TPX = 64;                     // pixels per tile
+    constexpr int SUB = TPX * 128;              // one 64-channel sub-tile: 64 rows x 128 B
+    constexpr int BUF = 4 * SUB;                // dY0 | dY1 | X0 | X1 = 32 KB
+    constexpr int RING = 4;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int b = blockIdx.x;
+    const int cib = b % p.CIB; b /= p.CIB;
+    const int cob = b % p.COB; b /= p.COB;
+    const int split = b;
+    const int ci0 = cib * 128, co0 = cob * 128;
+    const int ntile = split < p.PT ? (p.PT - 1 - split) / p.S + 1 : 0;
+    const int Cin = p.C0 + p.C1;
+
+    if (wave >= 4) {
+        // ============================================================ loaders (8 waves): 32 one-KiB pieces per tile, 4 each
+        const int l = wave - 4;
+        const bool first = ci0 < p.C0;
+        const char* const xsrc = reinterpret_cast<const char*>((first ? p.x0 : p.x1) + (first ? ci0 : ci0 - p.C0));
+        const int Cs = first ? p.C0 : p.C1;
+        const char* const dysrc = reinterpret_cast<const char*>(p.dy + co0);
+        const int prow = lane >> 3, pslot = lane & 7;
+        // piece j = l + 8 k (k = 0..3): sub-tile j >> 3 (0, 1: dY; 2, 3: X), rows 8 (j & 7) + prow; LDS slot pslot holds channel
+        // piece pslot ^ ((R & 2) << 1) of the row
+        long rel[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = l + 8 * k, st = j >> 3, R = (j & 7) * 8 + prow;
+            const int piece = pslot ^ ((R & 2) << 1);
+            rel[k] = st < 2 ? ((long)R * p.Cout + (st & 1) * 64 + piece * 8) * 2 : ((long)R * Cs + (st & 1) * 64 + piece * 8) * 2;
+        }
+        auto issue_tile = [&](int it) {
+            const int pt = split + it * p.S;
+            char* const buf = smem + (it % RING) * BUF;
+            const char* const yb = dysrc + (size_t)pt * TPX * p.Cout * 2;
+            const char* const xb = xsrc + (size_t)pt * TPX * Cs * 2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = l + 8 * k;
+                const char* src = (j >> 3) < 2 ? yb + rel[k] : xb + rel[k];
+                __builtin_amdgcn_global_load_lds(WG_GPTR(src), WG_LPTR(buf + j * 1024), 16, 0, 0);
+            }
+        };
+        for (int it = 0; it < RING - 1 && it < ntile; ++it) issue_tile(it);
+        for (int it = 0; it < ntile; ++it) {
+            // in-order retirement: tile `it` has landed when at most the 4 DMAs of each younger tile in flight are outstanding
+            const int younger = ntile - 1 - it < RING - 2 ? ntile - 1 - it : RING - 2;
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                // B_it: tile it landed; the MFMA waves are done with tile it - 1
+            if (it + RING - 1 < ntile) issue_tile(it + RING - 1);        // into the slot tile it - 1 vacated
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // ================================================================ MFMA waves: (cout half wr of dY0, dY1) x (ci half wc of X0, X1)
+    const int wr = wave >> 1, wc = wave & 1;
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int ch_off = (16 * (g & 1) + 4 * pp) * 2;
+    const int krow = 8 * (g >> 1) + q;
+    auto saddr = [&](int R, int hc) -> int { return ((R << 7) + hc) ^ ((R & 2) << 5); };
+    f32x16 acc[2][2];
+    float bsum = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    for (int it = 0; it < ntile; ++it) {
+        const char* const ybuf = smem + (it % RING) * BUF;
+        const char* const xbuf = ybuf + 2 * SUB;
+        __builtin_amdgcn_s_waitcnt(0xc07f);             // lgkmcnt(0): this wave's reads of the previous tile are complete
+        __builtin_amdgcn_s_barrier();                    // B_it
+        if (p.bpart && cib == 0) {   // bias gradient rides along: 128 couts x 64 staged pixels, two row halves
+            const int col = tid & 127, part = tid >> 7;
+            const char* const sub = ybuf + (col >> 6) * SUB;
+#pragma unroll 8
+            for (int px = part * 32; px < part * 32 + 32; ++px) bsum += (float)*reinterpret_cast<const bf16*>(sub + saddr(px, (col & 63) * 2));
+        }
+        // k-step kb = pixels 16 kb .. + 15: two dY fragments, two X fragments, four MFMAs; reads run two k-steps ahead
+        bf16x8 af[3][2], bfr[3][2];
+        auto read_step = [&](int kb) {
+            const int plo = kb * 16 + krow;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const char* al = ybuf + u * SUB + saddr(plo, wr * 64 + ch_off);
+                af[kb % 3][u] = tr_frag(al, al + 512);                   // rows plo, plo + 4: same swizzle bit
+                const char* bl = xbuf + u * SUB + saddr(plo, wc * 64 + ch_off);
+                bfr[kb % 3][u] = tr_frag(bl, bl + 512);
+            }
+        };
+        read_step(0);
+        read_step(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < TPX / 16; ++kb) {
+            if (kb + 2 < TPX / 16) read_step(kb + 2);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kb % 3][a], bfr[kb % 3][c], acc[a][c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (p.bpart && cib == 0) {
+        // four partial rows per split (the reduce adds S * 4 rows): rows 0, 1 = the two pixel halves, rows 2, 3 = 0
+        const int col = tid & 127, part = tid >> 7;
+        p.bpart[((size_t)split * 4 + part) * p.Cout + co0 + col] = bsum;
+        p.bpart[((size_t)split * 4 + 2 + part) * p.Cout + co0 + col] = 0.f;
+    }
+    const int h = lane >> 5;
+    float* pb = p.partial + (size_t)split * p.Cout * Cin;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + a * 64 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int ci = ci0 + c * 64 + wc * 32 + (lane & 31);
+                pb[(size_t)co * Cin + ci] = acc[a][c][r];
+            }
+}
+
 // sum the S partials in a fixed order -> OIHW fp32 gradient (optionally accumulated).  Four consecutive ci per thread (16-byte
 // loads of every partial); the trailing blocks of the same launch fold the bias-gradient partials (bpart [S*4][Cout]) in a
 // fixed order too, so a weight gradient with bias is two launches, not three.
@@ -641,10 +781,48 @@ int ilog2w(int v) {
 
 extern "C" int64_t dxmi_conv2d_wgrad_workspace_bytes(int32_t N, int32_t OH, int32_t OW, int32_t Cin, int32_t Cout, int32_t ksize) {
     const long PT = ((long)N * OH * OW + 127) / 128 + 16;
-    long S = 512 / ((long)(Cin / 64) * (Cout / 64));      // upper bound of the split count chosen at launch
+    long S = (ksize == 1 ? 1024 : 512) / ((long)(Cin / 64) * (Cout / 64));      // upper bound of the split count chosen at launch (1x1: 128 x 128 blocks, 256 workgroups)
     if (S < 1) S = 1;
     if (S > PT) S = PT;
     return S * ksize * ksize * (int64_t)Cout * Cin * 4 + S * 4 * (int64_t)Cout * 4;   // + bias-gradient partials
+}
+
+// the fixed-order reduce of the S split partials (+ the bias partials) behind every weight-gradient kernel
+static int wgrad_reduce_launch(const WgradArgs& a, void* workspace, float* dw_oihw, float* dbias, int S, int ksize, int Cout, int Cin,
+                               int accumulate, hipStream_t st) {
+    const long total = (long)ksize * ksize * Cout * Cin;
+    const bool wide = S >= 64;                 // 16 slices of the partials per block (layers of one or two 64 x 64 blocks)
+    const int np = wide ? 16 : 64;
+    const int taps = ksize * ksize;
+    const int bblocks = dbias ? (Cout + 15) / 16 : 0;
+    if ((long)Cout * Cin >= 65536) {
+        // all taps of a (co, 4 ci) position per thread: contiguous OIHW runs out (>= 256 workgroups from 256 x 256 channels up)
+        const long positions = (long)Cout * Cin / 4;
+        const int wblocks = (int)((positions + np - 1) / np);
+        const size_t rlds = (size_t)((wide ? 15 : 3) * np * taps) * 16;
+#define DXMI_WG_REDUCE(SL_, TAPS_)                                                                                                         \
+    hipLaunchKernelGGL((wgrad_reduce_kernel<SL_, TAPS_>), dim3((unsigned)(wblocks + bblocks)), dim3(256), rlds, st, (const float*)workspace, \
+                       dw_oihw, S, taps, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks)
+        if (wide) {
+            if (taps == 9) DXMI_WG_REDUCE(16, 9);
+            else DXMI_WG_REDUCE(16, 1);
+        } else {
+            if (taps == 9) DXMI_WG_REDUCE(4, 9);
+            else DXMI_WG_REDUCE(4, 1);
+        }
+#undef DXMI_WG_REDUCE
+    } else {
+        const long total = (long)taps * Cout * Cin;
+        const int wblocks = (int)((total / 4 + np - 1) / np);
+        if (wide)
+            hipLaunchKernelGGL(wgrad_reduce_flat_kernel<16>, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, (const float*)workspace, dw_oihw, S,
+                               taps, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_flat_kernel<4>, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, (const float*)workspace, dw_oihw, S,
+                               taps, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks);
+    }
+    DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad(reduce)");
+    return DXMI_OK;
 }
 
 static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, const void* dy, float* dw_oihw, float* dbias,
@@ -667,6 +845,24 @@ static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, co
     a.HH = (TH - 1) * stride + ksize; a.HWd = (TW - 1) * stride + ksize;
     const int ngroups = (N + a.SUBS - 1) / a.SUBS;
     a.PT = ngroups * (OH / TH) * (OW / TW);
+    static const int b128_env = getenv("DXMI_WGRAD_B128") ? atoi(getenv("DXMI_WGRAD_B128")) : 1;     // 0: 64 x 64 blocks for every 1x1 layer
+    const long npix = (long)N * OH * OW;
+    if (b128_env && ksize == 1 && stride == 1 && !upsample && pad == 0 && IH == OH && IW == OW && Cin % 128 == 0 && C0 % 128 == 0 &&
+        Cout % 128 == 0 && npix % 64 == 0 && npix * (C0 > C1 ? C0 : C1) * 2 < (1L << 31) && npix * Cout * 2 < (1L << 31)) {
+        a.CIB = Cin / 128; a.COB = Cout / 128;
+        a.PT = (int)(npix / 64);               // 64-pixel tiles
+        int S = 256 / (a.CIB * a.COB);              // one 768-thread workgroup per CU
+        if (S < 1) S = 1;
+        if (S > a.PT) S = a.PT;
+        a.S = S;
+        a.bpart = dbias ? reinterpret_cast<float*>(workspace) + (size_t)S * Cout * Cin : nullptr;
+        hipStream_t st = (hipStream_t)stream;
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad1x1_b128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        hipLaunchKernelGGL(conv_wgrad1x1_b128_kernel, dim3(S * a.CIB * a.COB), dim3(768), (size_t)4 * 4 * 64 * 128, st, a);
+        DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad(1x1 b128)");
+        return wgrad_reduce_launch(a, workspace, dw_oihw, dbias, S, ksize, Cout, Cin, accumulate, st);
+    }
     a.CIB = Cin / 64; a.COB = Cout / 64;
     // pixel splits: the kernel holds one workgroup per CU (368 registers per lane), so 256 workgroups fill the chip; more
     // splits only add partial-sum traffic (each split writes and the reduce re-reads taps x Cout x Cin floats)
@@ -721,39 +917,7 @@ static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, co
     else { if (pf) DXMI_WG_LAUNCH(1, true); else DXMI_WG_LAUNCH(1, false); }
 #undef DXMI_WG_LAUNCH
     DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad");
-    const long total = (long)ksize * ksize * Cout * Cin;
-    const bool wide = S >= 64;                 // 16 slices of the partials per block (layers of one or two 64 x 64 blocks)
-    const int np = wide ? 16 : 64;
-    const int taps = ksize * ksize;
-    const int bblocks = dbias ? (Cout + 15) / 16 : 0;
-    if ((long)Cout * Cin >= 65536) {
-        // all taps of a (co, 4 ci) position per thread: contiguous OIHW runs out (>= 256 workgroups from 256 x 256 channels up)
-        const long positions = (long)Cout * Cin / 4;
-        const int wblocks = (int)((positions + np - 1) / np);
-        const size_t rlds = (size_t)((wide ? 15 : 3) * np * taps) * 16;
-#define DXMI_WG_REDUCE(SL_, TAPS_)                                                                                                         \
-    hipLaunchKernelGGL((wgrad_reduce_kernel<SL_, TAPS_>), dim3((unsigned)(wblocks + bblocks)), dim3(256), rlds, st, (const float*)workspace, \
-                       dw_oihw, S, taps, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks)
-        if (wide) {
-            if (taps == 9) DXMI_WG_REDUCE(16, 9);
-            else DXMI_WG_REDUCE(16, 1);
-        } else {
-            if (taps == 9) DXMI_WG_REDUCE(4, 9);
-            else DXMI_WG_REDUCE(4, 1);
-        }
-#undef DXMI_WG_REDUCE
-    } else {
-        const long total = (long)taps * Cout * Cin;
-        const int wblocks = (int)((total / 4 + np - 1) / np);
-        if (wide)
-            hipLaunchKernelGGL(wgrad_reduce_flat_kernel<16>, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, (const float*)workspace, dw_oihw, S,
-                               taps, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks);
-        else
-            hipLaunchKernelGGL(wgrad_reduce_flat_kernel<4>, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, (const float*)workspace, dw_oihw, S,
-                               taps, Cout, Cin, accumulate, (const float*)a.bpart, dbias, wblocks);
-    }
-    DXMI_CHECK_LAUNCH("dxmi_conv2d_wgrad(reduce)");
-    return DXMI_OK;
+    return wgrad_reduce_launch(a, workspace, dw_oihw, dbias, S, ksize, Cout, Cin, accumulate, st);
 }
 
 extern "C" int dxmi_conv2d_wgrad(const void* x0, int32_t C0, const void* x1, int32_t C1, const void* dy, float* dw_oihw,

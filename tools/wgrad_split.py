@@ -8,7 +8,7 @@ from dxmi_hip import ops
 dev = "cuda:0"
 torch.manual_seed(0)
 SHAPES = [(256, 32, 128, 128, 3), (256, 32, 256, 128, 3), (256, 16, 256, 256, 3), (256, 16, 512, 256, 3), (256, 8, 256, 256, 3),
-          (256, 4, 256, 256, 3), (256, 16, 256, 768, 1), (256, 16, 256, 256, 1), (256, 32, 64, 64, 3), (256, 16, 64, 128, 3), (256, 16, 128, 128, 3)]
+          (256, 4, 256, 256, 3), (256, 16, 256, 768, 1), (256, 16, 256, 256, 1), (256, 32, 256, 128, 1), (256, 16, 512, 256, 1), (256, 16, 128, 256, 1), (256, 16, 128, 128, 3)]
 if __name__ == "__main__":
     for (N, H, Cin, Cout, k) in SHAPES:
         x = torch.randn(N, H, H, Cin, device=dev).to(torch.bfloat16)
