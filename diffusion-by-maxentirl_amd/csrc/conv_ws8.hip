@@ -19,7 +19,10 @@ constexpr int W8_HP = 10, W8_HS = 100;              // halo row pitch / pixels p
 constexpr int W8_HALO_BLOCKS = 25;                  // 4 x 100 pixels x 64 B = 25 KiB exactly
 constexpr int W8_HALO = W8_HALO_BLOCKS * 1024;
 constexpr int W8_A_SLOT = 4096;                     // one (chunk, tap): 2 k-steps x 2 cout blocks x 1 KiB fragments
-constexpr int W8_RING = 6;
+#ifndef W8_RING_SLOTS
+#define W8_RING_SLOTS 6
+#endif
+constexpr int W8_RING = W8_RING_SLOTS;        // must divide 18 (the MFMA waves index slots by the step inside a chunk pair)
 constexpr int W8_A_RING = W8_RING * W8_A_SLOT;
 constexpr int W8_RO = 256 * 128;                    // 256 px x 64 co bf16
 constexpr int W8_TB = 2048;                         // bias[64] | temb[4][64] fp32
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
         };
 #pragma unroll 1
         for (int g = 0; g < W8_RING - 1; ++g) issue_tap(cur.cot, g);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // tap 0 landed (4 younger taps may be outstanding)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (W8_RING - 2)) : "memory");    // tap 0 landed (RING - 2 younger taps may be outstanding)
         w8_barrier();                                       // P0
         for (;;) {
             const bool more = q + qstride < ntiles;
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
                 if (g3 < S) issue_tap(cur.cot, g3);
                 else if (more) issue_tap(nxt.cot, g3 - S);      // same ring slot: S % RING == 0 (host-checked)
                 else issued = false;
-                if (issued) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // taps g+2 .. g+5 (8 DMAs) may be outstanding
+                if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (W8_RING - 2)) : "memory");    // taps g+2 .. g+RING-1 may be outstanding
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 w8_barrier();                                    // B_g
             }

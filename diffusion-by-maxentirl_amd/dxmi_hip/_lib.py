@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdxmi_hip.so")
+LIB_PATH = os.environ.get("DXMI_LIB") or os.path.join(_HERE, "libdxmi_hip.so")      # DXMI_LIB: another build of the same library (A/B timing)
 
 c_void_p, c_int, c_float, c_int64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float, ctypes.c_int64
 
