@@ -27,6 +27,13 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
+// halo blocks per bulk mover and step / number of steps that issue them (HB2 = 11 blocks per mover and chunk): 2 x 6 by default;
+// -DWS_HALO_PER=3 -DWS_HALO_STEPS=4 or 4 x 3 issue them earlier in the chunk (A/B builds through DXMI_LIB)
+#ifndef WS_HALO_PER
+#define WS_HALO_PER 2
+#define WS_HALO_STEPS 6
+#endif
+
 #ifdef DXMI_CONV_STAMPS
 // timing-only build (make STAMPS=1): cycles MFMA wave 0 of every workgroup spends in each step barrier (tools/ws_stamps.py)
 __device__ unsigned g_ws_wait[256][176];
@@ -536,7 +543,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 int young = 0;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    if (t < 6 && do_halo) halo_issue(hc, hbuf, 2 * t, 2 * t + 2);
+                    if (t < WS_HALO_STEPS && do_halo) halo_issue(hc, hbuf, WS_HALO_PER * t, WS_HALO_PER * t + WS_HALO_PER);
                     WS_TSTAMP(164, wave == 6 && c == 0 && t == 0 && q == (int)blockIdx.x + qstride);
                     // tile-switch pieces of this step (piece_range: one per step while the halo blocks are being issued, two per
                     // step afterwards — at most four vector-memory instructions per mover and step).  Their LDS reads were
@@ -551,7 +558,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                                 if (ka + u < kb && piece_ok(prev, ka + u)) *reinterpret_cast<bf16x8*>(out_prev + piece_rel(ka + u)) = vcur[u];
                         }
                         fetch_residual_at(res_cur, cur, ka, kb);
-                        if (t >= 5) young += (kb - ka) * ((do_drain ? 1 : 0) + (do_res ? 1 : 0));   // issued after the last halo block
+                        if (t >= WS_HALO_STEPS - 1) young += (kb - ka) * ((do_drain ? 1 : 0) + (do_res ? 1 : 0));   // issued after the last halo block
                     }
                     WS_TSTAMP(165, wave == 6 && c == 0 && t == 0 && q == (int)blockIdx.x + qstride);
                     if (t < 8) piece_range(c, t + 1, na, nb_); else piece_range(c + 1, 0, na, nb_);
