@@ -17,7 +17,9 @@ The JSON line also carries
                      duration from HIP events on the launch stream, against the dense bf16 MFMA peak (2.5 PFLOP/s);
   roofline_classes   the same per kernel class — conv3x3 / conv1x1 (MFMA-graded), GroupNorm / attention / sampler step
                      (HBM-graded, algorithmic bytes / 8 TB/s), and for the train leg wgrad (MFMA), GroupNorm backward,
-                     optimiser, replay gather (HBM);
+                     optimiser, replay gather (HBM); `traffic` = HBM-side bytes per launch of the class's main kernel and
+                     `conv_kernels[*].traffic` per conv kernel, from the committed rocprofv3 --pmc passes (profiles/);
+  edm                BASELINE configs[3] / [4] generation (ImageNet-64 T=10, LSUN-256 T=4) and the EDM train step;
   train_steps_per_sec  second leg: full DxMI train step (sample T + update_f_v + update_sampler) at the same batch;
   reference_eager_gpu  the reference's op sequence (the oracle's eager restatement: NCHW, unfused torch ops on
                      MIOpen / rocBLAS) on the same GPU, fp32 and bf16-autocast — the ">= 3x" comparison, measured here;
@@ -115,6 +117,9 @@ def pmc_traffic(kname):
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
             k = json.load(f)["kernels"].get(kname)
+        if k is None:       # kernels of the train leg only (weight gradient, GroupNorm backward): the train leg's passes
+            with open(os.path.join(ROOT, PMC_FILE.replace("pmc_traffic", "pmc_train_traffic"))) as f:
+                k = json.load(f)["kernels"].get(kname)
         return (k["hbm_bytes_per_launch"] if k else None), PMC_FILE
     except (OSError, ValueError, KeyError):
         return None, PMC_FILE + " (missing)"
@@ -366,8 +371,17 @@ def class_rooflines(summ, step_seconds):
         if cls in ("conv1x1", "attention", "conv_other"):      # both rooflines shown
             e["frac_hbm"] = round(c["bytes"] / sec / 1e9 / HBM_PEAK_GBPS, 4)
             e["frac_mfma"] = round(c["flops"] / sec / 1e12 / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)
+        # HBM-side bytes per launch of the class's main kernel from the committed PMC passes (null when the profile lacks it)
+        main_kernel = CLASS_MAIN_KERNEL.get(cls)
+        if main_kernel:
+            e["traffic"] = {"kernel": main_kernel, "hbm_bytes_per_launch": pmc_traffic(main_kernel)[0]}
         out[cls] = e
     return out
+
+
+# the kernel that carries most of a non-conv class's bytes (conv classes: see `conv_kernels`)
+CLASS_MAIN_KERNEL = {"groupnorm": "gn_apply_kernel<4>", "attention": "attention256_kernel<true>", "wgrad": "conv_wgrad_ws_kernel<3>",
+                     "groupnorm_bwd": "gn_silu_bwd_kernel<4, 16>", "conv_stem": "conv_stem_kernel", "conv_other": "conv_head_kernel"}
 
 
 # ----------------------------------------------------------------------------------------------- main (one rank)
