@@ -705,17 +705,40 @@ __global__ __launch_bounds__(512) void gn_silu_bwd_kernel(GnBwdArgs p) {
     const float m1 = group_reduce(s1) * inv_cnt;
     const float m2 = group_reduce(s2) * inv_cnt;
 
-    // channel sums across the threads that share this channel piece (fixed order)
+    // channel sums across the threads that share a channel piece, in a fixed order.  chan is a [rows][cols] matrix (rows = nthr / ppp
+    // thread rows, cols = ppp x 2 VEC values): row segments are added in parallel, then the segment sums in order (the first version
+    // let ppp threads walk all rows x 2 VEC values alone: 512 dependent LDS reads, ~20 us of a workgroup's life)
+    constexpr int J = 2 * VEC;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { chan[tid * 2 * VEC + e] = dgs[e]; chan[tid * 2 * VEC + VEC + e] = dbs[e]; }
+    for (int e = 0; e < VEC; ++e) { chan[tid * J + e] = dgs[e]; chan[tid * J + VEC + e] = dbs[e]; }
     __syncthreads();
-    if (tid < p.ppp) {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            float tg = 0.f, tb = 0.f;
-            for (int k = tid; k < nthr; k += p.ppp) { tg += chan[k * 2 * VEC + e]; tb += chan[k * 2 * VEC + VEC + e]; }
-            p.dgamma_part[(size_t)n * C + c + e] = tg;
-            p.dbeta_part[(size_t)n * C + c + e] = tb;
+    {
+        const int cols = p.ppp * J, rows = nthr / p.ppp;
+        int nseg = nthr / cols;
+        if (nseg < 1) nseg = 1;
+        if (nseg > rows) nseg = rows;
+        float* const seg_part = chan + nthr * J;            // [nseg][cols], nseg * cols <= nthr (only used when nseg > 1)
+        if (nseg > 1) {
+            for (int i = tid; i < nseg * cols; i += nthr) {
+                const int sg = i / cols, cc = i - sg * cols;
+                const int r0 = rows * sg / nseg, r1 = rows * (sg + 1) / nseg;
+                float t = 0.f;
+                for (int r = r0; r < r1; ++r) t += chan[r * cols + cc];
+                seg_part[i] = t;
+            }
+            __syncthreads();
+        }
+        for (int cc = tid; cc < cols; cc += nthr) {
+            float t = 0.f;
+            if (nseg > 1) {
+                for (int sg = 0; sg < nseg; ++sg) t += seg_part[sg * cols + cc];
+            } else {
+                for (int r = 0; r < rows; ++r) t += chan[r * cols + cc];       // fewer rows than values per row: one short pass
+            }
+            const int pcc = cc / J, j = cc - pcc * J;
+            const size_t o = (size_t)n * C + s * Csl + pcc * VEC + (j < VEC ? j : j - VEC);
+            if (j < VEC) p.dgamma_part[o] = t;
+            else p.dbeta_part[o] = t;
         }
     }
 
@@ -769,7 +792,7 @@ int launch_gn(const GnArgs& a, int N, int pieces, int threads, hipStream_t st) {
 template <int VEC>
 int launch_gn_bwd(const GnBwdArgs& a, int N, int pieces, int threads, hipStream_t st) {
     dim3 grid(N * a.slices), block(threads);
-    const size_t dyn = (size_t)threads * 2 * VEC * sizeof(float);
+    const size_t dyn = (size_t)threads * (2 * VEC + 1) * sizeof(float);      // channel partials [threads][2 VEC] + segment sums (<= threads)
 #define GNB_CASE(P)                                                                     \
     if (pieces <= P) {                                                                  \
         hipLaunchKernelGGL((gn_silu_bwd_kernel<VEC, P>), grid, block, dyn, st, a);      \
