@@ -580,7 +580,7 @@ struct GnBwdArgs {
 };
 
 template <int VEC, int PIECES>
-__global__ __launch_bounds__(512) void gn_silu_bwd_kernel(GnBwdArgs p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((VEC * PIECES <= 64 ? 4 : 1), 8))) void gn_silu_bwd_kernel(GnBwdArgs p) {
     typedef typename PieceT<VEC>::type piece_t;
     constexpr int W = VEC / 2;
     __shared__ float red[512 / 64][32];
