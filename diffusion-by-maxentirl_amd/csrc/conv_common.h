@@ -28,6 +28,7 @@ struct ConvArgs {
     const float* gn_beta;
     float gn_eps;
     int gn_flags;            // bit 0: SiLU, bit 1: skip the raw output
+    int res_is_mask;         // conv_ws_kernel: `residual` carries the activation-mask source (out *= mask > 0 ? 1 : mask_slope), set by its launcher
 };
 
 // Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15): every lane of the row ends with the row's total.  Each step adds

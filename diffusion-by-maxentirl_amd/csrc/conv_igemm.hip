@@ -474,6 +474,7 @@ static int conv2d_impl(const dxmi_conv_desc* d, void* stream, int* kernel_id) {
     a.bias = d->bias; a.addvec = d->addvec; a.residual = (const bf16*)d->residual; a.out = d->out;
     a.mask_src = (const bf16*)d->mask_src; a.mask_slope = d->mask_slope; a.gn_stats = d->gn_stats;
     a.gn_out = (bf16*)d->gn_out; a.gn_gamma = d->gn_gamma; a.gn_beta = d->gn_beta; a.gn_eps = d->gn_eps; a.gn_flags = d->gn_flags;
+    a.res_is_mask = 0;
     DXMI_CHECK_ARG(!d->gn_out || (d->gn_gamma && d->gn_beta && d->gn_groups > 0 && d->Cout == 8 * d->gn_groups && d->variant == 0 &&
                                   d->out_mode == DXMI_OUT_NHWC_BF16),
                    "dxmi_conv2d_fwd: gn_out needs gamma / beta, 8 channels per group, the default variant and NHWC bf16 output");
@@ -619,7 +620,7 @@ extern "C" int dxmi_linear_fwd(const float* x, const void* wpacked, const float*
     ConvArgs a;
     a.in0 = (const bf16*)x; a.in1 = nullptr; a.w = (const bf16*)wpacked; a.bias = bias; a.addvec = nullptr;
     a.residual = nullptr; a.out = out; a.mask_src = nullptr; a.mask_slope = 0.f; a.gn_stats = nullptr; a.gn_out = nullptr;
-    a.gn_gamma = a.gn_beta = nullptr; a.gn_eps = 0.f; a.gn_flags = 0;
+    a.gn_gamma = a.gn_beta = nullptr; a.gn_eps = 0.f; a.gn_flags = 0; a.res_is_mask = 0;
     a.N = 1; a.IH = 1; a.IW = P; a.C0 = K; a.C1 = 0; a.OH = 1; a.OW = P; a.Cout = M;
     a.ksize = 1; a.stride = 1; a.pad = 0; a.ups = 0; a.act = post_act; a.addvec_ld = 0;
     a.in_mode = DXMI_IN_ROWS_F32; a.out_mode = DXMI_OUT_ROWS_F32; a.P = P; a.pre_act = pre_act;

@@ -279,8 +279,13 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = acc[cb][nb][e] + bv[e];
                         if (has_res) {
+                            if (p.res_is_mask) {          // data gradient through a LeakyReLU: the tile the movers fetched is the mask source
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += (float)r[nb][e];
+                                for (int e = 0; e < 4; ++e) v[e] *= ((float)r[nb][e] > 0.f ? 1.f : p.mask_slope);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)r[nb][e];
+                            }
                         }
                         if (!plain) {
 #pragma unroll
@@ -623,7 +628,9 @@ int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     static const int enabled = getenv("DXMI_CONV_WS") ? atoi(getenv("DXMI_CONV_WS")) : 1;   // DXMI_CONV_WS=0: conv_pipe_kernel for every shape
     if (!enabled) return 1;
     if (a.in_mode != DXMI_IN_NHWC_BF16 || a.out_mode != DXMI_OUT_NHWC_BF16) return 1;
-    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups == 2 || a.mask_src || a.act == DXMI_ACT_SILU) return 1;
+    // an activation mask (data gradient of the value net's convs: out *= mask_src > 0 ? 1 : slope) rides the residual tile's path
+    // when there is no residual; both at once stay on conv_pipe_kernel
+    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups == 2 || (a.mask_src && a.residual) || a.act == DXMI_ACT_SILU) return 1;
     if (a.Cout % 64 != 0 || (a.C0 + a.C1) % 32 != 0 || a.C0 % 32 != 0) return 1;   // Cout % 128 == 64: the last cout tile is half empty
     const int TW = a.OW >= 32 ? 32 : a.OW;
     if (TW != 32 && TW != 16) return 1;
@@ -648,7 +655,11 @@ int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
         zero_page = zp;
     }
     ConvArgs b = a;
-    b.mask_src = reinterpret_cast<const bf16*>(zero_page);    // the kernel has no activation mask: the field carries the zero page
+    if (a.mask_src) {
+        b.residual = a.mask_src;
+        b.res_is_mask = 1;
+    }
+    b.mask_src = reinterpret_cast<const bf16*>(zero_page);    // the field carries the zero page (a mask source travels in `residual`)
     b.SUBS = 1;
     b.PT = a.N * (a.OH / TH) * (a.OW / TW);
     b.CT = (a.Cout + 127) / 128;

@@ -462,3 +462,34 @@ def test_colsum_f32(ops):
         assert torch.equal(got, ops.colsum_f32(x))
     x2 = torch.randn(33, 64, generator=g).to(DEV)
     assert (ops.colsum_f32(x2).double() - x2.double().sum(0)).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("N,C,Cout,H", [(5, 128, 128, 32), (3, 256, 128, 16), (260, 128, 128, 16)])
+def test_conv_ws_activation_mask(ops, N, C, Cout, H):
+    """Data gradient through a LeakyReLU on conv_ws_kernel: the mask source rides the residual tile's path
+    (out = conv(x) * (mask > 0 ? 1 : slope); value net backward, models/modules.py:96-101)."""
+    g = torch.Generator().manual_seed(41 + N)
+    x = torch.randn(N, H, H, C, generator=g).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) * 0.03).to(DEV)
+    pw = ops.pack_conv_weight(w)
+    m = torch.randn(N, H, H, Cout, generator=g).to(torch.bfloat16).to(DEV)
+    prof = ops.OpProfiler()
+    ops.PROFILER = prof
+    try:
+        y = ops.conv2d(x, pw, mask_src=m, mask_slope=0.2)
+    finally:
+        ops.PROFILER = None
+    torch.cuda.synchronize()
+    assert [k[1] for k in prof.summary()] == [400000 + (32 if H == 32 else 16)]
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), padding=1)
+    ref = (ref * torch.where(m.float().permute(0, 3, 1, 2) > 0, 1.0, 0.2)).permute(0, 2, 3, 1)
+    assert ((y.float() - ref).norm() / ref.norm()).item() < 4e-3
+    assert torch.equal(y, ops.conv2d(x, pw, mask_src=m, mask_slope=0.2))
+    i = N - 1
+    assert torch.equal(ops.conv2d(x[i:i + 1].contiguous(), pw, mask_src=m[i:i + 1].contiguous(), mask_slope=0.2)[0], y[i])
+    # mask AND residual together stay on the pipelined kernel
+    r = torch.randn(N, H, H, Cout, generator=g).to(torch.bfloat16).to(DEV)
+    y2 = ops.conv2d(x, pw, mask_src=m, mask_slope=0.2, residual=r)
+    ref2 = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), padding=1) + r.float().permute(0, 3, 1, 2)
+    ref2 = (ref2 * torch.where(m.float().permute(0, 3, 1, 2) > 0, 1.0, 0.2)).permute(0, 2, 3, 1)
+    assert ((y2.float() - ref2).norm() / ref2.norm()).item() < 4e-3
