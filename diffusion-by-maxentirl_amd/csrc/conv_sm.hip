@@ -292,8 +292,13 @@ __global__ __launch_bounds__(256 + 64 * NL) void conv_sm_kernel(ConvArgs p) {
                     for (int e = 0; e < 4; ++e) v[e] = acc[cb][4 * g + e] + (bv[e] + tv[e]);
                     if (has_res) {
                         const bf16x4 rv = *reinterpret_cast<const bf16x4*>(resb + px * (MT * 2) + co * 2);
+                        if (p.res_is_mask) {              // data gradient through a LeakyReLU: the fetched tile is the mask source
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                            for (int e = 0; e < 4; ++e) v[e] *= ((float)rv[e] > 0.f ? 1.f : p.mask_slope);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                        }
                     }
                     if (!plain) {
 #pragma unroll
@@ -349,7 +354,7 @@ int conv_sm_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     static const int enabled = getenv("DXMI_CONV_SM") ? atoi(getenv("DXMI_CONV_SM")) : 1;
     if (!((a.OW == 4 && (enabled & 1)) || (a.OW == 8 && (enabled & 2)))) return 1;
     if (a.in_mode != DXMI_IN_NHWC_BF16 || a.out_mode != DXMI_OUT_NHWC_BF16) return 1;
-    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups != 0 || a.mask_src || a.act == DXMI_ACT_SILU || a.gn_stats) return 1;
+    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups != 0 || (a.mask_src && a.residual) || a.act == DXMI_ACT_SILU || a.gn_stats) return 1;   // a mask alone rides the residual path
     if (a.OH != a.OW || (a.OW != 4 && a.OW != 8) || a.IH != a.OH || a.IW != a.OW) return 1;
     // tile width: 64 couts where that still gives every CU a tile (8x8 maps at batch 256), else 32
     const int imgs = 128 / (a.OH * a.OW);
@@ -374,7 +379,11 @@ int conv_sm_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
         zero_page = zp;
     }
     ConvArgs b = a;
-    b.mask_src = reinterpret_cast<const bf16*>(zero_page);    // the kernel has no activation mask: the field carries the zero page
+    if (a.mask_src) {
+        b.residual = a.mask_src;
+        b.res_is_mask = 1;
+    }
+    b.mask_src = reinterpret_cast<const bf16*>(zero_page);    // the field carries the zero page (a mask source travels in `residual`)
     b.PT = PT;
     b.CT = a.Cout / MT;
     b.tile_px = 128;

@@ -187,8 +187,13 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = acc[cb][nb][e] + bv[e];
                         if (has_res) {
+                            if (p.res_is_mask) {          // data gradient through a LeakyReLU: the fetched tile is the mask source
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += (float)r[nb][e];
+                                for (int e = 0; e < 4; ++e) v[e] *= ((float)r[nb][e] > 0.f ? 1.f : p.mask_slope);
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)r[nb][e];
+                            }
                         }
                         if (!plain) {
 #pragma unroll
@@ -473,7 +478,7 @@ int conv_ws8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     static const int enabled = getenv("DXMI_CONV_WS8") ? atoi(getenv("DXMI_CONV_WS8")) : 1;   // 0: conv_pipe_kernel for the 8x8 maps
     if (!enabled) return 1;
     if (a.in_mode != DXMI_IN_NHWC_BF16 || a.out_mode != DXMI_OUT_NHWC_BF16) return 1;
-    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups == 2 || a.mask_src || a.act == DXMI_ACT_SILU) return 1;
+    if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups == 2 || (a.mask_src && a.residual) || a.act == DXMI_ACT_SILU) return 1;   // a mask alone rides the residual path
     if (a.OH != 8 || a.OW != 8) return 1;
     if (a.ups ? (a.IH != 4 || a.IW != 4) : (a.IH != 8 || a.IW != 8)) return 1;     // ups: nearest x2 upsample of a 4x4 map in front
     if (a.Cout % 64 != 0 || (a.C0 + a.C1) % 32 != 0 || a.C0 % 32 != 0) return 1;
@@ -496,7 +501,11 @@ int conv_ws8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
         zero_page = zp;
     }
     ConvArgs b = a;
-    b.mask_src = reinterpret_cast<const bf16*>(zero_page);    // the kernel has no activation mask: the field carries the zero page
+    if (a.mask_src) {
+        b.residual = a.mask_src;
+        b.res_is_mask = 1;
+    }
+    b.mask_src = reinterpret_cast<const bf16*>(zero_page);    // the field carries the zero page (a mask source travels in `residual`)
     b.SUBS = 4;
     b.PT = (a.N + 3) / 4;      // the last tile may hold fewer than four images (masked)
     b.CT = a.Cout / 64;
