@@ -443,21 +443,40 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs p) {
     const int tx = pt % txn, ty = (pt / txn) % tyn;
     const int n0 = (pt / (txn * tyn)) * p.SUBS, oy0 = ty << p.THl, ox0 = tx << p.TWl;
     {
-        // thread = (pixel, half of the 32 k-values); k = ci*9 + ky*3 + kx
+        // the tile's 3-channel halo ((TH + 2) x (TW + 2) pixels per sub-image, <= 3.4 KB) is fetched ONCE with row-coalesced loads
+        // (<= 4 per thread, all in flight) into LDS behind the epilogue slab; the im2col rows are gathered from there.  (Sixteen
+        // bounds-checked 4-byte global loads per thread cost 12 of the launch's 36 us: stem ablation, tools/stem_time.py.)
+        float* const himg = reinterpret_cast<float*>(smem + 128 * ROWB + EPI_BYTES);
         const float* xin = reinterpret_cast<const float*>(p.in0);
+        const int HWd = TW + 2, HHt = TH + 2, HPs = HHt * HWd;
+        const int total = p.SUBS * 3 * HPs;
+        float hv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {           // total <= 1024
+            const int i = tid + u * 256;
+            const int sub = i / (3 * HPs), r = i - sub * 3 * HPs;
+            const int ci = r / HPs, r2 = r - ci * HPs;
+            const int hy = r2 / HWd, hx = r2 - hy * HWd;
+            const int n = n0 + sub, iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+            hv[u] = 0.f;
+            if (i < total && n < p.N && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) hv[u] = xin[((n * 3 + ci) * p.IH + iy) * p.IW + ix];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (tid + u * 256 < total) himg[tid + u * 256] = hv[u];
+        lds_barrier();
+        // thread = (pixel, half of the 32 k-values); k = ci*9 + ky*3 + kx
         const int pix = tid & 127, half = tid >> 7;
         const int x = pix & (TW - 1);
         const int y = (pix >> p.TWl) & (TH - 1);
-        const int n = n0 + (pix >> (p.TWl + p.THl));
-        const int oy = oy0 + y, ox = ox0 + x;
+        const int sub = pix >> (p.TWl + p.THl);
+        const float* const hb = himg + sub * 3 * HPs + y * HWd + x;
         bf16x8 v[2];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int k = half * 16 + j;
             const int ci = k / 9, r = k - ci * 9, ky = r / 3, kx = r - ky * 3;
-            const int iy = oy + ky - 1, ix = ox + kx - 1;
-            float f = 0.f;
-            if (k < 27 && n < p.N && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) f = xin[((n * 3 + ci) * p.IH + iy) * p.IW + ix];
+            const float f = k < 27 ? hb[(ci * HHt + ky) * HWd + kx] : 0.f;
             v[j >> 3][j & 7] = (bf16)f;
         }
         *reinterpret_cast<bf16x8*>(smem + pix * ROWB + half * 32) = v[0];
@@ -636,7 +655,7 @@ int conv_stem_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     b.PT = ngroups * (a.OH / TH) * (a.OW / TW);
     b.CT = (a.Cout + 127) / 128;
     b.tile_px = tile;
-    hipLaunchKernelGGL(conv_stem_kernel, dim3(b.PT * b.CT), dim3(256), (size_t)128 * 80 + EPI_BYTES, st, b);
+    hipLaunchKernelGGL(conv_stem_kernel, dim3(b.PT * b.CT), dim3(256), (size_t)128 * 80 + EPI_BYTES + 4096, st, b);     // + the 3-channel halo image
     DXMI_CHECK_LAUNCH("dxmi_conv2d_fwd(stem)");
     return DXMI_OK;
 }
