@@ -175,6 +175,74 @@ __device__ __forceinline__ void conv_epilogue_lds(const ConvArgs& p, f32x16 (&ac
     }
 }
 
+// Lean epilogue: bias + linear activation only (no residual / per-image vector / activation mask / SiLU — conv_lean_ok()).
+// conv_epilogue_lds carries every feature of the conv family as run-time branches (~3 000 VALU instructions: with loads AND stores
+// ablated the 8-MFMA stem launch still took 28 of its 33 us, and a 64-pixel stride-2 tile spends a third of its time there).  Here:
+// bias + activation in the accumulator layout, ONE rounding, bf16 into a [NB * 32 px][128 co] LDS tile (16-byte slot c8 of pixel
+// row R at c8 ^ (R & 15)), then every thread moves 16-byte pieces of whole 256-byte NHWC rows; optional GroupNorm block statistics
+// as in conv_epilogue_lds (one image per tile, full cout tiles: host-checked).  Same values as conv_epilogue_lds.
+__device__ __forceinline__ bool conv_lean_ok(const ConvArgs& p) {
+    return !p.residual && !p.addvec && !p.mask_src && p.act != DXMI_ACT_SILU;
+}
+
+template <int NB>
+__device__ __forceinline__ void conv_epilogue_lean(const ConvArgs& p, f32x16 (&acc)[1][NB], char* tile, int n0, int oy0, int ox0,
+                                                   int cot, int wave, int lane, int tid) {
+    const int TW = 1 << p.TWl, TH = 1 << p.THl;
+    const int h = lane >> 5, pxl = lane & 31;
+    const float slope = dxmi_act_slope(p.act);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && cot * 128 + wave * 32 + 8 * g < p.Cout) bv = *reinterpret_cast<const f32x4*>(p.bias + cot * 128 + wave * 32 + 8 * g + 4 * h);
+        const int c8 = wave * 4 + g;                               // 16-byte slot of couts wave * 32 + 8 g .. + 7; this lane's half: + 8 h bytes
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int R = nb * 32 + pxl;
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)dxmi_act_lin(acc[0][nb][4 * g + e] + bv[e], slope);
+            *reinterpret_cast<bf16x4*>(tile + R * 256 + ((c8 ^ (R & 15)) << 4) + 8 * h) = o;
+        }
+    }
+    lds_barrier();
+    const int pc = tid & 15, pr = tid >> 4;
+    const bool pc_ok = cot * 128 + pc * 8 < p.Cout;
+    float gst[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int k = 0; k < 2 * NB; ++k) {
+        const int R = pr + 16 * k;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + R * 256 + ((pc ^ (R & 15)) << 4));
+        const int x = R & (TW - 1), y = (R >> p.TWl) & (TH - 1), n = n0 + (R >> (p.TWl + p.THl));
+        if (n < p.N && pc_ok) {
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + (((size_t)n * p.OH + oy0 + y) * p.OW + ox0 + x) * p.Cout + cot * 128 + pc * 8) = v;
+            if (p.gn_stats) {
+                const bf16x4 lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
+                dxmi_stats4(lo4, gst[0]);
+                dxmi_stats4(hi4, gst[1]);
+            }
+        }
+    }
+    if (p.gn_stats) {
+        // the 16 pixel lanes of a piece added in lane order: one partial per tile
+        lds_barrier();
+        float* const sl = reinterpret_cast<float*>(tile) + (pr * 16 + pc) * 8;
+        *reinterpret_cast<f32x4*>(sl) = f32x4{gst[0][0], gst[0][1], gst[0][2], gst[0][3]};
+        *reinterpret_cast<f32x4*>(sl + 4) = f32x4{gst[1][0], gst[1][1], gst[1][2], gst[1][3]};
+        lds_barrier();
+        if (tid < 128) {
+            const int j = tid & 7, c8s = tid >> 3;
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += reinterpret_cast<const float*>(tile)[(r * 16 + c8s) * 8 + j];
+            const int part = (oy0 >> p.THl) * (p.OW >> p.TWl) + (ox0 >> p.TWl);
+            const int P = (p.OH >> p.THl) * (p.OW >> p.TWl);
+            p.gn_stats[(((size_t)n0 * P + part) * (p.Cout >> 1) + cot * 64) * 2 + tid] = t;
+        }
+    }
+    lds_barrier();          // persistent callers reuse the tile / the buffers behind it
+}
+
 // AQ: how many steps ahead the weight fragments are requested (queue of AQ+1 fragment pairs).  Small-map layers are
 // bound by the L2 latency of those requests (4 MFMAs per step at NB=2), so they run a deeper queue.
 // SD: chunks of staging distance (1: the next chunk is requested at this chunk's first tap; 2: the chunk after next,
@@ -406,7 +474,11 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void conv_pipe_kernel(ConvA
         {
             int n0, oy0, ox0;
             tile_origin(pt, n0, oy0, ox0);
-            if (!(DBG & 32)) conv_epilogue_lds<NB>(p, acc, smem + 2 * BUF, n0, oy0, ox0, cot, wave, lane, tid);
+            if (!(DBG & 32)) {
+                // (the lean tile is NB * 8 KB: it fits the 33 KB epilogue area up to 128-pixel tiles)
+                if (NB <= 4 && conv_lean_ok(p)) conv_epilogue_lean<(NB <= 4 ? NB : 4)>(p, reinterpret_cast<f32x16(&)[1][(NB <= 4 ? NB : 4)]>(acc), smem + 2 * BUF, n0, oy0, ox0, cot, wave, lane, tid);
+                else conv_epilogue_lds<NB>(p, acc, smem + 2 * BUF, n0, oy0, ox0, cot, wave, lane, tid);
+            }
             else {
                 // timing-only ablation: keep EVERY accumulator live (a use of one element lets hipcc delete the MFMAs that
                 // feed the others: the "K loop alone" numbers of round 1 were taken that way and read 2x too fast)
@@ -504,69 +576,11 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs p) {
             const bf16x8 b = *reinterpret_cast<const bf16x8*>(smem + (nb * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16 + ks * 32);
             acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[ks], b, acc[0][nb], 0, 0, 0);
         }
-    if (p.residual || p.addvec || p.mask_src || p.act == DXMI_ACT_SILU) {       // not what the stems of the nets ask for: generic epilogue
+    if (!conv_lean_ok(p)) {       // not what the stems of the nets ask for: generic epilogue
         conv_epilogue_lds<NB>(p, acc, smem + 128 * ROWB, n0, oy0, ox0, cot, wave, lane, tid);
         return;
     }
-    // Lean epilogue (bias + linear activation only).  conv_epilogue_lds carries every feature of the conv family as run-time
-    // branches (~3 000 VALU instructions for a kernel of 8 MFMAs: with loads AND stores ablated the launch still took 28 of its
-    // 33 us).  Here: bias + activation in the accumulator layout, ONE rounding, bf16 into a [128 px][128 co] LDS tile (16-byte slot
-    // c8 of pixel row R at c8 ^ (R & 15)), then every thread moves eight 16-byte pieces of whole 256-byte NHWC rows.
-    {
-        char* const tile = smem + 128 * ROWB;
-        const int h = lane >> 5, pxl = lane & 31;
-        const float slope = dxmi_act_slope(p.act);
-        const bool wave_ok = cot * 128 + wave * 32 < p.Cout;          // Cout % 64 == 0: a wave's 32 couts are all in or all out
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias && wave_ok) bv = *reinterpret_cast<const f32x4*>(p.bias + cot * 128 + wave * 32 + 8 * g + 4 * h);
-            const int c8 = wave * 4 + g;                               // 16-byte slot of couts wave * 32 + 8 g .. + 7; this lane's half: + 8 h bytes
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                const int R = nb * 32 + pxl;
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16)dxmi_act_lin(acc[0][nb][4 * g + e] + bv[e], slope);
-                *reinterpret_cast<bf16x4*>(tile + R * 256 + ((c8 ^ (R & 15)) << 4) + 8 * h) = o;
-            }
-        }
-        lds_barrier();
-        const int pc = tid & 15, pr = tid >> 4;
-        const bool pc_ok = cot * 128 + pc * 8 < p.Cout;
-        float gst[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int R = pr + 16 * k;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(tile + R * 256 + ((pc ^ (R & 15)) << 4));
-            const int x = R & (TW - 1), y = (R >> p.TWl) & (TH - 1), n = n0 + (R >> (p.TWl + p.THl));
-            if (n < p.N && pc_ok) {
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.out) + (((size_t)n * p.OH + oy0 + y) * p.OW + ox0 + x) * p.Cout + cot * 128 + pc * 8) = v;
-                if (p.gn_stats) {
-                    const bf16x4 lo4 = {v[0], v[1], v[2], v[3]}, hi4 = {v[4], v[5], v[6], v[7]};
-                    dxmi_stats4(lo4, gst[0]);
-                    dxmi_stats4(hi4, gst[1]);
-                }
-            }
-        }
-        if (p.gn_stats) {
-            // (host: one image per tile, full cout tiles) the 16 pixel lanes of a piece added in lane order: one partial per tile
-            lds_barrier();
-            float* const sl = reinterpret_cast<float*>(tile) + (pr * 16 + pc) * 8;
-            *reinterpret_cast<f32x4*>(sl) = f32x4{gst[0][0], gst[0][1], gst[0][2], gst[0][3]};
-            *reinterpret_cast<f32x4*>(sl + 4) = f32x4{gst[1][0], gst[1][1], gst[1][2], gst[1][3]};
-            lds_barrier();
-            if (tid < 128) {
-                const int j = tid & 7, c8s = tid >> 3;
-                float t = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t += reinterpret_cast<const float*>(tile)[(r * 16 + c8s) * 8 + j];
-                const int part = (oy0 >> p.THl) * (p.OW >> p.TWl) + (ox0 >> p.TWl);
-                const int P = (p.OH >> p.THl) * (p.OW >> p.TWl);
-                p.gn_stats[(((size_t)n0 * P + part) * (p.Cout >> 1) + cot * 64) * 2 + tid] = t;
-            }
-        }
-    }
+    conv_epilogue_lean<NB>(p, acc, smem + 128 * ROWB, n0, oy0, ox0, cot, wave, lane, tid);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -683,7 +697,8 @@ __global__ __launch_bounds__(256, OCC) void conv1x1_stream_kernel(ConvArgs p) {
         if (left > RC) request_w(c0 + RC);
     }
     lds_barrier();                        // images are dead: the epilogue slab reuses them
-    conv_epilogue_lds<NB>(p, acc, smem, n0, oy0, ox0, cot, wave, lane, tid);
+    if (conv_lean_ok(p)) conv_epilogue_lean<NB>(p, acc, smem, n0, oy0, ox0, cot, wave, lane, tid);
+    else conv_epilogue_lds<NB>(p, acc, smem, n0, oy0, ox0, cot, wave, lane, tid);
 }
 
 template <int NB, int RC, int OCC>
