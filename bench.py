@@ -57,7 +57,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-eager-reference", action="store_true")
     ap.add_argument("--no-events", action="store_true", help="skip the per-launch HIP events (roofline legs)")
-    ap.add_argument("--train-steps", type=int, default=5, help="timed DxMI train steps (0 = skip the train leg)")
+    ap.add_argument("--train-steps", type=int, default=8, help="timed DxMI train steps (0 = skip the train leg)")
     ap.add_argument("--no-edm", action="store_true", help="skip the EDM legs (BASELINE configs[3], configs[4] at their per-GPU sizes)")
     return ap.parse_args()
 
@@ -462,7 +462,8 @@ def main():
         ring = TransitionRing(1, T, B, (3, 32, 32), device)
         gimg = torch.Generator(device=device).manual_seed(112233 + rank)
         imgs = torch.rand(B, 3, 32, 32, device=device, generator=gimg) * 2 - 1
-        train_step(tr, sampler, imgs, device, ring)          # warm-up (weight packing, workspaces, optimiser state)
+        for _ in range(2):                                   # warm-up (weight packing, workspaces, optimiser state, allocator growth)
+            train_step(tr, sampler, imgs, device, ring)
         sync_all()
         t1 = time.perf_counter()
         for _ in range(args.train_steps):
