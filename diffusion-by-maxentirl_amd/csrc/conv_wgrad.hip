@@ -367,6 +367,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_ws_kernel(WgradArgs p, const c
                 const int xl = plo & (TW - 1), yl = (plo >> p.TWl) & (TH - 1), sl = plo >> (p.TWl + p.THl);
                 hr0 = (sl * p.HH + yl) * p.HWd + xl;                     // halo row of tap (0, 0); tile rows >= 8 pixels: plo + 4 is hr0 + 4
             }
+#ifdef WG_DBG_SKIPB
+            if (t % 3 != 0) { bwin[i % WIN] = bwin[(i + WIN - 1) % WIN]; return; }      // timing-only ablation: one B read per kernel row
+#endif
             const char* bl = xim + saddr(hr0 + trow[t], wc * 64 + ch_off);
             bwin[i % WIN] = tr_frag(bl, bl + 512);
         };
