@@ -56,15 +56,20 @@ CONFIGS["imagenet64_T10"] = {
 }
 CONFIGS["imagenet64_T4"] = copy.deepcopy(CONFIGS["imagenet64_T10"])
 CONFIGS["imagenet64_T4"]["sampler"].update({"n_timesteps": 4, "stochastic_last": True, "rho": 4.0})
-CONFIGS["imagenet64_T4"]["trainer"].update({"n_timesteps": 4, "skip_sampler_tau": 0, "skip_running_last": 1})
+CONFIGS["imagenet64_T4"]["trainer"].update({"n_timesteps": 4, "skip_running_last": 1})
+del CONFIGS["imagenet64_T4"]["trainer"]["skip_sampler_tau"]        # configs/imagenet64/T4.yaml has no such key (default 0)
+CONFIGS["imagenet64_T4"]["training"]["n_iter"] = 100000
 CONFIGS["lsun_bedroom_T4"] = {
     # configs/lsun/T4.yaml:1-21: two res blocks per level, additive embedding (no scale-shift norm), unconditional
     "diffusion": dict(_EDM_COMMON, image_size=256, num_channels=256, class_cond=False, num_res_blocks=2,
                       use_scale_shift_norm=False),
-    "sampler": {"sample_shape": [3, 256, 256], "n_timesteps": 4, "class_cond": False, "num_classes": 1000,
+    "sampler": {"sample_shape": [3, 256, 256], "n_timesteps": 4, "class_cond": False, "num_classes": None,
                 "trainable_beta": "fix_last", "sigma_min": 0.002, "sigma_max": 80.0, "stochastic_last": True, "rho": 4.0},
-    "training": {"pretrained_path": "pretrained/lsun_bedroom_edm/edm_bedroom256_ema.pt", "batchsize": 16,
-                 "sampling_batchsize": 16, "seed": 42},
+    # the file's trainer / value name models.GCD classes that the reference snapshot does not hold (SURVEY 8c
+    # "parity unpinned" (2)): generation only; the training block is the file's, less its machine-local checkpoint path
+    "training": {"pretrained_path": "pretrained/lsun_bedroom_edm/edm_bedroom256_ema.pt", "value_ckpt": None, "n_iter": 100000,
+                 "batchsize": 64, "sampling_batchsize": 100, "n_fid_samples": 5000, "seed": 42, "lr": 1e-8, "v_lr": 1e-5,
+                 "beta_lr": 1e-6, "weight_decay": 0.0, "initial_log_loss_scale": 13, "log_every": 20, "fid_every": 100},
     "data": {"name": "lsun_bedroom"},
 }
 

@@ -1,10 +1,49 @@
 """Minimal stand-in for the OmegaConf + hydra.utils.instantiate pair the reference scripts use
 (train_cifar10.py:228-259, generate_cifar10.py:119-151): YAML load, recursive merge, attribute
 access, `_target_` instantiation.  Neither omegaconf nor hydra is installed in the target image,
-and the reference's YAML files must be accepted unchanged."""
+and the reference's YAML files must be accepted unchanged
+(tests/test_cli_config.py loads all ten of them when the reference checkout is present)."""
 import importlib
+import re
 
 import yaml
+
+
+class _Loader(yaml.SafeLoader):
+    """PyYAML's SafeLoader with OmegaConf's scalar rules (omegaconf/_utils.py get_yaml_loader, which
+    train_cifar10.py:228-233 goes through): floats by the YAML-1.2 pattern, so `1e-7` / `1e-5` (no dot, unsigned
+    exponent) are numbers and not the strings YAML 1.1 makes of them; no implicit timestamps; duplicate keys are
+    an error.  `Null`, `True`, `yes` ... resolve as in PyYAML (OmegaConf keeps those rules)."""
+
+
+_Loader.yaml_implicit_resolvers = {
+    k: [(tag, rx) for tag, rx in v if tag != "tag:yaml.org,2002:timestamp"]
+    for k, v in yaml.SafeLoader.yaml_implicit_resolvers.items()}
+_Loader.add_implicit_resolver(
+    "tag:yaml.org,2002:float",
+    re.compile(r"""^(?:
+         [-+]?(?:[0-9][0-9_]*)\.[0-9_]*(?:[eE][-+]?[0-9]+)?
+        |[-+]?(?:[0-9][0-9_]*)(?:[eE][-+]?[0-9]+)
+        |\.[0-9_]+(?:[eE][-+][0-9]+)?
+        |[-+]?[0-9][0-9_]*(?::[0-5]?[0-9])+\.[0-9_]*
+        |[-+]?\.(?:inf|Inf|INF)
+        |\.(?:nan|NaN|NAN))$""", re.X),
+    list("-+0123456789."))
+
+
+def _mapping_no_duplicates(loader, node, deep=False):
+    seen = set()
+    for key_node, _ in node.value:
+        key = loader.construct_object(key_node, deep=deep)
+        if key in seen:
+            raise yaml.constructor.ConstructorError(
+                "while constructing a mapping", node.start_mark, f"found duplicate key {key!r}", key_node.start_mark)
+        seen.add(key)
+    return yaml.SafeLoader.construct_mapping(loader, node, deep)
+
+
+_Loader.add_constructor(yaml.resolver.BaseResolver.DEFAULT_MAPPING_TAG,
+                        lambda loader, node: _mapping_no_duplicates(loader, node, deep=True))
 
 
 class Cfg(dict):
@@ -33,7 +72,7 @@ class Cfg(dict):
 
 def load(path):
     with open(path) as f:
-        return Cfg(yaml.safe_load(f) or {})
+        return Cfg(yaml.load(f, Loader=_Loader) or {})
 
 
 def merge(base, override):

@@ -64,6 +64,28 @@ def train_one_epoch(trainer, sampler, dataloader, n_critic, n_generator, device,
         state["i_iter"] += 1
 
 
+def load_config(config, dataset, overrides=None):
+    """--config / --dataset / `--a.b.c v` overrides -> merged Cfg (reference :228-233: OmegaConf.load x 2 + merge)."""
+    if config.startswith("builtin:"):
+        import configs_builtin
+        cfg = configs_builtin.get(config.split(":", 1)[1])
+    else:
+        cfg = dxmi_config.merge(dxmi_config.load(config), dxmi_config.load(dataset))
+    return dxmi_config.merge(cfg, overrides or {})
+
+
+def build_optimizers(cfg, net, sampler, v):
+    """Adam with the log_betas / rest learning-rate split, Adam for the value net (reference :283-296)."""
+    tune_beta = bool(sampler.trainable_beta) and cfg.training.get("beta_lr") is not None
+    if tune_beta:
+        not_beta = [p for n, p in net.named_parameters() if "log_betas" not in n]
+        optimizer = Adam([{"params": net.log_betas, "lr": cfg.training.beta_lr},
+                          {"params": not_beta, "lr": cfg.training.lr}])
+    else:
+        optimizer = Adam(net.parameters(), lr=cfg.training.lr)
+    return optimizer, Adam(v.parameters(), lr=cfg.training.v_lr)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=str, required=True)
@@ -75,12 +97,7 @@ def main():
     d_cmd_cfg = cmd.parse_nested_args(cmd.parse_unknown_args(unknown))
     print0("Overriding", d_cmd_cfg)
 
-    if args.config.startswith("builtin:"):
-        import configs_builtin
-        cfg = configs_builtin.get(args.config.split(":", 1)[1])
-    else:
-        cfg = dxmi_config.merge(dxmi_config.load(args.config), dxmi_config.load(args.dataset))
-    cfg = dxmi_config.merge(cfg, d_cmd_cfg)
+    cfg = load_config(args.config, args.dataset, d_cmd_cfg)
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,14 +125,7 @@ def main():
     broadcast_parameters(net)
     broadcast_parameters(v)
 
-    tune_beta = bool(sampler.trainable_beta) and cfg.training.get("beta_lr") is not None
-    if tune_beta:
-        not_beta = [p for n, p in net.named_parameters() if "log_betas" not in n]
-        optimizer = Adam([{"params": net.log_betas, "lr": cfg.training.beta_lr},
-                                      {"params": not_beta, "lr": cfg.training.lr}])
-    else:
-        optimizer = Adam(net.parameters(), lr=cfg.training.lr)
-    optimizer_v = Adam(v.parameters(), lr=cfg.training.v_lr)
+    optimizer, optimizer_v = build_optimizers(cfg, net, sampler, v)
 
     batchsize = cfg.training.batchsize // world     # the reference divides by the visible device count (:298-301)
     trainer = dxmi_config.instantiate(cfg.trainer, batchsize=batchsize)

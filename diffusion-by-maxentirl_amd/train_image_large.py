@@ -40,6 +40,35 @@ def synthetic_batches(batchsize, image_size, class_cond, n_class, device, seed):
         yield data, cond
 
 
+def load_config(config, dataset, overrides=None):
+    """--config / --dataset / `--a.b.c v` overrides -> merged Cfg (reference train_image_large.py:120-127)."""
+    if config.startswith("builtin:"):
+        import configs_builtin
+        cfg = configs_builtin.get(config.split(":", 1)[1])
+    else:
+        cfg = dxmi_config.merge(dxmi_config.load(config), dxmi_config.load(dataset))
+    return dxmi_config.merge(cfg, overrides or {})
+
+
+def build_optimizers(cfg, unet, v):
+    """MixedPrecisionTrainer + RAdam on its master tensors with the log_betas learning rate split, Adam for the value
+    net (reference train_image_large.py:152-168)."""
+    lls = cfg.training.get("initial_log_loss_scale", 20)
+    if cfg.training.get("beta_lr") is not None:
+        mp_trainer = MixedPrecisionTrainer(model=unet, use_fp16=cfg.diffusion.use_fp16, initial_lg_loss_scale=lls, special_key="log_betas")
+        if cfg.diffusion.use_fp16:
+            groups = [{"params": mp_trainer.master_params[1:], "lr": cfg.training.lr},
+                      {"params": mp_trainer.master_params[0:1], "lr": cfg.training.beta_lr}]
+        else:   # masters are the model parameters themselves: split by name
+            groups = [{"params": [p for n, p in unet.named_parameters() if "log_betas" not in n], "lr": cfg.training.lr},
+                      {"params": [unet.log_betas], "lr": cfg.training.beta_lr}]
+        opt = RAdam(groups, weight_decay=cfg.training.get("weight_decay", 0.0))
+    else:
+        mp_trainer = MixedPrecisionTrainer(model=unet, use_fp16=cfg.diffusion.use_fp16, initial_lg_loss_scale=lls)
+        opt = RAdam(mp_trainer.master_params, lr=cfg.training.lr, weight_decay=cfg.training.get("weight_decay", 0.0))
+    return mp_trainer, opt, Adam(v.parameters(), lr=cfg.training.v_lr)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=str, required=True)
@@ -54,12 +83,7 @@ def main():
     if local_rank == 0:
         print("Overriding", d_cmd_cfg)
 
-    if args.config.startswith("builtin:"):
-        import configs_builtin
-        cfg = configs_builtin.get(args.config.split(":", 1)[1])
-    else:
-        cfg = dxmi_config.merge(dxmi_config.load(args.config), dxmi_config.load(args.dataset))
-    cfg = dxmi_config.merge(cfg, d_cmd_cfg)
+    cfg = load_config(args.config, args.dataset, d_cmd_cfg)
 
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(device)
@@ -90,20 +114,7 @@ def main():
     broadcast_parameters(unet)
     broadcast_parameters(v)
 
-    lls = cfg.training.get("initial_log_loss_scale", 20)
-    if cfg.training.get("beta_lr") is not None:
-        mp_trainer = MixedPrecisionTrainer(model=unet, use_fp16=cfg.diffusion.use_fp16, initial_lg_loss_scale=lls, special_key="log_betas")
-        if cfg.diffusion.use_fp16:
-            groups = [{"params": mp_trainer.master_params[1:], "lr": cfg.training.lr},
-                      {"params": mp_trainer.master_params[0:1], "lr": cfg.training.beta_lr}]
-        else:   # masters are the model parameters themselves: split by name
-            groups = [{"params": [p for n, p in unet.named_parameters() if "log_betas" not in n], "lr": cfg.training.lr},
-                      {"params": [unet.log_betas], "lr": cfg.training.beta_lr}]
-        opt = RAdam(groups, weight_decay=cfg.training.get("weight_decay", 0.0))
-    else:
-        mp_trainer = MixedPrecisionTrainer(model=unet, use_fp16=cfg.diffusion.use_fp16, initial_lg_loss_scale=lls)
-        opt = RAdam(mp_trainer.master_params, lr=cfg.training.lr, weight_decay=cfg.training.get("weight_decay", 0.0))
-    opt_v = Adam(v.parameters(), lr=cfg.training.v_lr)
+    mp_trainer, opt, opt_v = build_optimizers(cfg, unet, v)
 
     batchsize = cfg.training.batchsize // world
     class_cond = bool(cfg.data.get("class_cond", cfg.sampler.get("class_cond", False)))
