@@ -352,6 +352,7 @@ int ilog2(int v) {
 }  // namespace
 
 extern "C" int64_t dxmi_packed_conv_weight_bytes(int32_t Cout, int32_t Cin, int32_t ksize, int32_t k27) {
+    if (Cout <= 0 || Cin <= 0 || (ksize != 1 && ksize != 3)) return 0;      // dxmi_pack_conv_weight rejects these
     const int64_t CB = (Cout + 31) / 32;
     if (k27) return CB * 2 * 64 * 8 * 2;
     const int64_t KST = (Cin + 15) / 16;
@@ -362,6 +363,7 @@ extern "C" int dxmi_pack_conv_weight(const float* w, void* dst, int32_t Cout, in
                                      int32_t transpose_flip, int32_t k27, void* stream) {
     DXMI_CHECK_ARG(w && dst, "dxmi_pack_conv_weight: null pointer");
     DXMI_CHECK_ARG(ksize == 1 || ksize == 3, "dxmi_pack_conv_weight: ksize must be 1 or 3");
+    DXMI_CHECK_ARG(Cout > 0 && Cin > 0, "dxmi_pack_conv_weight: Cout %d / Cin %d must be positive", Cout, Cin);
     DXMI_CHECK_ARG(!k27 || (Cin == 3 && ksize == 3 && !transpose_flip), "dxmi_pack_conv_weight: k27 needs Cin=3,k=3");
     const int CB = (Cout + 31) / 32;
     const int KST = k27 ? 2 : (Cin + 15) / 16;
@@ -383,7 +385,7 @@ extern "C" int dxmi_pack_conv_weights(const dxmi_pack_item* items, int32_t count
         long maxtotal = 0;
         for (int i = 0; i < n; ++i) {
             const dxmi_pack_item& d = items[base + i];
-            DXMI_CHECK_ARG(d.w && d.dst && (d.ksize == 1 || d.ksize == 3) && (!d.k27 || (d.Cin == 3 && d.ksize == 3 && !d.transpose_flip)),
+            DXMI_CHECK_ARG(d.w && d.dst && d.Cout > 0 && d.Cin > 0 && (d.ksize == 1 || d.ksize == 3) && (!d.k27 || (d.Cin == 3 && d.ksize == 3 && !d.transpose_flip)),
                            "dxmi_pack_conv_weights: bad item %d", base + i);
             P.it[i] = d;
             const long total = (long)(d.k27 ? 2 : (d.Cin + 15) / 16) * ((d.Cout + 31) / 32) * 64;       // fragment lanes (threads) of the item
@@ -450,7 +452,10 @@ static int conv2d_impl(const dxmi_conv_desc* d, void* stream, int* kernel_id) {
     const int Cin = d->C0 + d->C1;
     DXMI_CHECK_ARG(d->ksize == 1 || d->ksize == 3, "dxmi_conv2d_fwd: ksize %d unsupported", d->ksize);
     DXMI_CHECK_ARG(d->stride == 1 || d->stride == 2, "dxmi_conv2d_fwd: stride %d unsupported", d->stride);
-    DXMI_CHECK_ARG(d->N > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0, "dxmi_conv2d_fwd: empty shape");
+    DXMI_CHECK_ARG(d->N > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0 && d->IH > 0 && d->IW > 0 && d->C0 > 0 && d->C1 >= 0,
+                   "dxmi_conv2d_fwd: empty or negative shape (N %d, in %dx%dx(%d+%d), out %dx%dx%d)", d->N, d->IH, d->IW, d->C0, d->C1, d->OH, d->OW, d->Cout);
+    DXMI_CHECK_ARG(d->act >= DXMI_ACT_NONE && d->act <= DXMI_ACT_SILU, "dxmi_conv2d_fwd: act %d unknown", d->act);
+    DXMI_CHECK_ARG(!d->addvec || d->addvec_ld >= d->Cout, "dxmi_conv2d_fwd: addvec_ld %d < Cout %d", d->addvec_ld, d->Cout);
     DXMI_CHECK_ARG((d->OW & (d->OW - 1)) == 0 && (d->OH & (d->OH - 1)) == 0 && d->OW >= 4 && d->OH >= 4,
                    "dxmi_conv2d_fwd: OH/OW must be powers of two >= 4 (got %dx%d)", d->OH, d->OW);
     if (k27) {

@@ -782,11 +782,19 @@ int ilog2w(int v) {
 
 }  // namespace
 
-extern "C" int64_t dxmi_conv2d_wgrad_workspace_bytes(int32_t N, int32_t OH, int32_t OW, int32_t Cin, int32_t Cout, int32_t ksize) {
-    const long PT = ((long)N * OH * OW + 127) / 128 + 16;
-    long S = (ksize == 1 ? 1024 : 512) / ((long)(Cin / 64) * (Cout / 64));      // upper bound of the split count chosen at launch (1x1: 128 x 128 blocks, 256 workgroups)
+// Upper bound of the split count any launch below may choose: the workspace is sized with it and every launch checks its S
+// against it (round-3 ADVICE: the 128 x 128 1x1 path cuts 64-pixel tiles, the sizing assumed 128-pixel tiles).
+static long wgrad_split_bound(long npix, int Cin, int Cout, int ksize) {
+    const long PT = ksize == 1 ? (npix + 63) / 64 + 16 : (npix + 127) / 128 + 16;   // 1x1: 64-pixel tiles of the 128 x 128 kernel
+    long S = (ksize == 1 ? 1024 : 512) / ((long)(Cin / 64) * (Cout / 64));          // 1x1: 128 x 128 blocks, 256 workgroups; 64 x 64: 512
     if (S < 1) S = 1;
     if (S > PT) S = PT;
+    return S;
+}
+
+extern "C" int64_t dxmi_conv2d_wgrad_workspace_bytes(int32_t N, int32_t OH, int32_t OW, int32_t Cin, int32_t Cout, int32_t ksize) {
+    if (N <= 0 || OH <= 0 || OW <= 0 || Cin < 64 || Cout < 64 || (ksize != 1 && ksize != 3)) return 0;    // dxmi_conv2d_wgrad rejects these
+    const long S = wgrad_split_bound((long)N * OH * OW, Cin, Cout, ksize);
     return S * ksize * ksize * (int64_t)Cout * Cin * 4 + S * 4 * (int64_t)Cout * 4;   // + bias-gradient partials
 }
 
@@ -834,6 +842,8 @@ static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, co
     DXMI_CHECK_ARG(stride == 1 || stride == 2, "dxmi_conv2d_wgrad: stride %d unsupported", stride);
     DXMI_CHECK_ARG(x0 && dy && dw_oihw && workspace, "dxmi_conv2d_wgrad: null pointer");
     const int Cin = C0 + C1;
+    DXMI_CHECK_ARG(N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C0 > 0 && C1 >= 0 && Cout > 0,
+                   "dxmi_conv2d_wgrad: empty or negative shape (N %d, in %dx%dx(%d+%d), out %dx%dx%d)", N, IH, IW, C0, C1, OH, OW, Cout);
     DXMI_CHECK_ARG(ksize == 1 || ksize == 3, "dxmi_conv2d_wgrad: ksize %d unsupported", ksize);
     DXMI_CHECK_ARG(Cin % 64 == 0 && Cout % 64 == 0 && C0 % 64 == 0, "dxmi_conv2d_wgrad: Cin (%d+%d) and Cout (%d) must be multiples of 64", C0, C1, Cout);
     DXMI_CHECK_ARG((OW & (OW - 1)) == 0 && (OH & (OH - 1)) == 0 && OW >= 4 && OH >= 4, "dxmi_conv2d_wgrad: OH/OW must be powers of two >= 4");
@@ -857,6 +867,7 @@ static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, co
         int S = 256 / (a.CIB * a.COB);              // one 768-thread workgroup per CU
         if (S < 1) S = 1;
         if (S > a.PT) S = a.PT;
+        DXMI_CHECK_ARG(S <= wgrad_split_bound(npix, Cin, Cout, ksize), "dxmi_conv2d_wgrad: %d splits exceed the workspace bound", S);
         a.S = S;
         a.bpart = dbias ? reinterpret_cast<float*>(workspace) + (size_t)S * Cout * Cin : nullptr;
         hipStream_t st = (hipStream_t)stream;
@@ -876,6 +887,7 @@ static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, co
     int S = wgs / (a.CIB * a.COB);
     if (S < 1) S = 1;
     if (S > a.PT) S = a.PT;
+    DXMI_CHECK_ARG(S <= wgrad_split_bound(npix, Cin, Cout, ksize), "dxmi_conv2d_wgrad: %d splits exceed the workspace bound (DXMI_WGRAD_WGS?)", S);
     a.S = S;
     a.bpart = dbias ? reinterpret_cast<float*>(workspace) + (size_t)S * ksize * ksize * Cout * Cin : nullptr;
     const size_t lds = (size_t)(128 + a.SUBS * a.HH * a.HWd) * WG_PITCH;

@@ -372,6 +372,7 @@ __global__ __launch_bounds__(256) void quantize_u8_kernel(const float* __restric
 extern "C" int dxmi_timestep_embedding(const float* t, float* out, int32_t N, int32_t dim, int32_t order,
                                        float max_period, void* stream) {
     DXMI_CHECK_ARG(t && out && N > 0 && dim >= 4, "dxmi_timestep_embedding: bad arguments");
+    DXMI_CHECK_ARG(dim % 2 == 0, "dxmi_timestep_embedding: odd dim %d (the zero-padded last column of unet_small.py:25-26 is not implemented)", dim);
     const int total = N * (dim / 2);
     hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, out,
                        N, dim, order, logf(max_period));

@@ -865,6 +865,7 @@ extern "C" int dxmi_groupnorm_generic_fwd(const void* in0, int32_t C0, const voi
                                           void* workspace, int32_t N, int32_t HW, int32_t groups, float eps,
                                           int32_t apply_silu, void* stream) {
     DXMI_CHECK_ARG(in0 && out && gamma && beta && workspace, "dxmi_groupnorm_generic_fwd: null pointer");
+    DXMI_CHECK_ARG(N > 0 && HW > 0 && C0 > 0 && C1 >= 0, "dxmi_groupnorm_generic_fwd: empty or negative shape (N %d, HW %d, C %d+%d)", N, HW, C0, C1);
     const int C = C0 + C1;
     DXMI_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0 && C0 % 8 == 0 && C1 % 8 == 0 && (C1 == 0 || in1) && C <= 2048,
                    "dxmi_groupnorm_generic_fwd: C0=%d C1=%d groups=%d", C0, C1, groups);
@@ -1173,6 +1174,7 @@ extern "C" int dxmi_groupnorm_generic_bwd(const void* in0, int32_t C0, const voi
                                           void* workspace, int32_t N, int32_t HW, int32_t groups, float eps,
                                           int32_t apply_silu, void* stream) {
     DXMI_CHECK_ARG(in0 && dy && gamma && beta && dx0 && g_out && workspace, "dxmi_groupnorm_generic_bwd: null pointer");
+    DXMI_CHECK_ARG(N > 0 && HW > 0 && C0 > 0 && C1 >= 0, "dxmi_groupnorm_generic_bwd: empty or negative shape (N %d, HW %d, C %d+%d)", N, HW, C0, C1);
     const int C = C0 + C1;
     DXMI_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0 && C0 % 8 == 0 && C1 % 8 == 0 && (C1 == 0 || (in1 && dx1)) && C <= 2048,
                    "dxmi_groupnorm_generic_bwd: C0=%d C1=%d groups=%d", C0, C1, groups);

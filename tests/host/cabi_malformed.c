@@ -1,0 +1,124 @@
+/* Host-side robustness driver for the C-ABI ("-fsanitize=address on the host C-ABI shim").
+ * Built by `make -C diffusion-by-maxentirl_amd/csrc asan` against a HOST-ONLY AddressSanitizer + UBSan build of the
+ * library's sources (no device code: hipcc --offload-host-only; never run on the GPU box) and executed by
+ * tests/test_cabi_symbols.py.  Every call below hands an entry point a malformed argument set (null pointers, channel
+ * counts the kernels cannot tile, negative sizes, over-long lists): the contract (include/dxmi_hip.h, "Conventions") is a
+ * negative status + dxmi_last_error() text, no crash, no sanitizer report.  Device pointers are fake non-null addresses: the
+ * host side must never dereference them.
+ * Output: one line per case "ok <name> <status>" or "FAIL <name> <status>", exit code = number of failures. */
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "dxmi_hip.h"
+
+static int failures = 0;
+#define FAKE(n) ((void*)(uintptr_t)(0x100000ull * (n)))
+
+static void expect_einval(const char* name, int status) {
+    const char* msg = dxmi_last_error();
+    if (status == DXMI_EINVAL && msg && msg[0]) printf("ok   %-44s %d  (%s)\n", name, status, msg);
+    else { printf("FAIL %-44s %d  (%s)\n", name, status, msg ? msg : "(null)"); ++failures; }
+}
+static void expect_negative(const char* name, int status) {   /* valid arguments, no device: launch / device error, still no crash */
+    if (status < 0) printf("ok   %-44s %d\n", name, status);
+    else { printf("FAIL %-44s %d\n", name, status); ++failures; }
+}
+
+static dxmi_conv_desc good_conv(void) {
+    dxmi_conv_desc d;
+    memset(&d, 0, sizeof d);
+    d.in0 = FAKE(1); d.wpacked = FAKE(2); d.out = FAKE(3);
+    d.N = 4; d.IH = d.IW = d.OH = d.OW = 32; d.C0 = 128; d.Cout = 128; d.ksize = 3; d.stride = 1; d.pad = 1;
+    return d;
+}
+
+int main(void) {
+    setvbuf(stdout, NULL, _IOLBF, 0);
+    dxmi_conv_desc d;
+    /* ---- conv descriptor --------------------------------------------------------------------------------------- */
+    expect_einval("conv2d_fwd(NULL desc)", dxmi_conv2d_fwd(NULL, NULL));
+    d = good_conv(); d.in0 = NULL;      expect_einval("conv2d_fwd(in0 NULL)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.wpacked = NULL;  expect_einval("conv2d_fwd(wpacked NULL)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.out = NULL;      expect_einval("conv2d_fwd(out NULL)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.N = -4;          expect_einval("conv2d_fwd(N < 0)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.N = 0;           expect_einval("conv2d_fwd(N = 0)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.OH = -32;        expect_einval("conv2d_fwd(OH < 0)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.C0 = 0;          expect_einval("conv2d_fwd(C0 = 0)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.C0 = 100;        expect_einval("conv2d_fwd(C0 % 32 != 0)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.Cout = -128;     expect_einval("conv2d_fwd(Cout < 0)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.ksize = 5;       expect_einval("conv2d_fwd(ksize 5)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.stride = 3;      expect_einval("conv2d_fwd(stride 3)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.C1 = 128;        expect_einval("conv2d_fwd(C1 > 0, in1 NULL)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.act = 17;        expect_einval("conv2d_fwd(act 17)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.addvec = (const float*)FAKE(4); d.addvec_ld = 64;
+                                        expect_einval("conv2d_fwd(addvec_ld < Cout)", dxmi_conv2d_fwd(&d, NULL));
+    /* the wave-specialised path needs Cout % 64 == 0: variant pins it, so the dispatcher cannot quietly re-route */
+    d = good_conv(); d.Cout = 96; d.gn_stats = (float*)FAKE(5);
+                                        expect_einval("conv2d_fwd(gn_stats, Cout % 64 != 0)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.gn_out = FAKE(6); d.gn_groups = 32;     /* 32x32 map: no kernel holds whole images */
+                                        expect_einval("conv2d_fwd(gn_out on a 32x32 map)", dxmi_conv2d_fwd(&d, NULL));
+    d = good_conv(); d.IH = d.IW = d.OH = d.OW = 4; d.C0 = d.Cout = 256; d.gn_out = FAKE(6); d.gn_groups = 32;
+                                        expect_einval("conv2d_fwd(gn_out, gamma NULL)", dxmi_conv2d_fwd(&d, NULL));
+    expect_einval("conv2d_kernel_id(NULL)", dxmi_conv2d_kernel_id(NULL) < 0 ? DXMI_EINVAL : 0);
+    if (dxmi_conv2d_gn_fuse_supported(NULL) != 0 || dxmi_conv2d_gn_stats_partials(NULL) != 0) { printf("FAIL gn queries(NULL)\n"); ++failures; }
+    else printf("ok   gn_fuse_supported / gn_stats_partials(NULL) -> 0\n");
+    d = good_conv();                    expect_negative("conv2d_fwd(valid desc, no device)", dxmi_conv2d_fwd(&d, NULL));
+
+    /* ---- weight packing ---------------------------------------------------------------------------------------- */
+    expect_einval("pack_conv_weight(NULL src)", dxmi_pack_conv_weight(NULL, FAKE(1), 128, 128, 3, 0, 0, NULL));
+    expect_einval("pack_conv_weight(NULL dst)", dxmi_pack_conv_weight((const float*)FAKE(1), NULL, 128, 128, 3, 0, 0, NULL));
+    expect_einval("pack_conv_weight(ksize 2)", dxmi_pack_conv_weight((const float*)FAKE(1), FAKE(2), 128, 128, 2, 0, 0, NULL));
+    expect_einval("pack_conv_weight(Cout < 0)", dxmi_pack_conv_weight((const float*)FAKE(1), FAKE(2), -128, 128, 3, 0, 0, NULL));
+    expect_einval("pack_conv_weights(NULL items)", dxmi_pack_conv_weights(NULL, 3, NULL));
+    { dxmi_pack_item it[2]; memset(it, 0, sizeof it);
+      it[0].w = (const float*)FAKE(1); it[0].dst = FAKE(2); it[0].Cout = it[0].Cin = 128; it[0].ksize = 3;
+      it[1] = it[0]; it[1].dst = NULL;
+      expect_einval("pack_conv_weights(item dst NULL)", dxmi_pack_conv_weights(it, 2, NULL));
+      expect_einval("pack_conv_weights(count < 0)", dxmi_pack_conv_weights(it, -1, NULL)); }
+    if (dxmi_packed_conv_weight_bytes(-1, 128, 3, 0) > 0 || dxmi_packed_conv_weight_bytes(128, 128, 7, 0) > 0) { printf("FAIL packed_conv_weight_bytes(bad)\n"); ++failures; }
+    else printf("ok   packed_conv_weight_bytes(bad) <= 0\n");
+
+    /* ---- weight gradient --------------------------------------------------------------------------------------- */
+    expect_einval("conv2d_wgrad(NULL x)", dxmi_conv2d_wgrad(NULL, 128, NULL, 0, FAKE(1), (float*)FAKE(2), FAKE(3), 4, 32, 32, 32, 32, 128, 3, 1, 1, 0, 0, NULL));
+    expect_einval("conv2d_wgrad(NULL workspace)", dxmi_conv2d_wgrad(FAKE(1), 128, NULL, 0, FAKE(1), (float*)FAKE(2), NULL, 4, 32, 32, 32, 32, 128, 3, 1, 1, 0, 0, NULL));
+    expect_einval("conv2d_wgrad(Cout % 64 != 0)", dxmi_conv2d_wgrad(FAKE(1), 128, NULL, 0, FAKE(1), (float*)FAKE(2), FAKE(3), 4, 32, 32, 32, 32, 96, 3, 1, 1, 0, 0, NULL));
+    expect_einval("conv2d_wgrad(C0 = 0)", dxmi_conv2d_wgrad(FAKE(1), 0, NULL, 0, FAKE(1), (float*)FAKE(2), FAKE(3), 4, 32, 32, 32, 32, 128, 3, 1, 1, 0, 0, NULL));
+    expect_einval("conv2d_wgrad(N < 0)", dxmi_conv2d_wgrad(FAKE(1), 128, NULL, 0, FAKE(1), (float*)FAKE(2), FAKE(3), -4, 32, 32, 32, 32, 128, 3, 1, 1, 0, 0, NULL));
+    expect_einval("conv2d_wgrad(OW = 24)", dxmi_conv2d_wgrad(FAKE(1), 128, NULL, 0, FAKE(1), (float*)FAKE(2), FAKE(3), 4, 24, 24, 24, 24, 128, 3, 1, 1, 0, 0, NULL));
+    expect_einval("conv2d_wgrad(OH < 0)", dxmi_conv2d_wgrad(FAKE(1), 128, NULL, 0, FAKE(1), (float*)FAKE(2), FAKE(3), 4, 32, 32, -32, 32, 128, 3, 1, 1, 0, 0, NULL));
+    expect_einval("conv2d_wgrad_bias(NULL dbias)", dxmi_conv2d_wgrad_bias(FAKE(1), 128, NULL, 0, FAKE(1), (float*)FAKE(2), NULL, FAKE(3), 4, 32, 32, 32, 32, 128, 3, 1, 1, 0, 0, NULL));
+    if (dxmi_conv2d_wgrad_workspace_bytes(16, 16, 16, 256, 256, 1) < 64ll * 256 * 256 * 4 + 64ll * 4 * 256 * 4) { printf("FAIL wgrad_workspace_bytes(1x1, 64 splits)\n"); ++failures; }
+    else printf("ok   wgrad_workspace_bytes covers the 64 splits of the 128 x 128 1x1 kernel\n");
+
+    /* ---- GroupNorm / attention / elementwise / optimiser lists ------------------------------------------------- */
+    expect_einval("groupnorm_silu_fwd(NULL in)", dxmi_groupnorm_silu_fwd(NULL, 128, NULL, 0, (const float*)FAKE(1), (const float*)FAKE(2), FAKE(3), 4, 1024, 32, 1e-6f, 1, NULL));
+    expect_einval("groupnorm_silu_fwd(groups = 0)", dxmi_groupnorm_silu_fwd(FAKE(1), 128, NULL, 0, (const float*)FAKE(1), (const float*)FAKE(2), FAKE(3), 4, 1024, 0, 1e-6f, 1, NULL));
+    expect_einval("groupnorm_silu_fwd(C % groups)", dxmi_groupnorm_silu_fwd(FAKE(1), 100, NULL, 0, (const float*)FAKE(1), (const float*)FAKE(2), FAKE(3), 4, 1024, 32, 1e-6f, 1, NULL));
+    expect_einval("groupnorm_apply(NULL stats)", dxmi_groupnorm_apply(FAKE(1), 128, NULL, 8, NULL, 0, NULL, 0, (const float*)FAKE(1), (const float*)FAKE(2), NULL, 0, FAKE(3), 4, 1024, 32, 1e-6f, 1, NULL));
+    expect_einval("groupnorm_generic_fwd(N < 0)", dxmi_groupnorm_generic_fwd(FAKE(1), 192, NULL, 0, (const float*)FAKE(1), (const float*)FAKE(2), NULL, 0, FAKE(3), FAKE(4), -1, 1024, 32, 1e-5f, 1, NULL));
+    expect_einval("attention_fwd(NULL qkv)", dxmi_attention_fwd(NULL, FAKE(1), 4, 256, 256, 1, 0.0625f, NULL));
+    expect_einval("attention_fwd(C % heads)", dxmi_attention_fwd(FAKE(1), FAKE(2), 4, 256, 250, 4, 0.0625f, NULL));
+    expect_einval("attention_fwd(heads = 0)", dxmi_attention_fwd(FAKE(1), FAKE(2), 4, 256, 256, 0, 0.0625f, NULL));
+    expect_einval("attention_proj_fwd(T = 64)", dxmi_attention_proj_fwd(FAKE(1), FAKE(2), (const float*)FAKE(3), FAKE(4), FAKE(5), NULL, 4, 64, 256, 1, 0.0625f, NULL));
+    expect_einval("var_step_fwd(NULL x)", dxmi_var_step_fwd(NULL, (const float*)FAKE(1), (const float*)FAKE(2), (const float*)FAKE(3), (const float*)FAKE(4), (const float*)FAKE(5), (float*)FAKE(6), (float*)FAKE(7), (float*)FAKE(8), (float*)FAKE(9), 4, 3072, 0, NULL));
+    expect_einval("var_step_fwd(N < 0)", dxmi_var_step_fwd((const float*)FAKE(1), (const float*)FAKE(1), (const float*)FAKE(2), (const float*)FAKE(3), (const float*)FAKE(4), (const float*)FAKE(5), (float*)FAKE(6), (float*)FAKE(7), (float*)FAKE(8), (float*)FAKE(9), -4, 3072, 0, NULL));
+    expect_einval("var_gather_sched(NULL t)", dxmi_var_gather_sched(NULL, (const float*)FAKE(1), (const float*)FAKE(2), (const float*)FAKE(3), (const float*)FAKE(4), (float*)FAKE(5), (float*)FAKE(6), (float*)FAKE(7), (float*)FAKE(8), 4, 10, NULL));
+    expect_einval("gather_rows(NULL idx)", dxmi_gather_rows(FAKE(1), NULL, FAKE(2), 16, 64, 12288, NULL));
+    expect_einval("gather_rows(row_bytes < 0)", dxmi_gather_rows(FAKE(1), (const int64_t*)FAKE(3), FAKE(2), 16, 64, -12288, NULL));
+    expect_einval("quantize_u8(mode 9)", dxmi_quantize_u8((const float*)FAKE(1), FAKE(2), 4, 3, 1024, 9, 1, NULL));
+    expect_einval("linear_fwd(K = 0)", dxmi_linear_fwd((const float*)FAKE(1), FAKE(2), NULL, (float*)FAKE(3), 4, 0, 512, 0, 0, NULL));
+    expect_einval("timestep_embedding(dim odd)", dxmi_timestep_embedding((const float*)FAKE(1), (float*)FAKE(2), 4, 127, 0, 10000.f, NULL));
+    { void* ptrs[2] = {FAKE(1), FAKE(2)}; int64_t numel[2] = {1024, -5}; float lr[2] = {1e-3f, 1e-3f};
+      expect_einval("adam_step(count > DXMI_MT_MAX)", dxmi_adam_step(ptrs, ptrs, ptrs, ptrs, numel, lr, DXMI_MT_MAX + 1, 0.9, 0.999, 1e-8, 1.0, NULL, 0, NULL));
+      expect_einval("adam_step(NULL lists)", dxmi_adam_step(NULL, ptrs, ptrs, ptrs, numel, lr, 2, 0.9, 0.999, 1e-8, 1.0, NULL, 0, NULL));
+      expect_einval("adam_step(numel < 0)", dxmi_adam_step(ptrs, ptrs, ptrs, ptrs, numel, lr, 2, 0.9, 0.999, 1e-8, 1.0, NULL, 0, NULL));
+      expect_einval("radam_step(count < 0)", dxmi_radam_step(ptrs, ptrs, ptrs, ptrs, numel, lr, -2, 0.9, 0.999, 1e-8, 0.1, 1.0, 0.0, NULL, NULL, NULL));
+      expect_einval("gradnorm_clip(NULL partials)", dxmi_gradnorm_clip(ptrs, numel, 1, 0.1f, NULL, (float*)FAKE(3), 1, NULL)); }
+    expect_einval("dropout_bf16(p = 1.5)", dxmi_dropout_bf16(FAKE(1), FAKE(2), 1024, 1.5f, 7u, NULL));
+    expect_einval("colsum_f32(B = 0)", dxmi_colsum_f32((const float*)FAKE(1), (float*)FAKE(2), 0, 4, 128, NULL));
+    expect_einval("edm_step_fwd(NULL sigma)", dxmi_edm_step_fwd((const float*)FAKE(1), (const float*)FAKE(2), (const float*)FAKE(3), NULL, (const float*)FAKE(4), (const float*)FAKE(5), (float*)FAKE(6), (float*)FAKE(7), 4, 12288, 0.5f, NULL));
+
+    printf("%d failure(s)\n", failures);
+    return failures > 99 ? 99 : failures;
+}

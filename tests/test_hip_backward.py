@@ -74,6 +74,30 @@ def test_conv_wgrad(ops, N, cin, Cout, H, k):
     assert torch.equal(acc, got + got)
 
 
+@pytest.mark.parametrize("N,C,Cout,H,k,bias", [(16, 256, 256, 16, 1, True), (16, 256, 256, 16, 1, False), (24, 128, 128, 16, 1, True),
+                                              (16, 128, 128, 16, 3, True), (40, 256, 128, 8, 1, True)])
+def test_conv_wgrad_stays_inside_an_exactly_sized_workspace(ops, monkeypatch, N, C, Cout, H, k, bias):
+    """Round-3 ADVICE (high): the 128 x 128 1x1 kernel chose S = 64 splits of 64-pixel tiles at N=16, 256 -> 256, 16x16 while
+    dxmi_conv2d_wgrad_workspace_bytes assumed 128-pixel tiles (S = 48): 16 MiB written into 12.2 MiB.  The workspace here is
+    EXACTLY the advertised size, cut out of the middle of a guard buffer."""
+    from dxmi_hip._lib import load
+    need = load().dxmi_conv2d_wgrad_workspace_bytes(N, H, H, C, Cout, k)
+    guard = 1 << 20
+    buf = torch.full((need + 2 * guard,), 0x5A, dtype=torch.uint8, device=DEV)
+    monkeypatch.setattr(ops, "_workspace", lambda nbytes, device: buf[guard:guard + need] if nbytes <= need else pytest.fail("sizing"))
+    g = torch.Generator().manual_seed(N + C + H + k)
+    x = bf(torch.randn(N, C, H, H, generator=g))
+    dy = bf(torch.randn(N, Cout, H, H, generator=g))
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, C, k, k), dy, padding=k // 2)
+    got = ops.conv2d_wgrad(nhwc(x), nhwc(dy), k, with_bias=bias)
+    if bias:
+        got, db = got
+        assert rel_l2(db.cpu(), dy.sum((0, 2, 3))) < 1e-5
+    torch.cuda.synchronize()
+    assert rel_l2(got.cpu(), ref) < 1e-4
+    assert bool((buf[:guard] == 0x5A).all()) and bool((buf[guard + need:] == 0x5A).all()), "wgrad wrote outside its workspace"
+
+
 def test_colsum_and_pool_bwd_and_head_bwd(ops):
     g = torch.Generator().manual_seed(5)
     N, C, H = 5, 256, 8
