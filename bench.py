@@ -437,7 +437,14 @@ def main():
         out = step()
         marks[i + 1].record()
     sync_all()
-    elapsed = max_over_ranks(time.perf_counter() - t0)
+    my_elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(my_elapsed)
+    rank_elapsed = [my_elapsed]
+    if world > 1:       # every rank's own wall time over the same K steps (a scaling record should show which rank was slow)
+        tt = torch.zeros(world, device=device, dtype=torch.float64)
+        tt[rank] = my_elapsed
+        torch.distributed.all_reduce(tt)
+        rank_elapsed = tt.tolist()
     per_step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     assert torch.isfinite(out["sample"]).all()
 
@@ -499,6 +506,17 @@ def main():
                                  "fused Adam, device-side grad clip, dropout 0.1",
                          "grad_sync": "flat fp32 all-reduce over RCCL" if world > 1 else "none (1 GPU)"},
     }
+    from dxmi_hip import _lib
+    line["library"] = {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "dxmi_version": int(_lib.load().dxmi_version()),
+                       "selected_by_DXMI_LIB": bool(os.environ.get("DXMI_LIB"))}
+    if world > 1:
+        wire = getattr(getattr(tr, "sync_sampler", None), "wire_dtype", None) if args.train_steps > 0 else None
+        line["rccl"] = {"world": world, "backend": torch.distributed.get_backend(),
+                        "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                        "wire_dtype": str(wire or torch.float32).replace("torch.", ""),
+                        "collectives_in_generation": 0,
+                        "collectives_per_train_step": f"{T + 1} value-net all-reduces (20.5 MB fp32) + the U-Net's ~32 MB buckets (143 MB fp32)"}
+        line["per_rank_images_per_sec"] = [round(B * args.steps / e, 1) for e in rank_elapsed]
     if gen_summ:
         step_s = elapsed / args.steps
         convs = {k: v for k, v in gen_summ.items() if k[0].startswith("conv")}

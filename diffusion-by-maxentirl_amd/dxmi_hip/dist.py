@@ -153,7 +153,8 @@ class FlatGradSync:
             for h in self.handles:
                 h.wait()
             have = [i for i in range(len(self.params)) if self.params[i].grad is not None]
-            torch._foreach_copy_([views[i] for i in have], [self.params[i].grad for i in have])
+            if have:                    # torch's foreach ops reject empty lists (a rank may hold no gradient at all)
+                torch._foreach_copy_([views[i] for i in have], [self.params[i].grad for i in have])
             if missing:                 # the discarded collectives wrote into these slices
                 torch._foreach_zero_([views[i] for i in missing])
             if dist.get_backend() == "nccl":
@@ -185,7 +186,8 @@ class FlatGradSync:
                 if f > 0:
                     self.params[i].grad = torch.empty_like(self.params[i])
         have = [i for i in range(len(self.params)) if self.params[i].grad is not None]
-        torch._foreach_copy_([self.params[i].grad for i in have], [views[i] for i in have])   # one multi-tensor scatter back
+        if have:
+            torch._foreach_copy_([self.params[i].grad for i in have], [views[i] for i in have])   # one multi-tensor scatter back
         self._reset()
 
     __call__ = sync

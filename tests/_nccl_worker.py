@@ -42,6 +42,23 @@ def main():
         tr.sync_v, tr.sync_sampler = FlatGradSync(v, force=True), FlatGradSync(sampler, force=True)
     g = torch.Generator(device=dev).manual_seed(7 + rank)          # per-rank data
     img = torch.rand(B, 3, 32, 32, device=dev, generator=g) * 2 - 1
+    # ---- the exchange itself against the single-process mean: value-net gradients of a per-rank loss, gathered RAW from every
+    # rank (all_gather), averaged locally in rank order, vs what FlatGradSync leaves in .grad (RCCL's ring sums in another
+    # order: 1e-6 relative; at world 1 the AVG over one rank must return the gradient bit for bit)
+    for p in v.parameters():
+        p.grad = None
+    v(img, None).pow(2).sum().backward()
+    raw = torch.cat([p.grad.detach().flatten() for p in v.parameters()])
+    gathered = [torch.empty_like(raw) for _ in range(world)]
+    dist.all_gather(gathered, raw)
+    want = torch.stack(gathered).sum(0) / world
+    tr.sync_v()
+    got = torch.cat([p.grad.detach().flatten() for p in v.parameters()])
+    mean_err = ((got - want).norm() / want.norm()).item()
+    mean_bitwise = bool(torch.equal(got, want))
+    ranks_differ = bool(world == 1 or not torch.equal(gathered[0], gathered[-1]))     # the per-rank data really differed
+    for p in v.parameters():
+        p.grad = None
     ring = TransitionRing(1, T, B, (3, 32, 32), dev)
     sampler.eval()
     d = sampler.sample(B, device=dev, out=ring.next_slot())
@@ -58,7 +75,9 @@ def main():
     same = all(torch.equal(allc[0], c) for c in allc)
     fin = all(x == x for x in list(le.values()) + list(ls.values()))
     if rank == 0:
-        print(json.dumps({"world": world, "rank_identical_parameters": same, "finite": fin, "backend": dist.get_backend(),
+        print(json.dumps({"world": world, "rank_identical_parameters": same if world > 1 else None, "finite": fin, "backend": dist.get_backend(),
+                          "mean_rel_err": mean_err, "mean_bitwise": mean_bitwise, "ranks_differ": ranks_differ,
+                          "nccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()),
                           "flat_bytes": [tr.sync_v.flat.numel() * 4, tr.sync_sampler.flat.numel() * 4]}))
     dist.barrier()
     dist.destroy_process_group()

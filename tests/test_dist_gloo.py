@@ -231,3 +231,105 @@ def test_bucketed_overlapped_sync_gloo():
         want3 = (zero(o0["acc3"][k], o0["round3"][k]) + zero(o1["acc3"][k], o0["round3"][k])) / 2
         assert np.allclose(o0["round3"][k], want3, atol=1e-6) and np.array_equal(o0["round3"][k], o1["round3"][k]), k
     assert o0["same_buffer"] and o1["same_buffer"] and o0["round2_equal"] and o1["round2_equal"]
+
+
+# ---- round 4: the train step's whole collective SEQUENCE at world size 4 ---------------------------------------------
+def _sequence_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.join(ROOT, "diffusion-by-maxentirl_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dxmi_hip.dist as dd
+    log = []
+    real_all_reduce = dist.all_reduce
+
+    def logged(t, *a, **k):             # every collective this rank issues, in issue order
+        log.append((int(t.numel()), str(k.get("op", a[0] if a else "SUM")).split(".")[-1], bool(k.get("async_op", False))))
+        return real_all_reduce(t, *a, **k)
+    dd.dist.all_reduce = logged
+    T = 3
+    torch.manual_seed(11)               # same initial parameters everywhere (what broadcast_parameters establishes)
+    value = torch.nn.Sequential(torch.nn.Linear(12, 24), torch.nn.LeakyReLU(0.2), torch.nn.Linear(24, 1))
+    unet = torch.nn.ModuleDict({"down": torch.nn.Linear(12, 32), "mid": torch.nn.Linear(32, 32), "attn": torch.nn.Linear(32, 32),
+                                "up": torch.nn.Linear(32, 12)})
+    unet.register_parameter("log_betas", torch.nn.Parameter(torch.zeros(T)))
+    never = torch.nn.Linear(4, 4)       # a module whose parameters get no gradient on ANY rank (empty foreach lists)
+    sync_v, sync_u, sync_n = dd.FlatGradSync(value), dd.FlatGradSync(unet, bucket_mb=2e-3), dd.FlatGradSync(never)
+    g = torch.Generator().manual_seed(1000 + rank)      # rank-local data, as the rank-local replay ring
+    x = torch.randn(8, 12, generator=g)
+    local = {"value": [], "unet": None}
+    synced = {"value": [], "unet": None}
+    # update_f_v: one energy step + T TD steps, each: backward through the value net, all-reduce, optimiser step (trainer.py:230-346)
+    for step in range(T + 1):
+        for p in value.parameters():
+            p.grad = None
+        (value(x * (step + 1)).pow(2).mean()).backward()
+        local["value"].append([p.grad.clone().numpy() for p in value.parameters()])
+        sync_v()
+        synced["value"].append([p.grad.clone().numpy() for p in value.parameters()])
+    # update_sampler: one backward through value net INTO the U-Net; rank 2 does not touch the attention branch (missing gradients)
+    h = unet["mid"](torch.tanh(unet["down"](x)))
+    if rank != 2:
+        h = h + unet["attn"](h)
+    out = unet["up"](h) * torch.exp(unet.log_betas).sum()
+    for p in value.parameters():        # the policy step freezes the value net (trainer.py `_Frozen`): its hooks must not fire
+        p.requires_grad_(False)
+    value(out).sum().backward()
+    for p in value.parameters():
+        p.requires_grad_(True)
+    launched_during_backward = sync_u.next
+    local["unet"] = {k: (None if p.grad is None else p.grad.clone().numpy()) for k, p in unet.named_parameters()}
+    sync_u()
+    synced["unet"] = {k: p.grad.clone().numpy() for k, p in unet.named_parameters()}
+    sync_n()                            # nothing to exchange, nothing raised, .grad stays None
+    assert all(p.grad is None for p in never.parameters())
+    q.put((rank, log, local, synced, len(sync_u.buckets), launched_during_backward))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_step_collective_sequence_world4_gloo():
+    """The DxMI train step's exchange pattern (train_cifar10.py:298-309 + trainer.py:230-408) on 4 ranks: T+1 value-net
+    all-reduces, then the U-Net's bucketed reduce with one rank missing a branch's gradients, then a module nobody touched.
+    Every rank must issue the SAME collective sequence (sizes, ops, order) and end with the single-process mean of the per-rank
+    gradients, bit-identical across ranks."""
+    import socket
+    import numpy as np
+    world = 4
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sequence_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    logs = [r[1] for r in res]
+    for r in range(1, world):
+        assert [(n, op) for n, op, _ in logs[r]] == [(n, op) for n, op, _ in logs[0]], f"rank {r} issued a different collective sequence"
+    nb = res[0][4]
+    assert nb >= 3 and all(r[4] == nb for r in res)
+    # sequence: (T+1) x [value flat + used-flags]  +  nb U-Net buckets + flags  +  1 bucket + flags of the untouched module
+    T = 3
+    nv = sum(p.numel() for p in torch.nn.Sequential(torch.nn.Linear(12, 24), torch.nn.LeakyReLU(0.2), torch.nn.Linear(24, 1)).parameters())
+    sizes = [n for n, _, _ in logs[0]]
+    assert sizes[:2 * (T + 1)] == [nv, 4] * (T + 1)
+    assert len(sizes) == 2 * (T + 1) + nb + 1 + 2
+    assert res[0][5] >= 1 and res[2][5] < nb           # buckets launched DURING backward; rank 2 holds one back until sync()
+    for step in range(T + 1):
+        for i in range(4):
+            want = sum(res[r][2]["value"][step][i] for r in range(world)) / world
+            for r in range(world):
+                assert np.allclose(res[r][3]["value"][step][i], want, atol=1e-6)
+                assert np.array_equal(res[r][3]["value"][step][i], res[0][3]["value"][step][i])
+    for k in res[0][3]["unet"]:
+        like = res[0][3]["unet"][k]
+        want = sum((np.zeros_like(like) if res[r][2]["unet"][k] is None else res[r][2]["unet"][k]) for r in range(world)) / world
+        for r in range(world):
+            assert np.allclose(res[r][3]["unet"][k], want, atol=1e-6), k
+            assert np.array_equal(res[r][3]["unet"][k], like), k
+    assert res[2][2]["unet"]["attn.weight"] is None    # the missing gradients really were missing on rank 2

@@ -14,7 +14,13 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_trainer_step_under_rccl():
+_LINE = {}
+
+
+def _run_ranks():
+    """One run of the rank processes per session; both tests below read its line."""
+    if "line" in _LINE:
+        return _LINE["line"]
     world = torch.cuda.device_count()          # counting devices does not initialise the GPU in this process
     assert world >= 1
     with socket.socket() as s:
@@ -29,10 +35,30 @@ def test_trainer_step_under_rccl():
     outs = [p.communicate(timeout=900) for p in procs]
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-3000:]
-    line = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
-    assert line["backend"] == "nccl" and line["world"] == world
-    assert line["rank_identical_parameters"] and line["finite"]
+    _LINE["line"] = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
+    return _LINE["line"]
+
+
+def test_trainer_step_under_rccl():
+    """Any world size: the step runs under the nccl (= RCCL) backend with the persistent flat buffers of the whole parameter
+    sets; the exchanged value-net gradient equals the mean of the raw per-rank gradients (at 1 rank: bit for bit)."""
+    line = _run_ranks()
+    world = torch.cuda.device_count()
+    assert line["backend"] == "nccl" and line["world"] == world and line["finite"]
     assert line["flat_bytes"][0] == 5_134_595 * 4 and line["flat_bytes"][1] == (35_746_307 + 4) * 4
+    assert line["mean_rel_err"] < 1e-6
+    if world == 1:
+        assert line["mean_bitwise"]            # AVG over a 1-rank communicator returns its input
+
+
+def test_ranks_end_the_step_with_identical_parameters():
+    """Needs >= 2 GPUs: ranks see different data and different initial weights, and must end the step with bit-identical
+    parameters, the exchanged gradient being the single-process mean of the per-rank gradients.  On a 1-GPU box this is
+    SKIPPED (round-3 VERDICT: at one rank the assertion cannot fail)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("rank identity needs >= 2 GPUs (1 visible): unmeasured on this box, covered under gloo in tests/test_dist_gloo.py")
+    line = _run_ranks()
+    assert line["ranks_differ"] and line["rank_identical_parameters"] is True and line["mean_rel_err"] < 1e-6
 
 
 @pytest.mark.gpu
@@ -53,3 +79,6 @@ def test_bench_self_launch_over_visible_gpus():
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert line["n_gpus"] == n and line["steps"] == 2 and line["value"] > 0 and line["train_steps_per_sec"] > 0
     assert line["scaling"] == "weak" and line["config"]["images_per_gpu_per_step"] == 256
+    assert line["library"]["path"].endswith("libdxmi_hip.so") and line["library"]["dxmi_version"] >= 100
+    if n > 1:
+        assert line["rccl"]["world"] == n and len(line["per_rank_images_per_sec"]) == n

@@ -133,8 +133,7 @@ def test_var_sampling_vs_reference(golden_dir, T):
     s, sd = make_sampler(T)
     g = load(golden_dir, f"var_sampling_T{T}")
     B = int(g["B"])
-    torch.manual_seed(int(g["seed"]))
-    noise = [torch.randn(B, 3, 32, 32) for _ in range(T + 1)]  # the reference's CPU draws, re-drawn
+    noise = list(torch.from_numpy(g["noise"]))      # the reference run's own draws, stored with the fixture
     d = s.sample(B, device=DEV, noise=noise)
     assert len(d["l_sample"]) == T + 1 and len(d["mean"]) == T and d["sigma"][0].shape == (B, 1, 1, 1)
     errs = {k: rel_l2(torch.stack(d[k]).cpu(), g[k]) for k in ("l_sample", "mean", "control", "sigma", "logp")}
@@ -176,8 +175,7 @@ def test_sample_step_vs_reference(golden_dir, name, tb):
     s, sd = make_sampler(10, tb)
     g = load(golden_dir, name)
     x, t = torch.from_numpy(g["x"]), torch.from_numpy(g["t"])
-    torch.manual_seed(int(g["seed"]))
-    z = torch.randn_like(x)
+    z = torch.from_numpy(g["z"])                    # the reference run's own draw, stored with the fixture
     with torch.no_grad():
         d = s.sample_step(x.to(DEV), t.to(DEV), noise=z.to(DEV))
     for k in ("sample", "mean", "control"):
