@@ -455,7 +455,8 @@ static int conv2d_impl(const dxmi_conv_desc* d, void* stream, int* kernel_id) {
     DXMI_CHECK_ARG(d->N > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0 && d->IH > 0 && d->IW > 0 && d->C0 > 0 && d->C1 >= 0,
                    "dxmi_conv2d_fwd: empty or negative shape (N %d, in %dx%dx(%d+%d), out %dx%dx%d)", d->N, d->IH, d->IW, d->C0, d->C1, d->OH, d->OW, d->Cout);
     DXMI_CHECK_ARG(d->act >= DXMI_ACT_NONE && d->act <= DXMI_ACT_SILU, "dxmi_conv2d_fwd: act %d unknown", d->act);
-    DXMI_CHECK_ARG(!d->addvec || d->addvec_ld >= d->Cout, "dxmi_conv2d_fwd: addvec_ld %d < Cout %d", d->addvec_ld, d->Cout);
+    DXMI_CHECK_ARG(!d->addvec || d->addvec_ld == 0 || d->addvec_ld >= d->Cout,      // 0: one row for the whole batch (Model.temb_table)
+                   "dxmi_conv2d_fwd: addvec_ld %d is neither 0 (one shared row) nor >= Cout %d", d->addvec_ld, d->Cout);
     DXMI_CHECK_ARG((d->OW & (d->OW - 1)) == 0 && (d->OH & (d->OH - 1)) == 0 && d->OW >= 4 && d->OH >= 4,
                    "dxmi_conv2d_fwd: OH/OW must be powers of two >= 4 (got %dx%d)", d->OH, d->OW);
     if (k27) {

@@ -258,6 +258,16 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 // four accumulator values of a (cb, nb) are two pairs of one pixel: 8 pixels in registers, 16 in the DPP row.
                 const bool want_stats = p.gn_stats != nullptr;
                 const int cot_ = q % p.CT;
+#ifdef WS_DIRECT_STORE
+                // the output leaves from the accumulator layout: lane = pixel px of block nb, couts co .. co + 3 -> 8-byte stores,
+                // 32 contiguous bytes per pixel and instruction; the four cb of a wave and its ch partner fill the 256-byte row
+                // in L2.  The MFMA waves issue no loads, so nothing ever waits on these stores; the bulk movers drain nothing.
+                WsTile ct_;
+                tile_of(q, ct_);
+                bf16* const obase = reinterpret_cast<bf16*>(p.out) + ((((size_t)ct_.n0 * p.OH + ct_.oy0) * p.OW + ct_.ox0) * p.Cout + cot_ * 128);
+                // pixel of block nb: row (ph*8 + nb) / BROW, column ((ph*8 + nb) % BROW) * 16 + px
+                const int olane = (((ph * 8) / BROW) * p.OW + px) * p.Cout + 4 * kg + ch * 64;
+#endif
                 float* const stp = want_stats ? p.gn_stats + ((size_t)((q / p.CT) * 2 + ph) * (p.Cout >> 1) + cot_ * 64 + ch * 32 + kg * 2) * 2 : nullptr;
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
@@ -294,7 +304,12 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                         bf16x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+#ifdef WS_DIRECT_STORE
+                        if (cot_ * 128 + co < p.Cout)
+                            *reinterpret_cast<bf16x4*>(obase + olane + cb * 16 + ((nb / BROW) * p.OW + (nb % BROW) * 16) * p.Cout) = o;
+#else
                         *reinterpret_cast<bf16x4*>(a0 + nb * 4096) = o;
+#endif
                         if (want_stats) dxmi_stats4(o, st);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) acc[cb][nb][e] = 0.f;
@@ -324,6 +339,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
     } else if (wave < 6) {
         // ================================================================ weight loaders (waves 4, 5)
         const int lw = wave - 4;
+#if defined(WS_PRIO) && (WS_PRIO & 1)
+        __builtin_amdgcn_s_setprio(3);
+#endif
         const char* const wb = reinterpret_cast<const char*>(p.w) + (size_t)lane * 16;
         WsTile cur;
         tile_of(q, cur);
@@ -393,6 +411,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
     } else {
     // ==================================================================== bulk movers (waves 6, 7)
         const int bw = wave - 6;
+#if defined(WS_PRIO) && (WS_PRIO & 2)
+        __builtin_amdgcn_s_setprio(3);
+#endif
         const int t2 = bw * 64 + lane;                     // 0..127 over the two waves
         constexpr int HB2 = (WS_HALO_BLOCKS + 1) / 2;      // halo blocks per wave
         // halo block k of this wave = block bw + 2k: lane -> (halo pixel, 16-byte slot); slot s of pixel (hy, hx) holds
@@ -482,7 +503,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             }
         };
         auto fetch_residual = [&](const WsTile& t, int k0, int k1) { fetch_residual_at(p.residual + tile_base(t), t, k0, k1); };
+#ifdef WS_DIRECT_STORE
+        const bool do_drain = false;                       // the MFMA waves store their own output
+#else
         const bool do_drain = !(WS_DBG(4));
+#endif
         WsTile cur;
         tile_of(q, cur);
         // table rows that no DMA fills stay zero
@@ -556,7 +581,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                     int ka, kb, na, nb_;
                     piece_range(c, t, ka, kb);
                     if (ka < kb) {
+#ifndef WS_DIRECT_STORE
                         if (!pre_valid) read_pieces(ka, kb, vcur);       // first pieces of a tile switch: nothing was read ahead
+#endif
                         if (do_drain) {
 #pragma unroll
                             for (int u = 0; u < 2; ++u)      // (a store instruction always has valid lanes: every cout piece occurs in it)
@@ -568,7 +595,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                     WS_TSTAMP(165, wave == 6 && c == 0 && t == 0 && q == (int)blockIdx.x + qstride);
                     if (t < 8) piece_range(c, t + 1, na, nb_); else piece_range(c + 1, 0, na, nb_);
                     pre_valid = na < nb_;
+#ifndef WS_DIRECT_STORE
                     if (pre_valid) read_pieces(na, nb_, vnext);
+#endif
                     if (t == 8) {
                         // halo image (and everything older) landed; at the last chunk E1 needs the whole residual tile
                         if (wrap) ws_wait_vm(0);
@@ -596,6 +625,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
 
     // ==================================================================== last tile out: all eight waves
     // (every wave has passed the last E2; the two bulk movers alone needed ~3 us for the 64 KB)
+#ifndef WS_DIRECT_STORE
     {
         const int qlast = (int)blockIdx.x + ((ntiles - 1 - (int)blockIdx.x) / qstride) * qstride;
         WsTile lt;
@@ -619,6 +649,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         }
         WS_CLOCKSTAMP(174, wave == 0);
     }
+#endif
 }
 
 }  // namespace

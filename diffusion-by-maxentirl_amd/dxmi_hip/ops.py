@@ -748,6 +748,21 @@ def quantize_u8(x, mode=0, nhwc=True, out=None):
     return out
 
 
+def fid_stats(act):
+    """Activation statistics of the FID: act fp32 [N, D] (device) -> (mu fp64 [D], sigma fp64 [D, D]) = np.mean(act, axis=0),
+    np.cov(act, rowvar=False) of train_image_large.py:62-69, on the f32-input MFMA (csrc/fid_stats.hip)."""
+    _need_cuda(act)
+    assert act.dim() == 2 and act.dtype == torch.float32 and act.is_contiguous()
+    N, D = act.shape
+    lib = load()
+    mu = torch.empty(D, dtype=torch.float64, device=act.device)
+    sigma = torch.empty((D, D), dtype=torch.float64, device=act.device)
+    ws = _workspace(max(256, lib.dxmi_fid_stats_workspace_bytes(N, D)), act.device)
+    _prof("fid_stats", f"d{D}", float(N) * D * (D + 128), 4.0 * act.numel() * ((D + 127) // 128 + 1) / 2, lambda: check(
+        lib.dxmi_fid_stats(_ptr(act), N, D, _ptr(mu), _ptr(sigma), _ptr(ws), _stream()), "dxmi_fid_stats"))
+    return mu, sigma
+
+
 def nchw_f32_to_nhwc_bf16(x, out=None):
     _need_cuda(x, out)
     N, C, H, W = x.shape

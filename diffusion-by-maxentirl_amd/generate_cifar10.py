@@ -43,6 +43,10 @@ def main():
     ap.add_argument("--guidance_scale", type=float, default=None)
     ap.add_argument("--stat", type=str, default=None)
     ap.add_argument("--skip_fid", action="store_true")
+    ap.add_argument("--fid_extractor", type=str, default=None,
+                    help="'module:attribute' of the feature extractor the FID uses (the reference builds pytorch_fid's InceptionV3, "
+                         "whose weights this image cannot download): callable(batch in [0,1]) -> [features [B, 2048, h, w]]")
+    ap.add_argument("--fid_stats", type=str, default=None, help="statistics npz (`mu`, `sigma`) instead of the dataset's PNG folder")
     ap.add_argument("--synthetic", type=str, default=None, help="builtin config name, e.g. cifar10_T10 (random weights)")
     args, unknown = ap.parse_known_args()
 
@@ -125,18 +129,21 @@ def main():
     print0(f"Generated {args.n_generate} samples at {output_path} "
            f"({n_batches * args.batchsize / dt:.1f} images/s/rank incl. PNG writing)")
 
-    data_path = os.path.join("datasets", f"{run_config.data.name}_train_png")
+    data_path = args.fid_stats or os.path.join("datasets", f"{run_config.data.name}_train_png")
     if args.skip_fid or local_rank != 0:
         return
-    try:
-        from pytorch_fid.fid_score import calculate_fid_given_paths
-    except ImportError:
-        print0("pytorch_fid not installed: FID skipped (quality evaluation is outside the accelerated path)")
+    if args.fid_extractor is None:
+        print0("FID skipped: pass --fid_extractor module:attr (an InceptionV3 pool3 extractor; its weights are not in this image)")
         return
     if not os.path.exists(data_path):
         print0(f"Dataset not found at {data_path}: FID skipped")
         return
-    fid = calculate_fid_given_paths([output_path, data_path], batch_size=args.batchsize, device=device, dims=2048)
+    # reference :212-216: FID of the generated PNG folder against the dataset; the activation statistics run on the device
+    from pytorch_fid.fid_score import calculate_fid_given_paths, load_extractor
+    extractor = load_extractor(args.fid_extractor)
+    if hasattr(extractor, "to"):
+        extractor = extractor.to(device)
+    fid = calculate_fid_given_paths([output_path, data_path], batch_size=args.batchsize, device=device, dims=2048, extractor=extractor)
     print(f"FID score: {fid}")
 
 

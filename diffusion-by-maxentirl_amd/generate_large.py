@@ -32,6 +32,11 @@ def main():
     ap.add_argument("--batchsize", type=int, default=100)
     ap.add_argument("--guidance_scale", type=float, default=None)
     ap.add_argument("--skip_fid", action="store_true")
+    ap.add_argument("--fid_extractor", type=str, default=None,
+                    help="'module:attribute' of the feature extractor (the reference builds pytorch_fid's InceptionV3, whose "
+                         "weights this image cannot download): callable(batch in [0,1]) -> [features [B, dims, h, w]]")
+    ap.add_argument("--fid_stats", type=str, default=None, help="npz with the dataset's `mu` / `sigma` (reference: datasets/VIRTUAL_*.npz)")
+    ap.add_argument("--fid_dims", type=int, default=2048)
     ap.add_argument("--synthetic", type=str, default=None, help="builtin config name, e.g. imagenet64_T10 (random weights)")
     args, unknown = ap.parse_known_args()
 
@@ -113,11 +118,19 @@ def main():
         samples = torch.cat(gathered)
     if local_rank == 0:
         np.savez(os.path.join(args.log_dir, f"samples_{len(samples)}.npz"), samples.permute(0, 2, 3, 1).cpu().numpy())
-        try:
-            import pytorch_fid  # noqa: F401
-            print0("pytorch_fid found: run its fid_score on the saved npz (quality evaluation is outside the accelerated path)")
-        except ImportError:
-            print0("pytorch_fid not installed: FID skipped; samples saved as npz")
+    if args.fid_extractor is None or args.fid_stats is None:
+        print0("samples saved as npz; FID needs --fid_extractor module:attr (an InceptionV3 pool3 extractor: its weights are not in "
+               "this image) and --fid_stats <dataset statistics npz>")
+        return
+    # reference fid() (:57-74): this rank's strided share of ALL samples -> activations -> all_gather -> statistics -> distance;
+    # the statistics (np.mean / np.cov on the host in the reference) run on the device
+    from pytorch_fid.fid_score import fid_from_images, load_extractor, load_statistics
+    extractor = load_extractor(args.fid_extractor)
+    if hasattr(extractor, "to"):
+        extractor = extractor.to(device)
+    m2, s2 = load_statistics(args.fid_stats)
+    fid = fid_from_images(samples[local_rank::world], extractor, m2, s2, batch_size=50, dims=args.fid_dims, device=device)
+    print0(f"FID from {len(samples)} samples: {fid}")
 
 
 if __name__ == "__main__":

@@ -76,6 +76,11 @@ def main():
     ap.add_argument("--run", type=str, required=True)
     ap.add_argument("--synthetic_data", action="store_true")
     ap.add_argument("--max_iters", type=int, default=None, help="stop after this many iterations (smoke runs)")
+    ap.add_argument("--fid_extractor", type=str, default=None,
+                    help="'module:attribute' of the FID feature extractor (the reference builds pytorch_fid's InceptionV3, whose weights "
+                         "this image cannot download); with --fid_stats it enables the periodic fid() of training.fid_every")
+    ap.add_argument("--fid_stats", type=str, default=None, help="dataset statistics npz (`mu`, `sigma`; reference: datasets/VIRTUAL_*.npz)")
+    ap.add_argument("--fid_dims", type=int, default=2048)
     args, unknown = ap.parse_known_args()
     d_cmd_cfg = cmd.parse_nested_args(cmd.parse_unknown_args(unknown))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -143,12 +148,45 @@ def main():
     # device-resident replay ring (one trajectory per iteration, generated in place by the sampler; sigma is 1-D here)
     from models.DxMI.replay import TransitionRing
     state_dict = TransitionRing(1, trainer.n_timesteps, batchsize, sampler.sample_shape, device, with_y=class_cond, sigma_dims=1)
+    # periodic FID (reference :35-87, :256-257): n_fid_samples / sampling_batchsize / world batches per rank -> uint8 -> all ranks'
+    # activations gathered over RCCL -> statistics on the device (dxmi_fid_stats) -> distance; the best sampler is kept
+    fid_on = args.fid_extractor is not None and args.fid_stats is not None and cfg.training.get("fid_every") is not None
+    best_fid = float("inf")
+    if fid_on:
+        from dxmi_hip import ops
+        from pytorch_fid.fid_score import fid_from_images, load_extractor, load_statistics
+        extractor = load_extractor(args.fid_extractor)
+        extractor = extractor.to(device) if hasattr(extractor, "to") else extractor
+        m2, s2 = load_statistics(args.fid_stats)
+
+    def fid(it):
+        nonlocal best_fid
+        sb = cfg.training.sampling_batchsize
+        sampler.eval()
+        mine = [ops.quantize_u8(sampler.sample(sb, device=device, i_class=None, enable_grad=False)["sample"].contiguous().float(),
+                                mode=1, nhwc=False) for _ in range(int(cfg.training.n_fid_samples / sb / world))]
+        samples = torch.cat(mine)
+        if world > 1:                                   # reference :50-53, :59: gather the images, take this rank's strided share
+            parts = [torch.zeros_like(samples) for _ in range(world)]
+            torch.distributed.all_gather(parts, samples)
+            samples = torch.cat(parts)
+        value = fid_from_images(samples[local_rank::world], extractor, m2, s2, batch_size=50, dims=args.fid_dims, device=device)
+        print0(f"FID: {value}")
+        if local_rank == 0 and value < best_fid:
+            best_fid = value
+            np.savez(os.path.join(logdir, "best_samples.npz"), samples.permute(0, 2, 3, 1).cpu().numpy())
+            torch.save({"state_dict": unet.state_dict(), "fid": value, "i_iter": it}, os.path.join(logdir, "sampler.pth"))
+            torch.save({"state_dict": v.state_dict()}, os.path.join(logdir, "value.pth"))
+            print0(f"best FID: sampler saved at {os.path.join(logdir, 'sampler.pth')}")
+
     i_iter = -1
     for i_iter in range(n_iter):
         data, cond = next(loader)
         data = data.to(device)
         y = cond.get("y", None)
         y = y.to(device) if y is not None else None
+        if fid_on and i_iter % cfg.training.fid_every == 0:
+            fid(i_iter)
         sampler.eval()
         d_sample = sampler.sample(len(data), device=device, i_class=y, out=state_dict.next_slot() if len(data) == batchsize else None)
         append_buffer(state_dict, d_sample)
@@ -158,7 +196,7 @@ def main():
         if (i_iter + 1) % cfg.training.log_every == 0:
             print0(f"iter {i_iter}: d_loss {d_energy['ebm/d_loss_']:.4f} v_loss {d_energy['ebm/v_loss_']:.4f} "
                    f"sampler_loss {d_sampler['sampler/sampler_loss_']:.4f} lg_loss_scale {mp_trainer.lg_loss_scale:.3f}")
-    if local_rank == 0:
+    if local_rank == 0 and not (fid_on and best_fid < float("inf")):     # with FID tracking the best sampler is what stays on disk (reference :73-84)
         torch.save({"state_dict": unet.state_dict(), "fid": None, "i_iter": i_iter}, os.path.join(logdir, "sampler.pth"))
         torch.save({"state_dict": v.state_dict()}, os.path.join(logdir, "value.pth"))
         print0(f"saved {logdir}/sampler.pth and value.pth after {i_iter + 1} iterations")

@@ -78,7 +78,7 @@ typedef struct dxmi_conv_desc {
     int32_t upsample;        /* 1: input is nearest-upsampled x2 before the conv; 2: zero-stuffed x2 (the
                                 data gradient of a stride-2 conv is a stride-1 conv over the stuffed dY) */
     int32_t act;             /* DXMI_ACT_* applied last */
-    int32_t addvec_ld;
+    int32_t addvec_ld;       /* row stride of addvec in floats: >= Cout, or 0 = one row shared by the whole batch */
     int32_t in_mode;         /* DXMI_IN_*  */
     int32_t out_mode;        /* DXMI_OUT_* */
     int32_t variant;         /* 0 = default tiling; >0 selects an alternative (tuning / tests) */
@@ -407,6 +407,21 @@ int dxmi_dropout_bf16(const void* x, void* y, int64_t n, float p, uint32_t seed,
  * outside [-n_src_rows, n_src_rows) fills the row with 0xFF bytes instead of reading out of bounds. */
 int dxmi_gather_rows(const void* src, const int64_t* idx, void* dst, int64_t n_rows, int64_t n_src_rows,
                      int64_t row_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FID activation statistics (the part that needs no Inception weights).
+ * Replaces, on the device, the host-side numpy statistics the reference takes of the gathered activations:
+ *   m1, s1 = np.mean(act, axis=0), np.cov(act, rowvar=False)
+ * at train_image_large.py:62-69 (fid()), train_cifar10.py (fid()), and pytorch_fid/fid_score.py:283-303
+ * (calculate_activation_statistics).  act: fp32 [N, D] row-major (D % 4 == 0: pytorch_fid's feature sizes are 64 / 192 /
+ * 768 / 2048) -> mu fp64 [D], sigma fp64 [D, D] (unbiased, N - 1, as np.cov).  Column means in fp64; the centred Gram matrix on
+ * the f32-input MFMA (exact fp32 products, fp32 accumulation inside a row split), splits folded in fp64 in a fixed order
+ * (bitwise reproducible).  workspace: dxmi_fid_stats_workspace_bytes(N, D) bytes.
+ * The Frechet distance itself (a 2048 x 2048 matrix square root, fid_score.py:224-281) stays the reference's float64 host
+ * algorithm (scipy.linalg.sqrtm) in pytorch_fid/fid_score.py of this package.
+ * ---------------------------------------------------------------------------------------- */
+int64_t dxmi_fid_stats_workspace_bytes(int64_t N, int32_t D);
+int dxmi_fid_stats(const float* act, int64_t N, int32_t D, double* mu, double* sigma, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

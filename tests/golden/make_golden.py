@@ -30,8 +30,17 @@ tv = types.ModuleType("torchvision")
 tvt = types.ModuleType("torchvision.transforms")
 tvt.RandomCrop = object
 tv.transforms = tvt
+# pytorch_fid/inception.py:212-310 subclasses torchvision.models.inception.InceptionA/C/E at import (the FID fixtures only
+# call calculate_frechet_distance, which touches none of them): any attribute of the stub is torch.nn.Module
+tvm = types.ModuleType("torchvision.models")
+tvmi = types.ModuleType("torchvision.models.inception")
+tvmi.__getattr__ = lambda name: torch.nn.Module
+tvm.inception = tvmi
+tv.models = tvm
 sys.modules.setdefault("torchvision", tv)
 sys.modules.setdefault("torchvision.transforms", tvt)
+sys.modules.setdefault("torchvision.models", tvm)
+sys.modules.setdefault("torchvision.models.inception", tvmi)
 
 import models.DxMI.var_sampler as ref_vs  # noqa: E402
 import models.DxMI.unet_small as ref_unet  # noqa: E402
@@ -453,7 +462,38 @@ def gen_edm_trainer():
          mgrad_keys=np.array(gpick), n_opt_steps=np.int64(len(recorded)), **grads)
 
 
-GENS = {"schedule": gen_schedule, "unet": gen_unet_forward, "var_sampling": gen_var_sampling,
+def gen_fid():
+    """FID statistics path: the reference's own statistics expressions (train_image_large.py:68) and its own
+    calculate_frechet_distance (pytorch_fid/fid_score.py:224-281) on seeded synthetic activations (oracle/fid.py regenerates
+    them from the seeds; no activation tensor is stored)."""
+    import contextlib
+    import io
+    from pytorch_fid.fid_score import calculate_frechet_distance          # the REFERENCE's module (sys.path[0] = /root/reference)
+    from oracle.fid import CASES, synthetic_activations
+    out = {}
+    for name, dims, n1, n2, s1, s2, scale2, shift2 in CASES:
+        a1 = synthetic_activations(s1, n1, dims)
+        a2 = synthetic_activations(s2, n2, dims, scale=scale2, shift=shift2)
+        m1, c1 = np.mean(a1, axis=0), np.cov(a1, rowvar=False)
+        m2, c2 = np.mean(a2, axis=0), np.cov(a2, rowvar=False)
+        msg = io.StringIO()
+        with contextlib.redirect_stdout(msg):
+            fid = calculate_frechet_distance(mu1=m1, sigma1=c1, mu2=m2, sigma2=c2)
+        out[f"{name}_fid"] = np.float64(fid)
+        out[f"{name}_singular_retry"] = np.bool_("singular product" in msg.getvalue())
+        out[f"{name}_mu1"], out[f"{name}_mu2"] = m1, m2
+        out[f"{name}_trace1"], out[f"{name}_trace2"] = np.trace(c1), np.trace(c2)
+        out[f"{name}_fro1"], out[f"{name}_fro2"] = np.linalg.norm(c1), np.linalg.norm(c2)
+        out[f"{name}_corner1"] = c1[:8, :8].copy()
+        idx = np.random.RandomState(5).randint(0, dims, size=(64, 2))
+        out[f"{name}_idx"], out[f"{name}_entries1"] = idx, c1[idx[:, 0], idx[:, 1]]
+        if dims <= 64:
+            out[f"{name}_sigma1"], out[f"{name}_sigma2"] = c1, c2
+        print(name, "fid", fid, "retry", out[f"{name}_singular_retry"])
+    save("fid_stats", **out)
+
+
+GENS = {"fid": gen_fid, "schedule": gen_schedule, "unet": gen_unet_forward, "var_sampling": gen_var_sampling,
         "sample_step": gen_sample_step, "value": gen_value, "trainer": gen_trainer_step, "trainer_T4": gen_trainer_step_T4_resample, "log_prob": gen_log_prob_step, "output": gen_output_stage, "guidance": gen_guidance, "edm": gen_edm, "edm_trainer": gen_edm_trainer}
 
 if __name__ == "__main__":

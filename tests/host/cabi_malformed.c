@@ -119,6 +119,15 @@ int main(void) {
     expect_einval("colsum_f32(B = 0)", dxmi_colsum_f32((const float*)FAKE(1), (float*)FAKE(2), 0, 4, 128, NULL));
     expect_einval("edm_step_fwd(NULL sigma)", dxmi_edm_step_fwd((const float*)FAKE(1), (const float*)FAKE(2), (const float*)FAKE(3), NULL, (const float*)FAKE(4), (const float*)FAKE(5), (float*)FAKE(6), (float*)FAKE(7), 4, 12288, 0.5f, NULL));
 
+    /* ---- FID statistics ------------------------------------------------------------------------------------------ */
+    expect_einval("fid_stats(NULL act)", dxmi_fid_stats(NULL, 100, 64, (double*)FAKE(1), (double*)FAKE(2), FAKE(3), NULL));
+    expect_einval("fid_stats(N = 1)", dxmi_fid_stats((const float*)FAKE(1), 1, 64, (double*)FAKE(1), (double*)FAKE(2), FAKE(3), NULL));
+    expect_einval("fid_stats(D % 4 != 0)", dxmi_fid_stats((const float*)FAKE(1), 100, 66, (double*)FAKE(1), (double*)FAKE(2), FAKE(3), NULL));
+    expect_einval("fid_stats(D < 0)", dxmi_fid_stats((const float*)FAKE(1), 100, -64, (double*)FAKE(1), (double*)FAKE(2), FAKE(3), NULL));
+    expect_einval("fid_stats(NULL workspace)", dxmi_fid_stats((const float*)FAKE(1), 100, 64, (double*)FAKE(1), (double*)FAKE(2), NULL, NULL));
+    if (dxmi_fid_stats_workspace_bytes(-5, 64) != 0 || dxmi_fid_stats_workspace_bytes(100, -64) != 0) { printf("FAIL fid_stats_workspace_bytes(bad)\n"); ++failures; }
+    else printf("ok   fid_stats_workspace_bytes(bad) == 0\n");
+
     printf("%d failure(s)\n", failures);
     return failures > 99 ? 99 : failures;
 }

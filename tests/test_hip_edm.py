@@ -345,6 +345,31 @@ def test_cli_generate_large(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     arr = np.load(os.path.join(logdir, "samples_8.npz"))["arr_0"]
     assert arr.shape == (8, 16, 16, 3) and arr.dtype == np.uint8
+    assert "FID needs --fid_extractor" in r.stdout
+    # the FID mode proper (round 4): user-supplied extractor + dataset statistics; activations -> all_gather -> statistics on the
+    # device (dxmi_fid_stats) -> distance, as the reference's fid() (generate_large.py:57-74).  Checked against the oracle's
+    # host statistics of the very samples the run saved.
+    import re
+    import sys as _sys
+    tests_dir = os.path.dirname(os.path.abspath(__file__))
+    _sys.path.insert(0, tests_dir)
+    from fid_extractor_stub import PatchFeatures
+    from oracle import fid as ofid
+    rs = np.random.RandomState(3)
+    ref_act = (rs.random_sample((200, 16)) * 0.5 + 0.2).astype(np.float32)
+    m2, s2 = ofid.activation_statistics(ref_act)
+    np.savez(os.path.join(logdir, "VIRTUAL_stub.npz"), mu=m2, sigma=s2)
+    env2 = dict(env, PYTHONPATH=tests_dir + os.pathsep + env.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "generate_large.py", "--log_dir", logdir, "--n_sample", "48", "--batchsize", "16",
+                        "--fid_extractor", "fid_extractor_stub:PatchFeatures", "--fid_stats", os.path.join(logdir, "VIRTUAL_stub.npz"),
+                        "--fid_dims", "16"], cwd=pkg, env=env2, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = float(re.search(r"FID from 48 samples: ([-0-9.e+]+)", r.stdout).group(1))
+    saved = torch.from_numpy(np.load(os.path.join(logdir, "samples_48.npz"))["arr_0"]).permute(0, 3, 1, 2)
+    act = PatchFeatures()((saved / 255.0).float())[0][:, :, 0, 0].numpy()
+    m1, s1 = ofid.activation_statistics(act)
+    want = float(ofid.frechet_distance(m1, s1, m2, s2))
+    assert abs(got - want) <= 1e-4 * abs(want), (got, want)
 
 
 # ------------------------------------------------------------------------------------------ backward
