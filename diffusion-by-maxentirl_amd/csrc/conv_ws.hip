@@ -26,6 +26,13 @@
 // Everything else stays on conv_pipe.hip.
 #include "conv_common.h"
 #include <stdlib.h>
+#include <type_traits>
+
+// Round 4: the weight stream is register-staged and handed over in groups of three steps (one workgroup barrier per 96 / 48
+// MFMAs).  -DWS_PER_STEP_BARRIER builds the round-2/3 form (LDS-DMA loaders, one barrier per step) for A/B runs.
+#ifndef WS_PER_STEP_BARRIER
+#define WS_GROUP3 1
+#endif
 
 // halo blocks per bulk mover and step / number of steps that issue them (HB2 = 11 blocks per mover and chunk): 2 x 6 by default;
 // -DWS_HALO_PER=3 -DWS_HALO_STEPS=4 or 4 x 3 issue them earlier in the chunk (A/B builds through DXMI_LIB)
@@ -234,7 +241,13 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                     read_b(u, 1, By);
                     if (u & 1) mfma16(A1, Bx, 0); else mfma16(A0, Bx, 0);
                     WS_INTERLEAVE_4();
+#ifdef WS_GROUP3
+                    // groups of three steps: the loaders hand over three ring slots at a time (register-staged), so the MFMA
+                    // stream is interrupted by a barrier every 96 MFMAs instead of every 32
+                    if (u % 3 == 2) { if (!(WS_DBG(16))) WS_STAMPED_BARRIER(stamp_i + c * 9 + u); }
+#else
                     if (!(WS_DBG(16))) WS_STAMPED_BARRIER(stamp_i + c * 9 + u);   // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
+#endif
                     if (u & 1) read_a(u + 1, A0); else read_a(u + 1, A1);
                     read_b(u + 1, 0, Bx);
                     if (u & 1) mfma16(A1, By, 1); else mfma16(A0, By, 1);
@@ -258,72 +271,79 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 // four accumulator values of a (cb, nb) are two pairs of one pixel: 8 pixels in registers, 16 in the DPP row.
                 const bool want_stats = p.gn_stats != nullptr;
                 const int cot_ = q % p.CT;
-#ifdef WS_DIRECT_STORE
-                // the output leaves from the accumulator layout: lane = pixel px of block nb, couts co .. co + 3 -> 8-byte stores,
-                // 32 contiguous bytes per pixel and instruction; the four cb of a wave and its ch partner fill the 256-byte row
-                // in L2.  The MFMA waves issue no loads, so nothing ever waits on these stores; the bulk movers drain nothing.
-                WsTile ct_;
-                tile_of(q, ct_);
-                bf16* const obase = reinterpret_cast<bf16*>(p.out) + ((((size_t)ct_.n0 * p.OH + ct_.oy0) * p.OW + ct_.ox0) * p.Cout + cot_ * 128);
-                // pixel of block nb: row (ph*8 + nb) / BROW, column ((ph*8 + nb) % BROW) * 16 + px
-                const int olane = (((ph * 8) / BROW) * p.OW + px) * p.Cout + 4 * kg + ch * 64;
-#endif
                 float* const stp = want_stats ? p.gn_stats + ((size_t)((q / p.CT) * 2 + ph) * (p.Cout >> 1) + cot_ * 64 + ch * 32 + kg * 2) * 2 : nullptr;
+                // The run-time switches (residual / mask / activation / statistics) are uniform for the launch: as branches inside
+                // the 32 (cb, nb) bodies they cost ~130 scalar branches and their s_nop shadows per tile and keep hipcc from
+                // batching the LDS traffic (round 4: the epilogue was 9.4 k of a 128-channel tile's 38 k cycles).  The U-Net's
+                // four combinations get straight-line code; everything else takes the generic body.
+                auto epi = [&](auto RES, auto MASK, auto ACT, auto STATS) {
+                    constexpr bool kRes = decltype(RES)::value, kMask = decltype(MASK)::value, kAct = decltype(ACT)::value, kStats = decltype(STATS)::value;
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    float st[4] = {0.f, 0.f, 0.f, 0.f};
-                    const int co = ch * 64 + cb * 16 + 4 * kg;
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb + co), t0 = *reinterpret_cast<const f32x4*>(tb + 128 + co);
-                    f32x4 bv;
+                    for (int cb = 0; cb < 4; ++cb) {
+                        float st[4] = {0.f, 0.f, 0.f, 0.f};
+                        const int co = ch * 64 + cb * 16 + 4 * kg;
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb + co), t0 = *reinterpret_cast<const f32x4*>(tb + 128 + co);
+                        f32x4 bv;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[e] = b0[e] + t0[e];
-                    char* const a0 = rowb + (((ch * 8 + cb * 2 + (kg >> 1)) ^ px) << 4);   // slot of this cout piece: (c8 ^ (pixel & 15))
-                    bf16x4 r[8];
-                    if (has_res) {
+                        for (int e = 0; e < 4; ++e) bv[e] = b0[e] + t0[e];
+                        char* const a0 = rowb + (((ch * 8 + cb * 2 + (kg >> 1)) ^ px) << 4);   // slot of this cout piece: (c8 ^ (pixel & 15))
+                        bf16x4 r[8];
+                        if constexpr (kRes) {
 #pragma unroll
-                        for (int nb = 0; nb < 8; ++nb) r[nb] = *reinterpret_cast<const bf16x4*>(a0 + nb * 4096);
-                    }
+                            for (int nb = 0; nb < 8; ++nb) r[nb] = *reinterpret_cast<const bf16x4*>(a0 + nb * 4096);
+                        }
 #pragma unroll
-                    for (int nb = 0; nb < 8; ++nb) {
-                        f32x4 v;
+                        for (int nb = 0; nb < 8; ++nb) {
+                            f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[cb][nb][e] + bv[e];
-                        if (has_res) {
-                            if (p.res_is_mask) {          // data gradient through a LeakyReLU: the tile the movers fetched is the mask source
+                            for (int e = 0; e < 4; ++e) v[e] = acc[cb][nb][e] + bv[e];
+                            if constexpr (kRes) {
+                                if constexpr (kMask) {    // data gradient through a LeakyReLU: the tile the movers fetched is the mask source
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] *= ((float)r[nb][e] > 0.f ? 1.f : p.mask_slope);
-                            } else {
+                                    for (int e = 0; e < 4; ++e) v[e] *= ((float)r[nb][e] > 0.f ? 1.f : p.mask_slope);
+                                } else {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += (float)r[nb][e];
+                                    for (int e = 0; e < 4; ++e) v[e] += (float)r[nb][e];
+                                }
+                            }
+                            if constexpr (kAct) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = dxmi_act_lin(v[e], slope);
+                            }
+                            bf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+                            *reinterpret_cast<bf16x4*>(a0 + nb * 4096) = o;
+                            if constexpr (kStats) dxmi_stats4(o, st);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[cb][nb][e] = 0.f;
+                        }
+                        if constexpr (kStats) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) st[e] = dxmi_row16_sum(st[e]);
+                            if (px == 0 && cot_ * 128 + co < p.Cout) {
+                                f32x4 sv;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) sv[e] = st[e];
+                                *reinterpret_cast<f32x4*>(stp + cb * 16) = sv;     // pairs (co / 2, co / 2 + 1): 8 pairs per 16-cout block
                             }
                         }
-                        if (!plain) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = dxmi_act_lin(v[e], slope);
-                        }
-                        bf16x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-#ifdef WS_DIRECT_STORE
-                        if (cot_ * 128 + co < p.Cout)
-                            *reinterpret_cast<bf16x4*>(obase + olane + cb * 16 + ((nb / BROW) * p.OW + (nb % BROW) * 16) * p.Cout) = o;
-#else
-                        *reinterpret_cast<bf16x4*>(a0 + nb * 4096) = o;
-#endif
-                        if (want_stats) dxmi_stats4(o, st);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[cb][nb][e] = 0.f;
                     }
-                    if (want_stats) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) st[e] = dxmi_row16_sum(st[e]);
-                        if (px == 0 && cot_ * 128 + co < p.Cout) {
-                            f32x4 sv;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) sv[e] = st[e];
-                            *reinterpret_cast<f32x4*>(stp + cb * 16) = sv;     // pairs (co / 2, co / 2 + 1): 8 pairs per 16-cout block
-                        }
-                    }
+                };
+                using T_ = std::true_type;
+                using F_ = std::false_type;
+                const bool is_mask = has_res && p.res_is_mask;
+                if (plain && !is_mask) {                 // the U-Net's convs
+                    if (has_res) { if (want_stats) epi(T_{}, F_{}, F_{}, T_{}); else epi(T_{}, F_{}, F_{}, F_{}); }
+                    else { if (want_stats) epi(F_{}, F_{}, F_{}, T_{}); else epi(F_{}, F_{}, F_{}, F_{}); }
+                } else if (!want_stats) {                // the value net: LeakyReLU forward / masked data gradients
+                    if (is_mask) { if (plain) epi(T_{}, T_{}, F_{}, F_{}); else epi(T_{}, T_{}, T_{}, F_{}); }
+                    else if (has_res) epi(T_{}, F_{}, T_{}, F_{});
+                    else epi(F_{}, F_{}, T_{}, F_{});
+                } else {                                 // statistics together with an activation / a mask
+                    if (is_mask) epi(T_{}, T_{}, T_{}, T_{});
+                    else if (has_res) epi(T_{}, F_{}, T_{}, T_{});
+                    else epi(F_{}, F_{}, T_{}, T_{});
                 }
             }
             WS_TSTAMP(166, wave == 0 && q == (int)blockIdx.x);
@@ -339,9 +359,6 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
     } else if (wave < 6) {
         // ================================================================ weight loaders (waves 4, 5)
         const int lw = wave - 4;
-#if defined(WS_PRIO) && (WS_PRIO & 1)
-        __builtin_amdgcn_s_setprio(3);
-#endif
         const char* const wb = reinterpret_cast<const char*>(p.w) + (size_t)lane * 16;
         WsTile cur;
         tile_of(q, cur);
@@ -359,6 +376,163 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 __builtin_amdgcn_global_load_lds(WS_GPTR(src + (size_t)cb * 1024), WS_LPTR(dst + f * 1024), 16, 0, 0);
             }
         };
+#ifdef WS_GROUP3
+        // Round 4: register-staged weight stream, handed over in GROUPS of three steps.  The ring's six slots are two groups: the
+        // MFMA waves read group G (slots of parity G & 1) while this wave writes group G + 1 into the other three slots (last
+        // read in group G - 1: complete at the barrier that ended it) from registers, with ds_write_b128.  The fragments were
+        // requested two group steps earlier by plain global_load_dwordx4 (two register sets of 12 x 4 registers): a
+        // `global_load_lds` costs its wave ~190 cycles of issue (tools/dma_probe.hip, tools/stage_probe.hip), four per step
+        // and loader were more than a 512-cycle step, and one workgroup barrier per step cost 11-15 % by itself
+        // (DXMI_CONV_WS_DBG=15 vs 31).  vmcnt retires in order: each wait leaves the 12 loads of the younger group in flight.
+        u32x4 fq[2][3][4];
+        auto load_tap = [&](int cot, int g, u32x4 (&f)[4]) {
+            const int c = g / 9, t = g - c * 9;
+            const char* src = wb + ((size_t)(t * p.KST + c * 2 + lw) * p.CB) * 1024;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cb = cot * 4 + k < p.CB ? cot * 4 + k : p.CB - 1;
+                // inline asm: hipcc's own wait-count pass loses the count of loads in flight across the loop's back edge and
+                // drains the queue (s_waitcnt vmcnt(0)) before the first ds_write of every trip; the waits below are exact
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f[k]) : "v"(src + (size_t)cb * 1024) : "memory");
+            }
+        };
+        auto store_tap = [&](int g, const u32x4 (&f)[4]) {
+            char* dst = aring + (g % WS_RING) * WS_A_SLOT + lw * 4096 + lane * 16;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(dst + k * 1024) = f[k];
+        };
+        const int NG = S / 3;                           // groups per tile (even: S = 9 * nchunks, nchunks even)
+        // group G of the current tile, or group G - NG of the next one (past the last tile: the current tile's again, unused)
+        auto load_group = [&](int G, int cot_cur, int cot_nxt, u32x4 (&f)[3][4]) {
+            const bool nx = G >= NG;
+            const int g0 = (nx ? G - NG : G) * 3, cot = nx ? cot_nxt : cot_cur;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) load_tap(cot, g0 + j, f[j]);
+        };
+        auto store_group = [&](int G, const u32x4 (&f)[3][4]) {     // ring slots depend on G's parity only (NG even)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) store_tap((G & 1) * 3 + j, f[j]);
+        };
+        if (WS_DBG(1)) {}                               // (timing-only ablation of the weight stream: not available in this build)
+        load_group(0, cur.cot, cur.cot, fq[0]);
+        load_group(1, cur.cot, cur.cot, fq[1]);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        store_group(0, fq[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        load_group(2, cur.cot, cur.cot, fq[0]);
+        ws_barrier();                                       // P0 (its lgkmcnt(0): group 0 is in LDS)
+        bool first_tile = true;
+        for (;;) {
+            const bool more = q + qstride < ntiles;
+            WsTile nxt = cur;
+            if (more) tile_of(q + qstride, nxt);
+            if (!first_tile && lw == 0 && !(WS_DBG(8))) {
+                // bias / temb table of this tile: four 256-byte DMAs issued after E2 (the previous epilogue is done with the
+                // table); from the second group step on every wait below covers them (they are older than the 12 youngest)
+                const int co_a = cur.cot * 128 + lane, co_b = co_a + 64 < p.Cout ? co_a + 64 : p.Cout - 1;
+                if (p.bias) {
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_a), WS_LPTR(tb), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_b), WS_LPTR(tb + 64), 4, 0, 0);
+                }
+                if (p.addvec) {
+                    const float* av = p.addvec + (size_t)cur.n0 * p.addvec_ld;
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_a), WS_LPTR(tb + 128), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_b), WS_LPTR(tb + 192), 4, 0, 0);
+                }
+            }
+            first_tile = false;
+            for (int G0 = 0; G0 < NG; G0 += 2) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int G = G0 + j;
+                    // group step G (the MFMA waves read group G): group G + 1 sits in set (j + 1) & 1 since group step G - 1
+                    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // ... and has landed (group G + 2's loads stay in flight)
+                    store_group(G + 1, fq[(j + 1) & 1]);
+                    // the barrier's lgkmcnt(0) must precede the refill: a ds_write reads its data registers when it executes
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    load_group(G + 3, cur.cot, more ? nxt.cot : cur.cot, fq[(j + 1) & 1]);
+                    if (!(WS_DBG(16))) ws_barrier();                        // end of group step G
+                }
+            }
+            ws_barrier();                                        // E1
+            ws_barrier();                                        // E2
+            if (!more) break;
+            q += qstride;
+            cur = nxt;
+        }
+#elif defined(WS_LOADER_STAGE)
+        // Round 4: the weight fragments go through REGISTERS instead of LDS-DMA.  A `global_load_lds` costs its wave ~190 cycles
+        // of issue whatever it keeps in flight (tools/dma_probe.hip, tools/stage_probe.hip): four per step and loader is more
+        // than a 512-cycle step.  A loader wave has nothing else to do and 256 registers: fragments of step g + WS_LQ are
+        // requested with plain global_load_dwordx4 (16 registers per step in flight), step g + 1's are written into its ring
+        // slot with ds_write_b128 once they have landed (vmcnt retires in order: the wait leaves the WS_LQ - 1 younger steps in
+        // flight).  Ring slot (g + 1) % 6 was last read in step g - 5.
+        constexpr int WS_LQ = 6;                        // steps of fragments in flight; S % 6 == 0 (host-checked)
+        u32x4 fq[WS_LQ][4];
+        auto load_tap = [&](int cot, int g, u32x4 (&f)[4]) {
+            const int c = g / 9, t = g - c * 9;
+            const char* src = wb + ((size_t)(t * p.KST + c * 2 + lw) * p.CB) * 1024;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cb = cot * 4 + k < p.CB ? cot * 4 + k : p.CB - 1;
+                // inline asm: hipcc's own wait-count pass loses the count of loads in flight across the loop's back edge and
+                // drains the queue (s_waitcnt vmcnt(0)) before the first ds_write of every trip; the waits below are exact
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f[k]) : "v"(src + (size_t)cb * 1024) : "memory");
+            }
+        };
+        auto store_tap = [&](int g, const u32x4 (&f)[4]) {
+            char* dst = aring + (g % WS_RING) * WS_A_SLOT + lw * 4096 + lane * 16;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(dst + k * 1024) = f[k];
+        };
+        // prologue: steps 0 .. WS_LQ - 1 requested; step 0 written before P0
+#pragma unroll
+        for (int j = 0; j < WS_LQ; ++j) load_tap(cur.cot, j, fq[j]);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (WS_LQ - 1)) : "memory");
+        store_tap(0, fq[0]);
+        ws_barrier();                                       // P0
+        bool first_tile = true;
+        for (;;) {
+            const bool more = q + qstride < ntiles;
+            WsTile nxt = cur;
+            if (more) tile_of(q + qstride, nxt);
+            if (!first_tile && lw == 0 && !(WS_DBG(8))) {
+                // bias / temb table of this tile (see the DMA path below); four 256-byte DMAs, older than every load of this tile
+                const int co_a = cur.cot * 128 + lane, co_b = co_a + 64 < p.Cout ? co_a + 64 : p.Cout - 1;
+                if (p.bias) {
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_a), WS_LPTR(tb), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_b), WS_LPTR(tb + 64), 4, 0, 0);
+                }
+                if (p.addvec) {
+                    const float* av = p.addvec + (size_t)cur.n0 * p.addvec_ld;
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_a), WS_LPTR(tb + 128), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_b), WS_LPTR(tb + 192), 4, 0, 0);
+                }
+            }
+            first_tile = false;
+            for (int g0 = 0; g0 < S; g0 += WS_LQ) {
+#pragma unroll
+                for (int j = 0; j < WS_LQ; ++j) {
+                    const int g = g0 + j;
+                    // set j held step g (written to the ring in step g - 1, or by the prologue): refill it with step g + WS_LQ;
+                    // past the last tile the same addresses are read again (results unused: keeps the wait counts uniform)
+                    const int gn = g + WS_LQ;
+                    if (gn < S) load_tap(cur.cot, gn, fq[j]);
+                    else load_tap(nxt.cot, gn - S, fq[j]);
+                    // step g + 1's fragments: the WS_LQ - 1 younger steps stay in flight (the table DMAs of a tile start are
+                    // younger than its first steps' loads: the wait then only waits for a little more)
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (WS_LQ - 1)) : "memory");
+                    store_tap(g + 1, fq[(j + 1) % WS_LQ]);
+                    if (!(WS_DBG(16))) ws_barrier();                                // B_g (lgkmcnt(0): the writes are in LDS)
+                }
+            }
+            ws_barrier();                                        // E1
+            ws_barrier();                                        // E2
+            if (!more) break;
+            q += qstride;
+            cur = nxt;
+        }
+#else
 #pragma unroll 1
         for (int g = 0; g < WS_RING - 1; ++g) issue_tap(cur.cot, g);
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tap 0 landed (4 younger taps may be outstanding)
@@ -407,13 +581,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             q += qstride;
             cur = nxt;
         }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
     // ==================================================================== bulk movers (waves 6, 7)
         const int bw = wave - 6;
-#if defined(WS_PRIO) && (WS_PRIO & 2)
-        __builtin_amdgcn_s_setprio(3);
-#endif
         const int t2 = bw * 64 + lane;                     // 0..127 over the two waves
         constexpr int HB2 = (WS_HALO_BLOCKS + 1) / 2;      // halo blocks per wave
         // halo block k of this wave = block bw + 2k: lane -> (halo pixel, 16-byte slot); slot s of pixel (hy, hx) holds
@@ -503,11 +675,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             }
         };
         auto fetch_residual = [&](const WsTile& t, int k0, int k1) { fetch_residual_at(p.residual + tile_base(t), t, k0, k1); };
-#ifdef WS_DIRECT_STORE
-        const bool do_drain = false;                       // the MFMA waves store their own output
-#else
         const bool do_drain = !(WS_DBG(4));
-#endif
         WsTile cur;
         tile_of(q, cur);
         // table rows that no DMA fills stay zero
@@ -553,6 +721,98 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             for (int u = 0; u < 2; ++u)
                 if (ka + u < kb) v[u] = *reinterpret_cast<const bf16x8*>(ro + ((ka + u) * 128 + t2) * 16);
         };
+#ifdef WS_BULK_STAGE
+        // Round 4 (needs WS_GROUP3): the bulk movers' LOADS go through registers too.  Per group step: wait for everything this
+        // wave has in flight (loads AND stores: it has a whole group step of slack), write what the previous group step
+        // requested into LDS (halo blocks of the next chunk, residual pieces of this tile), then request this group step's
+        // share — halo blocks [0,6) / [6,11) of the next chunk in group steps 0 / 1, the tile switch's pieces of the three
+        // steps: output piece LDS -> registers -> global store, residual piece global -> registers.  A plain load + ds_write_b128
+        // costs the wave ~70 cycles per KiB against ~140-200 for an LDS-DMA and takes half the issue slots from the MFMA wave
+        // on its SIMD (tools/stage_probe.hip).
+        u32x4 hq[6], rq[6];
+        int rq_ka = 32, rq_kb = 32;                    // residual pieces requested in the previous group step
+        auto halo_load = [&](int c, int ka, int kb) {  // blocks ka .. kb-1 of this wave's share -> hq[k - ka]
+            const int cbase = c * 32;
+            const bool first = cbase < p.C0;
+            const char* base = reinterpret_cast<const char*>(first ? p.in0 : p.in1) + (first ? cbase : cbase - p.C0) * 2 + (first ? hbase0 : hbase1);
+#pragma unroll
+            for (int k = 0; k < HB2; ++k) {
+                if (k < ka || k >= kb) continue;
+                const char* g = (hmask >> k) & 1 ? base + (first ? hrel0[k] : hrel1[k]) : zero_page;
+                if (bw + 2 * k < WS_HALO_BLOCKS) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(hq[k - ka]) : "v"(g) : "memory");
+            }
+        };
+        auto halo_store = [&](char* buf, int ka, int kb) {
+#pragma unroll
+            for (int k = 0; k < HB2; ++k) {
+                if (k < ka || k >= kb) continue;
+                if (bw + 2 * k < WS_HALO_BLOCKS) *reinterpret_cast<u32x4*>(buf + (bw + 2 * k) * 1024 + lane * 16) = hq[k - ka];
+            }
+        };
+        for (;;) {
+            const bool more = q + qstride < ntiles;
+            for (int c = 0; c < nchunks; ++c) {
+                const bool wrap = c + 1 == nchunks;
+                if (wrap && more) {
+                    tile_of(q + qstride, nxt);
+                    out_next = reinterpret_cast<bf16*>(p.out) + tile_base(cur);
+                    res_next = p.residual + tile_base(nxt);
+                    halo_plan(nxt);
+                }
+                const bool do_halo = (!wrap || more) && !(WS_DBG(2));
+                char* const hbuf = halo0 + ((c + 1) & 1) * WS_HALO;
+                const int hc = wrap ? 0 : c + 1;
+#pragma unroll
+                for (int g3 = 0; g3 < 3; ++g3) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    // 1. into LDS: what the previous group step requested
+                    if (g3 == 1 && do_halo) halo_store(hbuf, 0, 6);
+                    if (g3 == 2 && do_halo) halo_store(hbuf, 6, HB2);
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+                        if (rq_ka + u < rq_kb) *reinterpret_cast<u32x4*>(ro + ((rq_ka + u) * 128 + t2) * 16) = rq[u];
+                    rq_ka = rq_kb = 32;
+                    // 2. this group step's requests
+                    if (g3 == 0 && do_halo) halo_load(hc, 0, 6);
+                    if (g3 == 1 && do_halo) halo_load(hc, 6, HB2);
+                    int ka, kb, kx, ky;
+                    piece_range(c, 3 * g3, ka, kx);
+                    piece_range(c, 3 * g3 + 2, ky, kb);
+                    if (ka < kb) {
+                        if (do_drain) {
+                            bf16x8 v[6];
+#pragma unroll
+                            for (int u = 0; u < 6; ++u)
+                                if (ka + u < kb) v[u] = *reinterpret_cast<const bf16x8*>(ro + ((ka + u) * 128 + t2) * 16);
+#pragma unroll
+                            for (int u = 0; u < 6; ++u)
+                                if (ka + u < kb && piece_ok(prev, ka + u)) *reinterpret_cast<bf16x8*>(out_prev + piece_rel(ka + u)) = v[u];
+                        }
+                        if (do_res) {
+#pragma unroll
+                            for (int u = 0; u < 6; ++u)
+                                if (ka + u < kb) {
+                                    const void* g = piece_ok(cur, ka + u) ? (const void*)(res_cur + piece_rel(ka + u)) : (const void*)zero_page;
+                                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rq[u]) : "v"(g) : "memory");
+                                }
+                            rq_ka = ka;
+                            rq_kb = kb;
+                        }
+                    }
+                    if (!(WS_DBG(16))) ws_barrier();                                // end of a group step (lgkmcnt(0): LDS writes done)
+                }
+            }
+            ws_barrier();                                        // E1
+            ws_barrier();                                        // E2
+            prev = cur;
+            have_prev = true;
+            if (!more) break;
+            q += qstride;
+            cur = nxt;
+            out_prev = out_next;
+            res_cur = res_next;
+        }
+#else
         for (;;) {
             const bool more = q + qstride < ntiles;
             WS_TSTAMP(160, wave == 6 && q == (int)blockIdx.x + qstride);
@@ -581,9 +841,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                     int ka, kb, na, nb_;
                     piece_range(c, t, ka, kb);
                     if (ka < kb) {
-#ifndef WS_DIRECT_STORE
                         if (!pre_valid) read_pieces(ka, kb, vcur);       // first pieces of a tile switch: nothing was read ahead
-#endif
                         if (do_drain) {
 #pragma unroll
                             for (int u = 0; u < 2; ++u)      // (a store instruction always has valid lanes: every cout piece occurs in it)
@@ -595,16 +853,19 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                     WS_TSTAMP(165, wave == 6 && c == 0 && t == 0 && q == (int)blockIdx.x + qstride);
                     if (t < 8) piece_range(c, t + 1, na, nb_); else piece_range(c + 1, 0, na, nb_);
                     pre_valid = na < nb_;
-#ifndef WS_DIRECT_STORE
                     if (pre_valid) read_pieces(na, nb_, vnext);
-#endif
                     if (t == 8) {
                         // halo image (and everything older) landed; at the last chunk E1 needs the whole residual tile
                         if (wrap) ws_wait_vm(0);
                         else ws_wait_vm(young);
                     }
                     WS_TSTAMP(153 + (t < 3 ? t : 3), wave == 6 && c == 0 && t < 3 && q == (int)blockIdx.x + qstride);
+#ifdef WS_GROUP3
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the reads ahead
+                    if (t % 3 == 2) { if (!(WS_DBG(16))) ws_barrier(); }            // end of a group step
+#else
                     if (!(WS_DBG(16))) ws_barrier();                                // B_g (its lgkmcnt(0) completes the reads ahead)
+#endif
                     vcur[0] = vnext[0];
                     vcur[1] = vnext[1];
                 }
@@ -621,11 +882,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             out_prev = out_next;
             res_cur = res_next;
         }
+#endif
     }
 
     // ==================================================================== last tile out: all eight waves
     // (every wave has passed the last E2; the two bulk movers alone needed ~3 us for the 64 KB)
-#ifndef WS_DIRECT_STORE
     {
         const int qlast = (int)blockIdx.x + ((ntiles - 1 - (int)blockIdx.x) / qstride) * qstride;
         WsTile lt;
@@ -649,7 +910,6 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         }
         WS_CLOCKSTAMP(174, wave == 0);
     }
-#endif
 }
 
 }  // namespace

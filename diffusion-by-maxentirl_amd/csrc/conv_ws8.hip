@@ -12,6 +12,13 @@
 // an even number (>= 4) of 32-channel chunks.
 #include "conv_common.h"
 #include <stdlib.h>
+#include <type_traits>
+
+// Round 4: the weight stream is register-staged and handed over in groups of three steps (one workgroup barrier per 96 / 48
+// MFMAs).  -DWS_PER_STEP_BARRIER builds the round-2/3 form (LDS-DMA loaders, one barrier per step) for A/B runs.
+#ifndef WS_PER_STEP_BARRIER
+#define WS_GROUP3 1
+#endif
 
 namespace {
 
@@ -154,7 +161,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
                     read_b(u, 1, By);
                     if (u & 1) mfma8(A1, Bx, 0); else mfma8(A0, Bx, 0);
                     W8_INTERLEAVE_2();
+#ifdef WS_GROUP3
+                    if (u % 3 == 2) w8_barrier();       // end of a group of three steps: the next group's weights (at a chunk end: the next halo image) landed
+#else
                     w8_barrier();                       // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
+#endif
                     if (u & 1) read_a(u + 1, A0); else read_a(u + 1, A1);
                     read_b(u + 1, 0, Bx);
                     if (u & 1) mfma8(A1, By, 1); else mfma8(A0, By, 1);
@@ -168,88 +179,99 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
                 // code when there is none (as conv_ws.hip)
                 const bool plain = p.act == DXMI_ACT_NONE;
                 char* const rowb = ro + ((wave * 64 + px) << 7) + 8 * (kg & 1);      // pixel row of block 0: blocks are 2 KiB apart
+                // run-time switches hoisted out of the 16 (cb, nb) bodies (as conv_ws.hip, round 4): straight-line code per combination
+                auto epi = [&](auto RES, auto MASK, auto ACT) {
+                    constexpr bool kRes = decltype(RES)::value, kMask = decltype(MASK)::value, kAct = decltype(ACT)::value;
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    const int co = cb * 16 + 4 * kg;
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb + co), t0 = *reinterpret_cast<const f32x4*>(tb + 64 + wave * 64 + co);
-                    f32x4 bv;
+                    for (int cb = 0; cb < 4; ++cb) {
+                        const int co = cb * 16 + 4 * kg;
+                        const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb + co), t0 = *reinterpret_cast<const f32x4*>(tb + 64 + wave * 64 + co);
+                        f32x4 bv;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[e] = b0[e] + t0[e];
-                    char* const a0 = rowb + (((cb * 2 + (kg >> 1)) ^ (px & 7)) << 4);
-                    bf16x4 r[4];
-                    if (has_res) {
+                        for (int e = 0; e < 4; ++e) bv[e] = b0[e] + t0[e];
+                        char* const a0 = rowb + (((cb * 2 + (kg >> 1)) ^ (px & 7)) << 4);
+                        bf16x4 r[4];
+                        if constexpr (kRes) {
 #pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) r[nb] = *reinterpret_cast<const bf16x4*>(a0 + nb * 2048);
-                    }
+                            for (int nb = 0; nb < 4; ++nb) r[nb] = *reinterpret_cast<const bf16x4*>(a0 + nb * 2048);
+                        }
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb) {
-                        f32x4 v;
+                        for (int nb = 0; nb < 4; ++nb) {
+                            f32x4 v;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[cb][nb][e] + bv[e];
-                        if (has_res) {
-                            if (p.res_is_mask) {          // data gradient through a LeakyReLU: the fetched tile is the mask source
+                            for (int e = 0; e < 4; ++e) v[e] = acc[cb][nb][e] + bv[e];
+                            if constexpr (kRes) {
+                                if constexpr (kMask) {          // data gradient through a LeakyReLU: the fetched tile is the mask source
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] *= ((float)r[nb][e] > 0.f ? 1.f : p.mask_slope);
+                                    for (int e = 0; e < 4; ++e) v[e] *= ((float)r[nb][e] > 0.f ? 1.f : p.mask_slope);
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] += (float)r[nb][e];
+                                }
+                            }
+                            if constexpr (kAct) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = dxmi_act_lin(v[e], slope);
+                            }
+                            bf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+                            if constexpr (GN) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[cb][nb][e] = (float)o[e];     // the value a separate launch would read
                             } else {
+                                *reinterpret_cast<bf16x4*>(a0 + nb * 2048) = o;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += (float)r[nb][e];
+                                for (int e = 0; e < 4; ++e) acc[cb][nb][e] = 0.f;
                             }
                         }
-                        if (!plain) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = dxmi_act_lin(v[e], slope);
-                        }
-                        bf16x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
                         if constexpr (GN) {
+                            // group = couts cb * 16 + 8 (kg >> 1) .. + 7 over the image's 64 pixels: two-pass statistics, fixed order
+                            float s = 0.f;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[cb][nb][e] = (float)o[e];     // the value a separate launch would read
-                        } else {
-                            *reinterpret_cast<bf16x4*>(a0 + nb * 2048) = o;
+                            for (int nb = 0; nb < 4; ++nb) s += (acc[cb][nb][0] + acc[cb][nb][1]) + (acc[cb][nb][2] + acc[cb][nb][3]);
+                            s = dxmi_row16_sum(s);
+                            s += __shfl_xor(s, 16, 64);
+                            const float mean = s * (1.f / 512.f);
+                            float qv = 0.f;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[cb][nb][e] = 0.f;
-                        }
-                    }
-                    if constexpr (GN) {
-                        // group = couts cb * 16 + 8 (kg >> 1) .. + 7 over the image's 64 pixels: two-pass statistics, fixed order
-                        float s = 0.f;
+                            for (int nb = 0; nb < 4; ++nb) {
+                                float d[4];
 #pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) s += (acc[cb][nb][0] + acc[cb][nb][1]) + (acc[cb][nb][2] + acc[cb][nb][3]);
-                        s = dxmi_row16_sum(s);
-                        s += __shfl_xor(s, 16, 64);
-                        const float mean = s * (1.f / 512.f);
-                        float qv = 0.f;
-#pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) {
-                            float d[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) d[e] = acc[cb][nb][e] - mean;
-                            qv += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
-                        }
-                        qv = dxmi_row16_sum(qv);
-                        qv += __shfl_xor(qv, 16, 64);
-                        const float rstd = rsqrtf(qv * (1.f / 512.f) + p.gn_eps);
-                        float ga[4], be[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            ga[e] = gam[cb][e] * rstd;               // same form as groupnorm_silu_kernel
-                            be[e] = bet[cb][e] - mean * ga[e];
-                        }
-#pragma unroll
-                        for (int nb = 0; nb < 4; ++nb) {
-                            bf16x4 y;
+                                for (int e = 0; e < 4; ++e) d[e] = acc[cb][nb][e] - mean;
+                                qv += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+                            }
+                            qv = dxmi_row16_sum(qv);
+                            qv += __shfl_xor(qv, 16, 64);
+                            const float rstd = rsqrtf(qv * (1.f / 512.f) + p.gn_eps);
+                            float ga[4], be[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                float t = acc[cb][nb][e] * ga[e] + be[e];
-                                if (p.gn_flags & 1) t = dxmi_silu_fast(t);
-                                y[e] = (bf16)t;
-                                acc[cb][nb][e] = 0.f;
+                                ga[e] = gam[cb][e] * rstd;               // same form as groupnorm_silu_kernel
+                                be[e] = bet[cb][e] - mean * ga[e];
                             }
-                            *reinterpret_cast<bf16x4*>(a0 + nb * 2048) = y;
+#pragma unroll
+                            for (int nb = 0; nb < 4; ++nb) {
+                                bf16x4 y;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float t = acc[cb][nb][e] * ga[e] + be[e];
+                                    if (p.gn_flags & 1) t = dxmi_silu_fast(t);
+                                    y[e] = (bf16)t;
+                                    acc[cb][nb][e] = 0.f;
+                                }
+                                *reinterpret_cast<bf16x4*>(a0 + nb * 2048) = y;
+                            }
                         }
                     }
-                }
+                };
+                using T_ = std::true_type;
+                using F_ = std::false_type;
+                const bool is_mask = has_res && p.res_is_mask;
+                if (plain && !is_mask) { if (has_res) epi(T_{}, F_{}, F_{}); else epi(F_{}, F_{}, F_{}); }
+                else if (is_mask) { if (plain) epi(T_{}, T_{}, F_{}); else epi(T_{}, T_{}, T_{}); }
+                else if (has_res) epi(T_{}, F_{}, T_{});
+                else epi(F_{}, F_{}, T_{});
             }
             w8_barrier();                               // E2: output tile complete, the bulk movers may drain it
             if (!more) break;
@@ -272,6 +294,63 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
             for (int f = 0; f < 2; ++f)
                 __builtin_amdgcn_global_load_lds(W8_GPTR(src + f * 1024), W8_LPTR(dst + f * 1024), 16, 0, 0);
         };
+#ifdef WS_GROUP3
+        // register-staged weight stream handed over in groups of three steps (see conv_ws.hip, round 4): the ring's six slots are
+        // two groups; group G + 1 is written from registers (ds_write_b128) while the MFMA waves read group G; its fragments were
+        // requested two group steps earlier (two register sets of 6 x 4 registers).  One barrier per three steps.
+        static_assert(W8_RING == 6, "group hand-over needs the six-slot ring");
+        u32x4 fq[2][3][2];
+        auto load_tap = [&](int cot, int g, u32x4 (&f)[2]) {
+            const int c = g / 9, t = g - c * 9;
+            const char* src = wb + ((size_t)(t * p.KST + c * 2 + lw) * p.CB + cot * 2) * 1024;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f[k]) : "v"(src + k * 1024) : "memory");
+        };
+        auto store_tap = [&](int g, const u32x4 (&f)[2]) {
+            char* dst = aring + (g % W8_RING) * W8_A_SLOT + lw * 2048 + lane * 16;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) *reinterpret_cast<u32x4*>(dst + k * 1024) = f[k];
+        };
+        const int NG = S / 3;                           // groups per tile (even)
+        auto load_group = [&](int G, int cot_cur, int cot_nxt, u32x4 (&f)[3][2]) {
+            const bool nx = G >= NG;
+            const int g0 = (nx ? G - NG : G) * 3, cot = nx ? cot_nxt : cot_cur;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) load_tap(cot, g0 + j, f[j]);
+        };
+        auto store_group = [&](int G, const u32x4 (&f)[3][2]) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) store_tap((G & 1) * 3 + j, f[j]);
+        };
+        load_group(0, cur.cot, cur.cot, fq[0]);
+        load_group(1, cur.cot, cur.cot, fq[1]);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        store_group(0, fq[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        load_group(2, cur.cot, cur.cot, fq[0]);
+        w8_barrier();                                       // P0
+        for (;;) {
+            const bool more = q + qstride < ntiles;
+            W8Tile nxt = cur;
+            if (more) tile_of(q + qstride, nxt);
+            for (int G0 = 0; G0 < NG; G0 += 2) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int G = G0 + j;
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // group G + 1 landed (group G + 2's loads stay in flight)
+                    store_group(G + 1, fq[(j + 1) & 1]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    load_group(G + 3, cur.cot, more ? nxt.cot : cur.cot, fq[(j + 1) & 1]);
+                    w8_barrier();                                           // end of group step G
+                }
+            }
+            w8_barrier();                                        // E1
+            w8_barrier();                                        // E2
+            if (!more) break;
+            q += qstride;
+            cur = nxt;
+        }
+#else
 #pragma unroll 1
         for (int g = 0; g < W8_RING - 1; ++g) issue_tap(cur.cot, g);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (W8_RING - 2)) : "memory");    // tap 0 landed (RING - 2 younger taps may be outstanding)
@@ -296,6 +375,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
             q += qstride;
             cur = nxt;
         }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
@@ -445,7 +525,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
                         if (wrap) w8_wait_vm(0);
                         else w8_wait_vm(young);
                     }
+#ifdef WS_GROUP3
+                    if (t % 3 == 2) w8_barrier();                // end of a group step
+#else
                     w8_barrier();                                // B_g
+#endif
                 }
             }
             w8_barrier();                                        // E1
