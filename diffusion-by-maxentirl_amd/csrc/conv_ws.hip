@@ -414,6 +414,13 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             for (int j = 0; j < 3; ++j) store_tap((G & 1) * 3 + j, f[j]);
         };
         if (WS_DBG(1)) {}                               // (timing-only ablation of the weight stream: not available in this build)
+        // residual pieces (see the bulk movers: piece L = k*128 + t2 with t2 = lw*64 + lane)
+        const int t2l = lw * 64 + lane, prl = t2l >> 4;
+        const int lpar_l0 = prl * p.Cout + (((t2l & 15) ^ prl) * 8), lpar_l1 = prl * p.Cout + (((t2l & 15) ^ (prl | 8)) * 8);
+        const int c8e_l = (t2l & 15) ^ prl, c8o_l = (t2l & 15) ^ (prl | 8);
+        const int kpc_l = (32 + nchunks - 2) / (nchunks - 1);
+        const char* const zero_page_l = reinterpret_cast<const char*>(p.mask_src);
+        bool first_tile_l = true;
         load_group(0, cur.cot, cur.cot, fq[0]);
         load_group(1, cur.cot, cur.cot, fq[1]);
         asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -440,6 +447,15 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                     __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_b), WS_LPTR(tb + 192), 4, 0, 0);
                 }
             }
+            // The residual tile of THIS tile (tile switch): the bulk movers drain piece k of the previous tile's output in the
+            // group step their schedule gives it; its residual replacement is fetched here one group step later (the group barrier
+            // orders the two) — the loaders idle for two thirds of a group step, the bulk movers were 3-4 k cycles per chunk short
+            // (stamp build: 10 k cycles of barrier waits per 128-channel tile).  The wait below leaves only the 12 youngest
+            // operations in flight, so these DMAs (older than the next group step's loads) are complete two group steps later:
+            // before E1, because the last chunk of a tile carries no pieces.
+            const bf16* const res_t = p.residual + ((((size_t)cur.n0 * p.OH + cur.oy0) * p.OW + cur.ox0) * p.Cout + cur.cot * 128);
+            const bool res_here = !first_tile_l && p.residual != nullptr && !(WS_DBG(8));
+            first_tile_l = false;
             first_tile = false;
             for (int G0 = 0; G0 < NG; G0 += 2) {
 #pragma unroll
@@ -450,6 +466,21 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                     store_group(G + 1, fq[(j + 1) & 1]);
                     // the barrier's lgkmcnt(0) must precede the refill: a ds_write reads its data registers when it executes
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (res_here && G > 0) {
+                        const int cg = (G - 1) / 3, g3 = (G - 1) - cg * 3;     // the group step whose pieces were drained
+                        if (cg + 1 < nchunks) {
+                            const int k0 = cg * kpc_l < 32 ? cg * kpc_l : 32, k1 = k0 + kpc_l < 32 ? k0 + kpc_l : 32;
+                            const int i0 = g3 < 2 ? 3 * g3 : 6, i1 = g3 < 2 ? 3 * g3 + 3 : 12;      // steps 3 g3 .. 3 g3 + 2 of piece_range()
+                            const int ka = k0 + i0 < k1 ? k0 + i0 : k1, kb = k0 + i1 < k1 ? k0 + i1 : k1;
+#pragma unroll 1
+                            for (int k = ka; k < kb; ++k) {
+                                const int rel = ((k >> (TWl - 3)) * p.OW + (k & (TW / 8 - 1)) * 8) * p.Cout + ((k & 1) ? lpar_l1 : lpar_l0);
+                                const bool ok = cur.cot * 128 + ((k & 1) ? c8o_l : c8e_l) * 8 < p.Cout;
+                                const void* g = ok ? (const void*)(res_t + rel) : (const void*)zero_page_l;
+                                __builtin_amdgcn_global_load_lds(WS_GPTR(g), WS_LPTR(ro + (k * 128 + lw * 64) * 16), 16, 0, 0);
+                            }
+                        }
+                    }
                     load_group(G + 3, cur.cot, more ? nxt.cot : cur.cot, fq[(j + 1) & 1]);
                     if (!(WS_DBG(16))) ws_barrier();                        // end of group step G
                 }
@@ -665,7 +696,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_b), WS_LPTR(tb + 192), 4, 0, 0);
             }
         };
+#ifdef WS_GROUP3
+        bool do_res = p.residual != nullptr && !(WS_DBG(8));      // prologue only: from the second tile on the loaders fetch the residual tile
+#else
         const bool do_res = p.residual != nullptr && !(WS_DBG(8));
+#endif
         auto fetch_residual_at = [&](const bf16* rb, const WsTile& t, int k0, int k1) {      // rb = residual + tile_base(t)
             if (!do_res) return;
 #pragma unroll 1
@@ -691,6 +726,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         if (do_res) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ws_barrier();                                           // P0
+#ifdef WS_GROUP3
+        do_res = false;
+#endif
         bool have_prev = false;
         WsTile prev = cur;
         // Neither the halo image of the next chunk (11 DMAs per wave) nor the tile switch (64 KB out + 64 KB residual in per
