@@ -420,7 +420,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         const int c8e_l = (t2l & 15) ^ prl, c8o_l = (t2l & 15) ^ (prl | 8);
         const int kpc_l = (32 + nchunks - 2) / (nchunks - 1);
         const char* const zero_page_l = reinterpret_cast<const char*>(p.mask_src);
-        bool first_tile_l = true;
+        bool first_tile_l = true, first_group0 = true;
         load_group(0, cur.cot, cur.cot, fq[0]);
         load_group(1, cur.cot, cur.cot, fq[1]);
         asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -461,11 +461,14 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int G = G0 + j;
-                    // group step G (the MFMA waves read group G): group G + 1 sits in set (j + 1) & 1 since group step G - 1
-                    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // ... and has landed (group G + 2's loads stay in flight)
-                    store_group(G + 1, fq[(j + 1) & 1]);
-                    // the barrier's lgkmcnt(0) must precede the refill: a ds_write reads its data registers when it executes
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // group step G (the MFMA waves read group G): group G + 1 sits in set (j + 1) & 1 since group step G - 1.
+                    // (Group step 0 of every tile but the first was done ahead, in front of E1 of the previous tile: see below.)
+                    if (G > 0 || first_group0) {
+                        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // ... and has landed (group G + 2's loads stay in flight)
+                        store_group(G + 1, fq[(j + 1) & 1]);
+                        // the barrier's lgkmcnt(0) must precede the refill: a ds_write reads its data registers when it executes
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    }
                     if (res_here && G > 0) {
                         const int cg = (G - 1) / 3, g3 = (G - 1) - cg * 3;     // the group step whose pieces were drained
                         if (cg + 1 < nchunks) {
@@ -481,12 +484,24 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                             }
                         }
                     }
-                    load_group(G + 3, cur.cot, more ? nxt.cot : cur.cot, fq[(j + 1) & 1]);
+                    if (G > 0 || first_group0) load_group(G + 3, cur.cot, more ? nxt.cot : cur.cot, fq[(j + 1) & 1]);
+                    WS_TSTAMP(151, wave == 4 && G == 0 && q == (int)blockIdx.x + qstride);
                     if (!(WS_DBG(16))) ws_barrier();                        // end of group step G
                 }
             }
+            first_group0 = false;
+            if (more) {
+                // group step 0 of the NEXT tile, ahead of time: its ring slots (parity 1) were last read in this tile's last
+                // group step, and after E2 every wave starts at once — the tile-start bookkeeping plus this block made the
+                // loaders 1.1 k cycles late at the next tile's first group barrier (stamp build: 2.7 k cycles after E2)
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                store_group(1, fq[1]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                load_group(3, nxt.cot, nxt.cot, fq[1]);
+            }
             ws_barrier();                                        // E1
             ws_barrier();                                        // E2
+            WS_TSTAMP(150, wave == 4 && q == (int)blockIdx.x);
             if (!more) break;
             q += qstride;
             cur = nxt;
@@ -614,6 +629,181 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
         }
 #endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if defined(WS_GROUP3) && !defined(WS_SHARED_BULK)
+    } else if (wave == 6) {
+        // ================================================================ halo mover (wave 6): loads only
+        // Round 4: the two bulk movers no longer share every job.  vmcnt retires in order, so a wave that stores (the drain) and
+        // loads (the halo image) waits, at the chunk end, for the acknowledgement of stores it issued long before the halo
+        // blocks it actually needs (stamp build: 300-850 cycles late at every group barrier of a tile switch).  This wave issues
+        // nothing but the next chunk's halo image (22 DMAs per chunk, three per step) and waits with vmcnt(0).
+        constexpr int HBA = WS_HALO_BLOCKS;
+        const char* const zero_page = reinterpret_cast<const char*>(p.mask_src);
+        int hrel0[HBA], hrel1[HBA];
+        unsigned m_in = 0, m_top = 0, m_bot = 0, m_left = 0, m_right = 0;
+#pragma unroll
+        for (int k = 0; k < HBA; ++k) {
+            const int hp = k * 16 + (lane >> 2);
+            const int hy = hp / HP, hx = hp - hy * HP;
+            const int rel = ((hy - 1) >> ups) * p.IW + ((hx - 1) >> ups);
+            const int j8 = ((lane & 3) ^ (2 * ((hx >> 2) & 1))) * 8;
+            hrel0[k] = (rel * p.C0 + j8) * 2;
+            hrel1[k] = (rel * p.C1 + j8) * 2;
+            m_in |= (unsigned)(hy < HH && hx < TW + 2) << k;
+            m_top |= (unsigned)(hy == 0) << k;
+            m_bot |= (unsigned)(hy == HH - 1) << k;
+            m_left |= (unsigned)(hx == 0) << k;
+            m_right |= (unsigned)(hx == TW + 1) << k;
+        }
+        unsigned hmask = 0;
+        int hbase0 = 0, hbase1 = 0;
+        auto halo_plan = [&](const WsTile& t) {
+            hmask = m_in;
+            if (t.oy0 == 0) hmask &= ~m_top;
+            if (t.oy0 + TH == p.OH) hmask &= ~m_bot;
+            if (t.ox0 == 0) hmask &= ~m_left;
+            if (t.ox0 + TW == p.OW) hmask &= ~m_right;
+            const int pix = (t.n0 * p.IH + (t.oy0 >> ups)) * p.IW + (t.ox0 >> ups);
+            hbase0 = pix * p.C0 * 2;
+            hbase1 = pix * p.C1 * 2;
+        };
+        auto halo_issue = [&](int c, char* buf, int ka, int kb) {     // blocks ka .. kb-1 (compile-time range)
+            if (WS_DBG(2)) return;
+            const int cbase = c * 32;
+            const bool first = cbase < p.C0;
+            const char* base = reinterpret_cast<const char*>(first ? p.in0 : p.in1) + (first ? cbase : cbase - p.C0) * 2 + (first ? hbase0 : hbase1);
+#pragma unroll
+            for (int k = 0; k < HBA; ++k) {
+                if (k < ka || k >= kb) continue;
+                const char* g = (hmask >> k) & 1 ? base + (first ? hrel0[k] : hrel1[k]) : zero_page;
+                __builtin_amdgcn_global_load_lds(WS_GPTR(g), WS_LPTR(buf + k * 1024), 16, 0, 0);
+            }
+        };
+        WsTile cur;
+        tile_of(q, cur);
+        if (!p.bias) { tb[lane] = 0.f; tb[64 + lane] = 0.f; }            // table rows that no DMA fills stay zero
+        if (!p.addvec) { tb[128 + lane] = 0.f; tb[192 + lane] = 0.f; }
+        halo_plan(cur);
+        halo_issue(0, halo0, 0, HBA);
+        if (!(WS_DBG(8))) {                                              // first tile's bias / temb table (later ones: loader 0)
+            const int co_a = cur.cot * 128 + lane, co_b = co_a + 64 < p.Cout ? co_a + 64 : p.Cout - 1;
+            if (p.bias) {
+                __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_a), WS_LPTR(tb), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_b), WS_LPTR(tb + 64), 4, 0, 0);
+            }
+            if (p.addvec) {
+                const float* av = p.addvec + (size_t)cur.n0 * p.addvec_ld;
+                __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_a), WS_LPTR(tb + 128), 4, 0, 0);
+                __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_b), WS_LPTR(tb + 192), 4, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ws_barrier();                                           // P0
+        WsTile nxt = cur;
+        for (;;) {
+            const bool more = q + qstride < ntiles;
+            for (int c = 0; c < nchunks; ++c) {
+                const bool wrap = c + 1 == nchunks;
+                if (wrap && more) {
+                    tile_of(q + qstride, nxt);
+                    halo_plan(nxt);
+                }
+                const bool do_halo = !wrap || more;
+                char* const hbuf = halo0 + ((c + 1) & 1) * WS_HALO;
+                const int hc = wrap ? 0 : c + 1;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (t < 8 && do_halo) halo_issue(hc, hbuf, 3 * t, 3 * t + 3 < HBA ? 3 * t + 3 : HBA);
+                    if (t == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the halo image landed
+                    if (t % 3 == 2) { if (!(WS_DBG(16))) ws_barrier(); }            // end of a group step
+                }
+            }
+            ws_barrier();                                        // E1
+            ws_barrier();                                        // E2
+            if (!more) break;
+            q += qstride;
+            cur = nxt;
+        }
+    } else if (wave == 7) {
+        // ================================================================ drain mover (wave 7): LDS -> global stores only
+        // All 32 pieces (2 KiB each: both 64-lane halves) of the previous tile's output, on the schedule of piece_range(); the
+        // loaders refill a piece with the residual one group step later.  No load, so no wait on a store's acknowledgement
+        // anywhere but in front of E1 of the first tile (whose residual tile this wave fetched in the prologue).
+        const char* const zero_page = reinterpret_cast<const char*>(p.mask_src);
+        const int prA = lane >> 4, prB = 4 + (lane >> 4), lc = lane & 15;
+        const int lparA[2] = {prA * p.Cout + ((lc ^ prA) * 8), prA * p.Cout + ((lc ^ (prA | 8)) * 8)};
+        const int lparB[2] = {prB * p.Cout + ((lc ^ prB) * 8), prB * p.Cout + ((lc ^ (prB | 8)) * 8)};
+        const int c8A[2] = {lc ^ prA, lc ^ (prA | 8)}, c8B[2] = {lc ^ prB, lc ^ (prB | 8)};
+        auto tile_base = [&](const WsTile& t) -> size_t {
+            return (((size_t)t.n0 * p.OH + t.oy0) * p.OW + t.ox0) * p.Cout + t.cot * 128;
+        };
+        auto piece_u = [&](int k) -> int { return ((k >> (TWl - 3)) * p.OW + (k & (TW / 8 - 1)) * 8) * p.Cout; };
+        WsTile cur;
+        tile_of(q, cur);
+        if (p.residual != nullptr && !(WS_DBG(8))) {              // first tile's residual tile (later ones: the loaders)
+            const bf16* rb = p.residual + tile_base(cur);
+#pragma unroll 1
+            for (int k = 0; k < 32; ++k) {
+                const int u = piece_u(k);
+                const void* ga = cur.cot * 128 + c8A[k & 1] * 8 < p.Cout ? (const void*)(rb + u + lparA[k & 1]) : (const void*)zero_page;
+                const void* gb = cur.cot * 128 + c8B[k & 1] * 8 < p.Cout ? (const void*)(rb + u + lparB[k & 1]) : (const void*)zero_page;
+                __builtin_amdgcn_global_load_lds(WS_GPTR(ga), WS_LPTR(ro + (k * 128) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(WS_GPTR(gb), WS_LPTR(ro + (k * 128 + 64) * 16), 16, 0, 0);
+            }
+        }
+        ws_barrier();                                           // P0
+        bool have_prev = false;
+        WsTile prev = cur;
+        const int kpc = (32 + nchunks - 2) / (nchunks - 1);
+        auto piece_range = [&](int c, int t, int& ka, int& kb) {
+            ka = kb = 32;
+            if (!have_prev || c + 1 >= nchunks) return;
+            const int k0 = c * kpc < 32 ? c * kpc : 32, k1 = k0 + kpc < 32 ? k0 + kpc : 32;
+            const int i0 = t < 6 ? t : 6 + 2 * (t - 6), i1 = t < 6 ? t + 1 : i0 + 2;
+            ka = k0 + i0 < k1 ? k0 + i0 : k1;
+            kb = k0 + i1 < k1 ? k0 + i1 : k1;
+        };
+        const bool do_drain = !(WS_DBG(4));
+        bf16* out_prev = reinterpret_cast<bf16*>(p.out);
+        for (;;) {
+            const bool more = q + qstride < ntiles;
+            WsTile nxt = cur;
+            if (more) tile_of(q + qstride, nxt);
+            for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    int ka, kb;
+                    piece_range(c, t, ka, kb);
+                    if (ka < kb && do_drain) {
+                        bf16x8 va[2], vb[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            if (ka + u < kb) {
+                                va[u] = *reinterpret_cast<const bf16x8*>(ro + ((ka + u) * 128 + lane) * 16);
+                                vb[u] = *reinterpret_cast<const bf16x8*>(ro + ((ka + u) * 128 + 64 + lane) * 16);
+                            }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+                            if (ka + u < kb) {
+                                const int k = ka + u, pu = piece_u(k);
+                                if (prev.cot * 128 + c8A[k & 1] * 8 < p.Cout) *reinterpret_cast<bf16x8*>(out_prev + pu + lparA[k & 1]) = va[u];
+                                if (prev.cot * 128 + c8B[k & 1] * 8 < p.Cout) *reinterpret_cast<bf16x8*>(out_prev + pu + lparB[k & 1]) = vb[u];
+                            }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the piece is out of LDS before the group barrier
+                    if (t % 3 == 2) { if (!(WS_DBG(16))) ws_barrier(); }            // end of a group step
+                }
+            }
+            if (!have_prev) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first tile: the residual tile of the prologue landed
+            ws_barrier();                                        // E1
+            ws_barrier();                                        // E2
+            out_prev = reinterpret_cast<bf16*>(p.out) + tile_base(cur);
+            prev = cur;
+            have_prev = true;
+            if (!more) break;
+            q += qstride;
+            cur = nxt;
+        }
+#endif
     } else {
     // ==================================================================== bulk movers (waves 6, 7)
         const int bw = wave - 6;

@@ -322,6 +322,19 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) store_tap((G & 1) * 3 + j, f[j]);
         };
+        // residual pieces of a tile switch (see the bulk movers: piece L = k*128 + t2, t2 = lw*64 + lane): fetched here one
+        // group step after the bulk movers drained the piece (conv_ws.hip, round 4)
+        const int t2l = lw * 64 + lane;
+        const int kpc_l = (16 + nchunks - 2) / (nchunks - 1), pps_l = (kpc_l + 7) >> 3;
+        const char* const zero_page_l = reinterpret_cast<const char*>(p.mask_src);
+        auto piece_off_l = [&](const W8Tile& t, int k) -> long {
+            const int lp = k * 16 + (t2l >> 3);
+            const int c8 = (t2l & 7) ^ (lp & 7);
+            const int n = t.n0 + (lp >> 6);
+            if (n >= p.N) return -1;
+            return (long)((((size_t)n * 8 + ((lp >> 3) & 7)) * 8 + (lp & 7)) * p.Cout + t.cot * 64 + c8 * 8);
+        };
+        bool first_tile_l = true;
         load_group(0, cur.cot, cur.cot, fq[0]);
         load_group(1, cur.cot, cur.cot, fq[1]);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -333,6 +346,8 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
             const bool more = q + qstride < ntiles;
             W8Tile nxt = cur;
             if (more) tile_of(q + qstride, nxt);
+            const bool res_here = !first_tile_l && p.residual != nullptr;
+            first_tile_l = false;
             for (int G0 = 0; G0 < NG; G0 += 2) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -340,6 +355,20 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
                     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");        // group G + 1 landed (group G + 2's loads stay in flight)
                     store_group(G + 1, fq[(j + 1) & 1]);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (res_here && G > 0) {
+                        const int cg = (G - 1) / 3, g3 = (G - 1) - cg * 3;     // the group step whose pieces were drained
+                        if (cg + 1 < nchunks) {
+                            const int k0 = cg * kpc_l < 16 ? cg * kpc_l : 16, k1 = k0 + kpc_l < 16 ? k0 + kpc_l : 16;
+                            const int s0 = 3 * g3, s1 = g3 < 2 ? 3 * g3 + 3 : 8;       // steps of the group that carry pieces (t < 8)
+                            const int ka = k0 + s0 * pps_l < k1 ? k0 + s0 * pps_l : k1, kb = k0 + s1 * pps_l < k1 ? k0 + s1 * pps_l : k1;
+#pragma unroll 1
+                            for (int k = ka; k < kb; ++k) {
+                                const long o = piece_off_l(cur, k);
+                                const void* g = o >= 0 ? (const void*)(p.residual + o) : (const void*)zero_page_l;
+                                __builtin_amdgcn_global_load_lds(W8_GPTR(g), W8_LPTR(ro + (k * 128 + lw * 64) * 16), 16, 0, 0);
+                            }
+                        }
+                    }
                     load_group(G + 3, cur.cot, more ? nxt.cot : cur.cot, fq[(j + 1) & 1]);
                     w8_barrier();                                           // end of group step G
                 }
@@ -439,7 +468,11 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
                 }
             }
         };
+#ifdef WS_GROUP3
+        bool do_res = p.residual != nullptr;       // prologue only: from the second tile on the loaders fetch the residual tile
+#else
         const bool do_res = p.residual != nullptr;
+#endif
         auto fetch_residual = [&](const W8Tile& t, int k0, int k1) {
             if (!do_res) return;
 #pragma unroll 1
@@ -489,6 +522,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
         if (do_res) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         w8_barrier();                                           // P0
+#ifdef WS_GROUP3
+        do_res = false;
+#endif
         bool have_prev = false;
         W8Tile prev = cur;
         const int kpc = (16 + nchunks - 2) / (nchunks - 1);      // tile-switch pieces per chunk (first nchunks-1 chunks)
