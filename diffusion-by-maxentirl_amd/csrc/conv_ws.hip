@@ -9,17 +9,25 @@
 //              weight fragments from a 6-slot ring, input pixels from a double-buffered halo image — at per-lane bases plus
 //              compile-time offsets (no address arithmetic in the loop), with a half-step software pipeline: the reads of
 //              the next 16 MFMAs fly under the current 16.  No vector-memory instruction is ever issued, so nothing a mover
-//              does can stall them; the only waits are lgkmcnt for LDS reads and one barrier per (chunk, tap) step.
-//   waves 4,5  weight loaders: stream the pre-packed A fragments of step g+5 into the ring by LDS DMA
-//              (`global_load_lds_dwordx4`: one 1-KiB fragment per instruction, no staging registers), wait with a counted
-//              vmcnt that leaves four steps in flight.
-//   waves 6,7  bulk movers: the next 32-channel chunk's halo image (DMA, XOR-swizzled 16-byte slots instead of padding: a
-//              DMA writes 1 KiB linearly), the residual tile and the bias / temb table of the CURRENT tile (DMA into the
-//              output tile's own LDS buffer), and the drain of the PREVIOUS tile's output (LDS -> 256-byte NHWC rows) —
-//              issued a few instructions per step, never in bursts (a DMA costs its wave ~100 cycles of issue and a mover
-//              that is late at a step barrier stalls the MFMA waves), every wait counting exactly the younger operations.
+//              does can stall them; the only waits are lgkmcnt for LDS reads and ONE barrier per GROUP of three (chunk, tap)
+//              steps (round 4: a barrier per step cost 11-15 % by itself).
+//   waves 4,5  weight loaders, register-staged (round 4): the ring is two groups of three slots; the fragments of group G + 1
+//              are written from registers (ds_write_b128) while the MFMA waves read group G, after having been requested two
+//              group steps earlier by plain global_load_dwordx4 (a `global_load_lds` costs its wave ~2x the issue time and
+//              takes twice the issue slots from the MFMA wave on its SIMD: tools/stage_probe.hip).  They also fetch the bias /
+//              temb table and, from the second tile on, the RESIDUAL tile (LDS DMA, one group step after the drain wave
+//              emptied the piece), and do the next tile's first group step in front of E1.
+//   wave 6     halo mover: the next 32-channel chunk's halo image (DMA, XOR-swizzled 16-byte slots instead of padding: a
+//              DMA writes 1 KiB linearly), three blocks per step.  Loads only, so its vmcnt(0) at a chunk end waits for
+//              nothing but the image.
+//   wave 7     drain mover: the PREVIOUS tile's output LDS -> 256-byte NHWC rows, a piece or two per step.  Stores only: no
+//              wait on a store's acknowledgement anywhere (round 3's two bulk movers shared both jobs and, vmcnt retiring in
+//              order, waited at every chunk end for stores older than the halo blocks they needed).
 // Tile end: the MFMA waves add bias + temb + residual to the accumulators in the accumulator layout (LDS reads of their
-// own cout columns), apply the activation, round ONCE to bf16 and write the output tile in place in LDS; two barriers.
+// own cout columns), apply the activation, round ONCE to bf16 and write the output tile in place in LDS; two barriers.  The
+// epilogue is specialised on its launch-uniform switches (straight-line code per combination: 9.4 k -> 3.3 k cycles per tile).
+// What was measured on the way, including what did NOT work (A fragments fetched by the MFMA waves, output stored from the
+// accumulator layout, register-staged halo / residual with one group step or one chunk of lead): DESIGN.md 5.4.
 //
 // Scope: 3x3 / stride 1 / pad 1 (optionally behind a nearest x2 upsample), NHWC bf16 in (virtual concat) and out,
 // Cout % 64 == 0 (half-empty last cout tile masked), an even number (>= 4) of 32-channel chunks, maps >= 16x16 (one image per 256-pixel tile); 8x8 maps: conv_ws8.hip.
@@ -28,18 +36,6 @@
 #include <stdlib.h>
 #include <type_traits>
 
-// Round 4: the weight stream is register-staged and handed over in groups of three steps (one workgroup barrier per 96 / 48
-// MFMAs).  -DWS_PER_STEP_BARRIER builds the round-2/3 form (LDS-DMA loaders, one barrier per step) for A/B runs.
-#ifndef WS_PER_STEP_BARRIER
-#define WS_GROUP3 1
-#endif
-
-// halo blocks per bulk mover and step / number of steps that issue them (HB2 = 11 blocks per mover and chunk): 2 x 6 by default;
-// -DWS_HALO_PER=3 -DWS_HALO_STEPS=4 or 4 x 3 issue them earlier in the chunk (A/B builds through DXMI_LIB)
-#ifndef WS_HALO_PER
-#define WS_HALO_PER 2
-#define WS_HALO_STEPS 6
-#endif
 
 #ifdef DXMI_CONV_STAMPS
 // timing-only build (make STAMPS=1): cycles MFMA wave 0 of every workgroup spends in each step barrier (tools/ws_stamps.py)
@@ -241,13 +237,9 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                     read_b(u, 1, By);
                     if (u & 1) mfma16(A1, Bx, 0); else mfma16(A0, Bx, 0);
                     WS_INTERLEAVE_4();
-#ifdef WS_GROUP3
                     // groups of three steps: the loaders hand over three ring slots at a time (register-staged), so the MFMA
                     // stream is interrupted by a barrier every 96 MFMAs instead of every 32
                     if (u % 3 == 2) { if (!(WS_DBG(16))) WS_STAMPED_BARRIER(stamp_i + c * 9 + u); }
-#else
-                    if (!(WS_DBG(16))) WS_STAMPED_BARRIER(stamp_i + c * 9 + u);   // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
-#endif
                     if (u & 1) read_a(u + 1, A0); else read_a(u + 1, A1);
                     read_b(u + 1, 0, Bx);
                     if (u & 1) mfma16(A1, By, 1); else mfma16(A0, By, 1);
@@ -376,7 +368,6 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
                 __builtin_amdgcn_global_load_lds(WS_GPTR(src + (size_t)cb * 1024), WS_LPTR(dst + f * 1024), 16, 0, 0);
             }
         };
-#ifdef WS_GROUP3
         // Round 4: register-staged weight stream, handed over in GROUPS of three steps.  The ring's six slots are two groups: the
         // MFMA waves read group G (slots of parity G & 1) while this wave writes group G + 1 into the other three slots (last
         // read in group G - 1: complete at the barrier that ended it) from registers, with ds_write_b128.  The fragments were
@@ -506,130 +497,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             q += qstride;
             cur = nxt;
         }
-#elif defined(WS_LOADER_STAGE)
-        // Round 4: the weight fragments go through REGISTERS instead of LDS-DMA.  A `global_load_lds` costs its wave ~190 cycles
-        // of issue whatever it keeps in flight (tools/dma_probe.hip, tools/stage_probe.hip): four per step and loader is more
-        // than a 512-cycle step.  A loader wave has nothing else to do and 256 registers: fragments of step g + WS_LQ are
-        // requested with plain global_load_dwordx4 (16 registers per step in flight), step g + 1's are written into its ring
-        // slot with ds_write_b128 once they have landed (vmcnt retires in order: the wait leaves the WS_LQ - 1 younger steps in
-        // flight).  Ring slot (g + 1) % 6 was last read in step g - 5.
-        constexpr int WS_LQ = 6;                        // steps of fragments in flight; S % 6 == 0 (host-checked)
-        u32x4 fq[WS_LQ][4];
-        auto load_tap = [&](int cot, int g, u32x4 (&f)[4]) {
-            const int c = g / 9, t = g - c * 9;
-            const char* src = wb + ((size_t)(t * p.KST + c * 2 + lw) * p.CB) * 1024;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int cb = cot * 4 + k < p.CB ? cot * 4 + k : p.CB - 1;
-                // inline asm: hipcc's own wait-count pass loses the count of loads in flight across the loop's back edge and
-                // drains the queue (s_waitcnt vmcnt(0)) before the first ds_write of every trip; the waits below are exact
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f[k]) : "v"(src + (size_t)cb * 1024) : "memory");
-            }
-        };
-        auto store_tap = [&](int g, const u32x4 (&f)[4]) {
-            char* dst = aring + (g % WS_RING) * WS_A_SLOT + lw * 4096 + lane * 16;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(dst + k * 1024) = f[k];
-        };
-        // prologue: steps 0 .. WS_LQ - 1 requested; step 0 written before P0
-#pragma unroll
-        for (int j = 0; j < WS_LQ; ++j) load_tap(cur.cot, j, fq[j]);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (WS_LQ - 1)) : "memory");
-        store_tap(0, fq[0]);
-        ws_barrier();                                       // P0
-        bool first_tile = true;
-        for (;;) {
-            const bool more = q + qstride < ntiles;
-            WsTile nxt = cur;
-            if (more) tile_of(q + qstride, nxt);
-            if (!first_tile && lw == 0 && !(WS_DBG(8))) {
-                // bias / temb table of this tile (see the DMA path below); four 256-byte DMAs, older than every load of this tile
-                const int co_a = cur.cot * 128 + lane, co_b = co_a + 64 < p.Cout ? co_a + 64 : p.Cout - 1;
-                if (p.bias) {
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_a), WS_LPTR(tb), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_b), WS_LPTR(tb + 64), 4, 0, 0);
-                }
-                if (p.addvec) {
-                    const float* av = p.addvec + (size_t)cur.n0 * p.addvec_ld;
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_a), WS_LPTR(tb + 128), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_b), WS_LPTR(tb + 192), 4, 0, 0);
-                }
-            }
-            first_tile = false;
-            for (int g0 = 0; g0 < S; g0 += WS_LQ) {
-#pragma unroll
-                for (int j = 0; j < WS_LQ; ++j) {
-                    const int g = g0 + j;
-                    // set j held step g (written to the ring in step g - 1, or by the prologue): refill it with step g + WS_LQ;
-                    // past the last tile the same addresses are read again (results unused: keeps the wait counts uniform)
-                    const int gn = g + WS_LQ;
-                    if (gn < S) load_tap(cur.cot, gn, fq[j]);
-                    else load_tap(nxt.cot, gn - S, fq[j]);
-                    // step g + 1's fragments: the WS_LQ - 1 younger steps stay in flight (the table DMAs of a tile start are
-                    // younger than its first steps' loads: the wait then only waits for a little more)
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (WS_LQ - 1)) : "memory");
-                    store_tap(g + 1, fq[(j + 1) % WS_LQ]);
-                    if (!(WS_DBG(16))) ws_barrier();                                // B_g (lgkmcnt(0): the writes are in LDS)
-                }
-            }
-            ws_barrier();                                        // E1
-            ws_barrier();                                        // E2
-            if (!more) break;
-            q += qstride;
-            cur = nxt;
-        }
-#else
-#pragma unroll 1
-        for (int g = 0; g < WS_RING - 1; ++g) issue_tap(cur.cot, g);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // tap 0 landed (4 younger taps may be outstanding)
-        ws_barrier();                                       // P0
-        bool first_tile = true;
-        for (;;) {
-            const bool more = q + qstride < ntiles;
-            WsTile nxt = cur;
-            if (more) tile_of(q + qstride, nxt);
-            if (!first_tile && lw == 0 && !(WS_DBG(8))) {
-                // bias / temb table of this tile (the first tile's is fetched by the bulk movers' prologue): the loaders have slack
-                // at a tile start, the bulk movers do not.  4-byte DMA, 256 B per instruction; issued after E2 (the previous
-                // tile's epilogue is done with the table), complete well before E1: a loader's vmcnt(16) waits leave only the 16
-                // youngest operations in flight and it issues four per step (being younger than the taps in flight, the table
-                // only makes those waits wait for a little more).
-                // (couts past Cout in a half-empty last tile: clamped to the last valid one, results unused)
-                const int co_a = cur.cot * 128 + lane, co_b = co_a + 64 < p.Cout ? co_a + 64 : p.Cout - 1;
-                if (p.bias) {
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_a), WS_LPTR(tb), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_b), WS_LPTR(tb + 64), 4, 0, 0);
-                }
-                if (p.addvec) {
-                    const float* av = p.addvec + (size_t)cur.n0 * p.addvec_ld;
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_a), WS_LPTR(tb + 128), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_b), WS_LPTR(tb + 192), 4, 0, 0);
-                }
-            }
-            first_tile = false;
-            for (int g = 0; g < S; ++g) {
-                const int g3 = g + WS_RING - 1;
-                bool issued = true;
-                if (g3 < S) issue_tap(cur.cot, g3);
-                else if (more) issue_tap(nxt.cot, g3 - S);      // ring slot (g3 - S) % RING == g3 % RING: S % RING == 0 (host-checked)
-                else issued = false;
-                // at most taps g+2 .. g+5 (16 DMAs) outstanding -> tap g+1 landed; without a new issue (last steps of the last
-                // tile) the count of younger DMAs shrinks, so everything is awaited
-                if (issued) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                WS_TSTAMP(151, wave == 4 && g == 0 && q == (int)blockIdx.x + qstride);
-                if (!(WS_DBG(16))) ws_barrier();                                    // B_g
-            }
-            ws_barrier();                                        // E1
-            ws_barrier();                                        // E2
-            WS_TSTAMP(150, wave == 4 && q == (int)blockIdx.x);
-            if (!more) break;
-            q += qstride;
-            cur = nxt;
-        }
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if defined(WS_GROUP3) && !defined(WS_SHARED_BULK)
     } else if (wave == 6) {
         // ================================================================ halo mover (wave 6): loads only
         // Round 4: the two bulk movers no longer share every job.  vmcnt retires in order, so a wave that stores (the drain) and
@@ -803,314 +671,6 @@ __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
             q += qstride;
             cur = nxt;
         }
-#endif
-    } else {
-    // ==================================================================== bulk movers (waves 6, 7)
-        const int bw = wave - 6;
-        const int t2 = bw * 64 + lane;                     // 0..127 over the two waves
-        constexpr int HB2 = (WS_HALO_BLOCKS + 1) / 2;      // halo blocks per wave
-        // halo block k of this wave = block bw + 2k: lane -> (halo pixel, 16-byte slot); slot s of pixel (hy, hx) holds
-        // channel piece s ^ (2 * ((hx >> 2) & 1)).  Per tile each lane keeps the BYTE offset of its source piece inside either
-        // concat part (-1: zero padding): per chunk a DMA address is then one 64-bit add and a select — the movers' issue rate is
-        // what bounds this kernel, and 64-bit multiplies or a GOT load of the zero page per DMA (what the straightforward
-        // expression compiles to) cost more than the DMA itself.
-        const char* const zero_page = reinterpret_cast<const char*>(p.mask_src);    // 16 zero bytes (host: &ws_zero16)
-        // once per kernel: offset of every block lane's source piece relative to the tile's first input pixel (either concat
-        // part), and which of its blocks lie on the halo's border rows / columns; per TILE the plan is then a handful of scalar
-        // operations (the per-tile version of this loop cost the movers ~2 k cycles at every tile start)
-        int hrel0[HB2], hrel1[HB2];
-        unsigned m_in = 0, m_top = 0, m_bot = 0, m_left = 0, m_right = 0;
-#pragma unroll
-        for (int k = 0; k < HB2; ++k) {
-            const int hp = (bw + 2 * k) * 16 + (lane >> 2);
-            const int hy = hp / HP, hx = hp - hy * HP;
-            const int rel = ((hy - 1) >> ups) * p.IW + ((hx - 1) >> ups);      // tile origins are even: (o - 1 + h) >> ups == (o >> ups) + ((h - 1) >> ups)
-            const int j8 = ((lane & 3) ^ (2 * ((hx >> 2) & 1))) * 8;
-            hrel0[k] = (rel * p.C0 + j8) * 2;
-            hrel1[k] = (rel * p.C1 + j8) * 2;
-            m_in |= (unsigned)(hy < HH && hx < TW + 2) << k;
-            m_top |= (unsigned)(hy == 0) << k;
-            m_bot |= (unsigned)(hy == HH - 1) << k;
-            m_left |= (unsigned)(hx == 0) << k;
-            m_right |= (unsigned)(hx == TW + 1) << k;
-        }
-        unsigned hmask = 0;          // blocks of the planned tile whose source pixel exists (the others are zero padding)
-        int hbase0 = 0, hbase1 = 0;  // byte offset of the planned tile's first input pixel in either concat part
-        auto halo_plan = [&](const WsTile& t) {
-            hmask = m_in;
-            if (t.oy0 == 0) hmask &= ~m_top;
-            if (t.oy0 + TH == p.OH) hmask &= ~m_bot;
-            if (t.ox0 == 0) hmask &= ~m_left;
-            if (t.ox0 + TW == p.OW) hmask &= ~m_right;
-            const int pix = (t.n0 * p.IH + (t.oy0 >> ups)) * p.IW + (t.ox0 >> ups);
-            hbase0 = pix * p.C0 * 2;
-            hbase1 = pix * p.C1 * 2;
-        };
-        auto halo_issue = [&](int c, char* buf, int ka, int kb) {     // blocks ka .. kb-1 of this wave's share (compile-time range)
-            if (WS_DBG(2)) return;                  // timing-only ablation: no halo stream
-            const int cbase = c * 32;
-            const bool first = cbase < p.C0;
-            const char* base = reinterpret_cast<const char*>(first ? p.in0 : p.in1) + (first ? cbase : cbase - p.C0) * 2 + (first ? hbase0 : hbase1);
-#pragma unroll
-            for (int k = 0; k < HB2; ++k) {
-                if (k < ka || k >= kb) continue;
-                const int blk = bw + 2 * k;
-                const char* g = (hmask >> k) & 1 ? base + (first ? hrel0[k] : hrel1[k]) : zero_page;
-                if (blk < WS_HALO_BLOCKS)
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(g), WS_LPTR(buf + blk * 1024), 16, 0, 0);
-            }
-        };
-        // output-tile pieces of this thread: L = k*128 + t2 (k = 0..31): pixel lp = k*8 + (t2 >> 4), cout piece (t2 & 15) ^ (lp & 15).
-        // Element offset of piece k = tile_base(tile) + piece_u(k) * Cout + lpar[k & 1]: a uniform part and two per-lane constants.
-        const int pr = t2 >> 4;
-        const int lpar[2] = {pr * p.Cout + (((t2 & 15) ^ pr) * 8), pr * p.Cout + (((t2 & 15) ^ (pr | 8)) * 8)};
-        auto tile_base = [&](const WsTile& t) -> size_t {
-            return (((size_t)t.n0 * p.OH + t.oy0) * p.OW + t.ox0) * p.Cout + t.cot * 128;
-        };
-        auto piece_rel = [&](int k) -> int {
-            return ((k >> (TWl - 3)) * p.OW + (k & (TW / 8 - 1)) * 8) * p.Cout + lpar[k & 1];
-        };
-        // cout pieces past Cout (half-empty last cout tile): the lane's piece of even / odd k is c8e / c8o
-        const int c8e = (t2 & 15) ^ pr, c8o = (t2 & 15) ^ (pr | 8);
-        auto piece_ok = [&](const WsTile& t, int k) -> bool { return t.cot * 128 + ((k & 1) ? c8o : c8e) * 8 < p.Cout; };
-        auto fetch_table = [&](const WsTile& t) {            // bias[128] (2 x 64 floats) and this image's temb row: 4-byte DMA, 256 B per instruction
-            if (bw != 0 || (WS_DBG(8))) return;
-            const int co_a = t.cot * 128 + lane, co_b = co_a + 64 < p.Cout ? co_a + 64 : p.Cout - 1;
-            if (p.bias) {
-                __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_a), WS_LPTR(tb), 4, 0, 0);
-                __builtin_amdgcn_global_load_lds(WS_GPTR(p.bias + co_b), WS_LPTR(tb + 64), 4, 0, 0);
-            }
-            if (p.addvec) {
-                const float* av = p.addvec + (size_t)t.n0 * p.addvec_ld;
-                __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_a), WS_LPTR(tb + 128), 4, 0, 0);
-                __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_b), WS_LPTR(tb + 192), 4, 0, 0);
-            }
-        };
-#ifdef WS_GROUP3
-        bool do_res = p.residual != nullptr && !(WS_DBG(8));      // prologue only: from the second tile on the loaders fetch the residual tile
-#else
-        const bool do_res = p.residual != nullptr && !(WS_DBG(8));
-#endif
-        auto fetch_residual_at = [&](const bf16* rb, const WsTile& t, int k0, int k1) {      // rb = residual + tile_base(t)
-            if (!do_res) return;
-#pragma unroll 1
-            for (int k = k0; k < k1; ++k) {
-                const void* g = piece_ok(t, k) ? (const void*)(rb + piece_rel(k)) : (const void*)zero_page;
-                __builtin_amdgcn_global_load_lds(WS_GPTR(g), WS_LPTR(ro + (k * 128 + bw * 64) * 16), 16, 0, 0);
-            }
-        };
-        auto fetch_residual = [&](const WsTile& t, int k0, int k1) { fetch_residual_at(p.residual + tile_base(t), t, k0, k1); };
-        const bool do_drain = !(WS_DBG(4));
-        WsTile cur;
-        tile_of(q, cur);
-        // table rows that no DMA fills stay zero
-        if (bw == 0) {
-            if (!p.bias) { tb[lane] = 0.f; tb[64 + lane] = 0.f; }
-            if (!p.addvec) { tb[128 + lane] = 0.f; tb[192 + lane] = 0.f; }
-        }
-        halo_plan(cur);
-        halo_issue(0, halo0, 0, HB2);
-        fetch_table(cur);
-        fetch_residual(cur, 0, 32);
-        // P0 needs the halo image and the table, not the residual tile (32 younger DMAs; E1's vmcnt(0) covers them)
-        if (do_res) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ws_barrier();                                           // P0
-#ifdef WS_GROUP3
-        do_res = false;
-#endif
-        bool have_prev = false;
-        WsTile prev = cur;
-        // Neither the halo image of the next chunk (11 DMAs per wave) nor the tile switch (64 KB out + 64 KB residual in per
-        // CU) is issued in one burst: a DMA costs its wave ~100+ cycles of issue, and a mover that arrives late at a step
-        // barrier stalls the MFMA waves (stamp build: 1.5k cycles per chunk for the halo burst, up to 6.6k with the tile
-        // switch behind it).  Per step a mover issues two halo blocks (steps 0-5) and its share of the tile switch's pieces
-        // (spread over the first nchunks-1 chunks, all nine steps).  vmcnt retires in order: the wait for the halo image at a
-        // chunk's last step leaves in flight exactly the tile-switch operations issued after the last halo block.
-        const int kpc = (32 + nchunks - 2) / (nchunks - 1);      // tile-switch pieces per chunk
-        // pieces [ka, kb) that step t of chunk c moves (empty before the first tile switch and in a tile's last chunk)
-        auto piece_range = [&](int c, int t, int& ka, int& kb) {
-            ka = kb = 32;
-            if (!have_prev || c + 1 >= nchunks) return;
-            const int k0 = c * kpc < 32 ? c * kpc : 32, k1 = k0 + kpc < 32 ? k0 + kpc : 32;
-            const int i0 = t < 6 ? t : 6 + 2 * (t - 6), i1 = t < 6 ? t + 1 : i0 + 2;
-            ka = k0 + i0 < k1 ? k0 + i0 : k1;
-            kb = k0 + i1 < k1 ? k0 + i1 : k1;
-        };
-        bf16x8 vcur[2], vnext[2];
-        bool pre_valid = false;
-        WsTile nxt = cur;
-        bf16* out_prev = reinterpret_cast<bf16*>(p.out);          // element bases of the tile switch (valid from the second tile on)
-        const bf16* res_cur = p.residual;
-        bf16* out_next = out_prev;
-        const bf16* res_next = res_cur;
-        auto read_pieces = [&](int ka, int kb, bf16x8 (&v)[2]) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (ka + u < kb) v[u] = *reinterpret_cast<const bf16x8*>(ro + ((ka + u) * 128 + t2) * 16);
-        };
-#ifdef WS_BULK_STAGE
-        // Round 4 (needs WS_GROUP3): the bulk movers' LOADS go through registers too.  Per group step: wait for everything this
-        // wave has in flight (loads AND stores: it has a whole group step of slack), write what the previous group step
-        // requested into LDS (halo blocks of the next chunk, residual pieces of this tile), then request this group step's
-        // share — halo blocks [0,6) / [6,11) of the next chunk in group steps 0 / 1, the tile switch's pieces of the three
-        // steps: output piece LDS -> registers -> global store, residual piece global -> registers.  A plain load + ds_write_b128
-        // costs the wave ~70 cycles per KiB against ~140-200 for an LDS-DMA and takes half the issue slots from the MFMA wave
-        // on its SIMD (tools/stage_probe.hip).
-        u32x4 hq[6], rq[6];
-        int rq_ka = 32, rq_kb = 32;                    // residual pieces requested in the previous group step
-        auto halo_load = [&](int c, int ka, int kb) {  // blocks ka .. kb-1 of this wave's share -> hq[k - ka]
-            const int cbase = c * 32;
-            const bool first = cbase < p.C0;
-            const char* base = reinterpret_cast<const char*>(first ? p.in0 : p.in1) + (first ? cbase : cbase - p.C0) * 2 + (first ? hbase0 : hbase1);
-#pragma unroll
-            for (int k = 0; k < HB2; ++k) {
-                if (k < ka || k >= kb) continue;
-                const char* g = (hmask >> k) & 1 ? base + (first ? hrel0[k] : hrel1[k]) : zero_page;
-                if (bw + 2 * k < WS_HALO_BLOCKS) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(hq[k - ka]) : "v"(g) : "memory");
-            }
-        };
-        auto halo_store = [&](char* buf, int ka, int kb) {
-#pragma unroll
-            for (int k = 0; k < HB2; ++k) {
-                if (k < ka || k >= kb) continue;
-                if (bw + 2 * k < WS_HALO_BLOCKS) *reinterpret_cast<u32x4*>(buf + (bw + 2 * k) * 1024 + lane * 16) = hq[k - ka];
-            }
-        };
-        for (;;) {
-            const bool more = q + qstride < ntiles;
-            for (int c = 0; c < nchunks; ++c) {
-                const bool wrap = c + 1 == nchunks;
-                if (wrap && more) {
-                    tile_of(q + qstride, nxt);
-                    out_next = reinterpret_cast<bf16*>(p.out) + tile_base(cur);
-                    res_next = p.residual + tile_base(nxt);
-                    halo_plan(nxt);
-                }
-                const bool do_halo = (!wrap || more) && !(WS_DBG(2));
-                char* const hbuf = halo0 + ((c + 1) & 1) * WS_HALO;
-                const int hc = wrap ? 0 : c + 1;
-#pragma unroll
-                for (int g3 = 0; g3 < 3; ++g3) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    // 1. into LDS: what the previous group step requested
-                    if (g3 == 1 && do_halo) halo_store(hbuf, 0, 6);
-                    if (g3 == 2 && do_halo) halo_store(hbuf, 6, HB2);
-#pragma unroll
-                    for (int u = 0; u < 6; ++u)
-                        if (rq_ka + u < rq_kb) *reinterpret_cast<u32x4*>(ro + ((rq_ka + u) * 128 + t2) * 16) = rq[u];
-                    rq_ka = rq_kb = 32;
-                    // 2. this group step's requests
-                    if (g3 == 0 && do_halo) halo_load(hc, 0, 6);
-                    if (g3 == 1 && do_halo) halo_load(hc, 6, HB2);
-                    int ka, kb, kx, ky;
-                    piece_range(c, 3 * g3, ka, kx);
-                    piece_range(c, 3 * g3 + 2, ky, kb);
-                    if (ka < kb) {
-                        if (do_drain) {
-                            bf16x8 v[6];
-#pragma unroll
-                            for (int u = 0; u < 6; ++u)
-                                if (ka + u < kb) v[u] = *reinterpret_cast<const bf16x8*>(ro + ((ka + u) * 128 + t2) * 16);
-#pragma unroll
-                            for (int u = 0; u < 6; ++u)
-                                if (ka + u < kb && piece_ok(prev, ka + u)) *reinterpret_cast<bf16x8*>(out_prev + piece_rel(ka + u)) = v[u];
-                        }
-                        if (do_res) {
-#pragma unroll
-                            for (int u = 0; u < 6; ++u)
-                                if (ka + u < kb) {
-                                    const void* g = piece_ok(cur, ka + u) ? (const void*)(res_cur + piece_rel(ka + u)) : (const void*)zero_page;
-                                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rq[u]) : "v"(g) : "memory");
-                                }
-                            rq_ka = ka;
-                            rq_kb = kb;
-                        }
-                    }
-                    if (!(WS_DBG(16))) ws_barrier();                                // end of a group step (lgkmcnt(0): LDS writes done)
-                }
-            }
-            ws_barrier();                                        // E1
-            ws_barrier();                                        // E2
-            prev = cur;
-            have_prev = true;
-            if (!more) break;
-            q += qstride;
-            cur = nxt;
-            out_prev = out_next;
-            res_cur = res_next;
-        }
-#else
-        for (;;) {
-            const bool more = q + qstride < ntiles;
-            WS_TSTAMP(160, wave == 6 && q == (int)blockIdx.x + qstride);
-            for (int c = 0; c < nchunks; ++c) {
-                const bool wrap = c + 1 == nchunks;
-                WS_TSTAMP(163, wave == 6 && c == 0 && q == (int)blockIdx.x + qstride);
-                if (wrap && more) {
-                    // the last chunk of a tile carries no tile-switch pieces: the next tile's coordinates (integer divisions),
-                    // element bases (64-bit multiplies) and halo plan are computed here, off the tile start's critical path
-                    tile_of(q + qstride, nxt);
-                    out_next = reinterpret_cast<bf16*>(p.out) + tile_base(cur);
-                    res_next = p.residual + tile_base(nxt);
-                    halo_plan(nxt);
-                }
-                const bool do_halo = !wrap || more;
-                char* const hbuf = halo0 + ((c + 1) & 1) * WS_HALO;
-                const int hc = wrap ? 0 : c + 1;
-                int young = 0;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    if (t < WS_HALO_STEPS && do_halo) halo_issue(hc, hbuf, WS_HALO_PER * t, WS_HALO_PER * t + WS_HALO_PER);
-                    WS_TSTAMP(164, wave == 6 && c == 0 && t == 0 && q == (int)blockIdx.x + qstride);
-                    // tile-switch pieces of this step (piece_range: one per step while the halo blocks are being issued, two per
-                    // step afterwards — at most four vector-memory instructions per mover and step).  Their LDS reads were
-                    // issued one step ahead (completed by the barrier's lgkmcnt wait), so a step's chain is store + DMA only.
-                    int ka, kb, na, nb_;
-                    piece_range(c, t, ka, kb);
-                    if (ka < kb) {
-                        if (!pre_valid) read_pieces(ka, kb, vcur);       // first pieces of a tile switch: nothing was read ahead
-                        if (do_drain) {
-#pragma unroll
-                            for (int u = 0; u < 2; ++u)      // (a store instruction always has valid lanes: every cout piece occurs in it)
-                                if (ka + u < kb && piece_ok(prev, ka + u)) *reinterpret_cast<bf16x8*>(out_prev + piece_rel(ka + u)) = vcur[u];
-                        }
-                        fetch_residual_at(res_cur, cur, ka, kb);
-                        if (t >= WS_HALO_STEPS - 1) young += (kb - ka) * ((do_drain ? 1 : 0) + (do_res ? 1 : 0));   // issued after the last halo block
-                    }
-                    WS_TSTAMP(165, wave == 6 && c == 0 && t == 0 && q == (int)blockIdx.x + qstride);
-                    if (t < 8) piece_range(c, t + 1, na, nb_); else piece_range(c + 1, 0, na, nb_);
-                    pre_valid = na < nb_;
-                    if (pre_valid) read_pieces(na, nb_, vnext);
-                    if (t == 8) {
-                        // halo image (and everything older) landed; at the last chunk E1 needs the whole residual tile
-                        if (wrap) ws_wait_vm(0);
-                        else ws_wait_vm(young);
-                    }
-                    WS_TSTAMP(153 + (t < 3 ? t : 3), wave == 6 && c == 0 && t < 3 && q == (int)blockIdx.x + qstride);
-#ifdef WS_GROUP3
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the reads ahead
-                    if (t % 3 == 2) { if (!(WS_DBG(16))) ws_barrier(); }            // end of a group step
-#else
-                    if (!(WS_DBG(16))) ws_barrier();                                // B_g (its lgkmcnt(0) completes the reads ahead)
-#endif
-                    vcur[0] = vnext[0];
-                    vcur[1] = vnext[1];
-                }
-            }
-            pre_valid = false;                                   // the epilogue rewrites the output tile: nothing read ahead survives it
-            ws_barrier();                                        // E1
-            ws_barrier();                                        // E2
-            WS_TSTAMP(152, wave == 6 && q == (int)blockIdx.x);
-            prev = cur;
-            have_prev = true;
-            if (!more) break;
-            q += qstride;
-            cur = nxt;
-            out_prev = out_next;
-            res_cur = res_next;
-        }
-#endif
     }
 
     // ==================================================================== last tile out: all eight waves

@@ -14,11 +14,6 @@
 #include <stdlib.h>
 #include <type_traits>
 
-// Round 4: the weight stream is register-staged and handed over in groups of three steps (one workgroup barrier per 96 / 48
-// MFMAs).  -DWS_PER_STEP_BARRIER builds the round-2/3 form (LDS-DMA loaders, one barrier per step) for A/B runs.
-#ifndef WS_PER_STEP_BARRIER
-#define WS_GROUP3 1
-#endif
 
 namespace {
 
@@ -161,11 +156,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
                     read_b(u, 1, By);
                     if (u & 1) mfma8(A1, Bx, 0); else mfma8(A0, Bx, 0);
                     W8_INTERLEAVE_2();
-#ifdef WS_GROUP3
                     if (u % 3 == 2) w8_barrier();       // end of a group of three steps: the next group's weights (at a chunk end: the next halo image) landed
-#else
-                    w8_barrier();                       // B_g: tap g+1 (and, at a chunk end, the next halo image) landed
-#endif
                     if (u & 1) read_a(u + 1, A0); else read_a(u + 1, A1);
                     read_b(u + 1, 0, Bx);
                     if (u & 1) mfma8(A1, By, 1); else mfma8(A0, By, 1);
@@ -294,7 +285,6 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
             for (int f = 0; f < 2; ++f)
                 __builtin_amdgcn_global_load_lds(W8_GPTR(src + f * 1024), W8_LPTR(dst + f * 1024), 16, 0, 0);
         };
-#ifdef WS_GROUP3
         // register-staged weight stream handed over in groups of three steps (see conv_ws.hip, round 4): the ring's six slots are
         // two groups; group G + 1 is written from registers (ds_write_b128) while the MFMA waves read group G; its fragments were
         // requested two group steps earlier (two register sets of 6 x 4 registers).  One barrier per three steps.
@@ -379,32 +369,6 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
             q += qstride;
             cur = nxt;
         }
-#else
-#pragma unroll 1
-        for (int g = 0; g < W8_RING - 1; ++g) issue_tap(cur.cot, g);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (W8_RING - 2)) : "memory");    // tap 0 landed (RING - 2 younger taps may be outstanding)
-        w8_barrier();                                       // P0
-        for (;;) {
-            const bool more = q + qstride < ntiles;
-            W8Tile nxt = cur;
-            if (more) tile_of(q + qstride, nxt);
-            for (int g = 0; g < S; ++g) {
-                const int g3 = g + W8_RING - 1;
-                bool issued = true;
-                if (g3 < S) issue_tap(cur.cot, g3);
-                else if (more) issue_tap(nxt.cot, g3 - S);      // same ring slot: S % RING == 0 (host-checked)
-                else issued = false;
-                if (issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (W8_RING - 2)) : "memory");    // taps g+2 .. g+RING-1 may be outstanding
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                w8_barrier();                                    // B_g
-            }
-            w8_barrier();                                        // E1
-            w8_barrier();                                        // E2
-            if (!more) break;
-            q += qstride;
-            cur = nxt;
-        }
-#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
@@ -468,11 +432,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
                 }
             }
         };
-#ifdef WS_GROUP3
         bool do_res = p.residual != nullptr;       // prologue only: from the second tile on the loaders fetch the residual tile
-#else
-        const bool do_res = p.residual != nullptr;
-#endif
         auto fetch_residual = [&](const W8Tile& t, int k0, int k1) {
             if (!do_res) return;
 #pragma unroll 1
@@ -522,9 +482,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
         if (do_res) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         w8_barrier();                                           // P0
-#ifdef WS_GROUP3
         do_res = false;
-#endif
         bool have_prev = false;
         W8Tile prev = cur;
         const int kpc = (16 + nchunks - 2) / (nchunks - 1);      // tile-switch pieces per chunk (first nchunks-1 chunks)
@@ -561,11 +519,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
                         if (wrap) w8_wait_vm(0);
                         else w8_wait_vm(young);
                     }
-#ifdef WS_GROUP3
                     if (t % 3 == 2) w8_barrier();                // end of a group step
-#else
-                    w8_barrier();                                // B_g
-#endif
                 }
             }
             w8_barrier();                                        // E1
