@@ -59,6 +59,9 @@ SIGNATURES = {
     "dxmi_groupnorm_silu_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 9 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dxmi_bgemm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, c_float, c_int, c_int, c_void_p]),
     "dxmi_softmax_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "dxmi_attention_bwd_supported": (c_int, [c_int, c_int, c_int]),
+    "dxmi_attention_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "dxmi_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dxmi_colsum_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "dxmi_colsum_blocks_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "dxmi_colsum_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -391,14 +391,26 @@ def bgemm(A, B, C, M, N, K, a_strides, a_ld, a_kc, b_strides, b_ld, b_kc, c_stri
     return C
 
 
-def attention_bwd(qkv, do, heads, scale):
-    """qkv [N,T,3C] ([q|k|v], heads = contiguous channel blocks), do [N,T,C] -> dqkv [N,T,3C] (bf16)."""
-    _need_cuda(qkv, do)
+FUSED_ATTENTION_BWD = True      # A-B switch: False keeps the five-GEMM path for every head size
+
+
+def attention_bwd(qkv, do, heads, scale, o=None):
+    """qkv [N,T,3C] ([q|k|v], heads = contiguous channel blocks), do [N,T,C] -> dqkv [N,T,3C] (bf16).
+    o: the forward pass's attention output [N,T,C]; with it, 64-wide heads take the fused kernels (no [T,T] tensor in HBM)."""
+    _need_cuda(qkv, do, o)
     N, T, C3 = qkv.shape
     C = C3 // 3
     D = C // heads
     dev = qkv.device
     assert qkv.dtype == torch.bfloat16 and do.dtype == torch.bfloat16 and qkv.is_contiguous() and do.is_contiguous()
+    if o is not None and FUSED_ATTENTION_BWD and load().dxmi_attention_bwd_supported(T, C, heads):
+        assert o.dtype == torch.bfloat16 and o.is_contiguous() and o.numel() == N * T * C
+        dqkv = torch.empty_like(qkv)
+        ws = _workspace(max(256, load().dxmi_attention_bwd_workspace_bytes(N, T, heads)), dev)
+        _prof("attention_bwd", f"T{T}_D{D}", 16.0 * N * T * T * C, 2.0 * (2 * qkv.numel() + 2 * do.numel()) * 2, lambda: check(
+            load().dxmi_attention_bwd(_ptr(qkv), _ptr(o), _ptr(do), _ptr(dqkv), _ptr(ws), N, T, C, heads, float(scale), _stream()),
+            "dxmi_attention_bwd"))
+        return dqkv
     S = torch.empty((N, heads, T, T), dtype=torch.float32, device=dev)
     dP = torch.empty_like(S)
     P = torch.empty((N, heads, T, T), dtype=torch.bfloat16, device=dev)

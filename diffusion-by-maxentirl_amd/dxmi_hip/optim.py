@@ -86,7 +86,8 @@ def _batches(opt, name):
 
 def _cache_for(opt, key, b):
     caches = opt.__dict__.setdefault("_dxmi_cache", {})
-    cache = caches.setdefault(key[:3] + (len(b.params),), {})
+    # (the first parameter's address tells apart two batches of equal length: parameters whose step counts differ)
+    cache = caches.setdefault(key[:3] + (len(b.params), b.params[0].data_ptr()), {})
     pk = _ptr_key(b.params, b.ms, b.vs)
     if cache.get("ptr_key") != pk:
         cache.clear()
@@ -118,6 +119,7 @@ class RAdam(_FusedBase, torch.optim.RAdam):
         """grad_scale / found_inf: optional device scalars (loss-scale reciprocal, overflow flag: a flagged step is skipped
         on the device; the caller rolls `step` back with `rollback_step()` once it reads the flag)."""
         assert closure is None
+        self._dxmi_last_stepped = [self.state[p] for g in self.param_groups for p in g["params"] if p.grad is not None]
         for key, b in _batches(self, "RAdam").items():
             b1, b2, eps, t = key
             bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
@@ -134,9 +136,66 @@ class RAdam(_FusedBase, torch.optim.RAdam):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self.__dict__.pop("_dxmi_cache", None)
+        self.__dict__.pop("_dxmi_slices", None)
+
+    @torch.no_grad()
+    def step_sliced(self, slices, grad_scale=None, found_inf=None):
+        """One RAdam step of FLAT master parameters taken tensor by tensor (MixedPrecisionTrainer, models/cm/fp16_util.py:
+        204-223): `slices[master] = [model_param, ...]` lists, in flattening order, the model parameters whose storage IS the
+        corresponding slice of `master` (the trainer aliases them), each carrying its own `.grad`.  The kernels then read the
+        model gradients where autograd left them and update parameter and moment slices in place: no flattened gradient
+        copy, no `grad.mul_(1 / scale)` pass (grad_scale), no copy back into the model.  Same arithmetic, state layout
+        (`state[master]`: step, flat exp_avg / exp_avg_sq) and step counting as `step()`."""
+        cache = self.__dict__.setdefault("_dxmi_slices", {})
+        self._dxmi_last_stepped = [self.state[P] for g in self.param_groups for P in g["params"]]
+        batches = {}
+        for group in self.param_groups:
+            _check_group(group, "RAdam")
+            if group.get("decoupled_weight_decay"):
+                raise DxmiError("dxmi_hip.optim.RAdam: decoupled_weight_decay is not implemented")
+            b1, b2 = group["betas"]
+            for P in group["params"]:
+                ps = slices[P]
+                st = self.state[P]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(P, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(P, memory_format=torch.preserve_format)
+                st["step"] += 1
+                ck = (id(P), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), P.data_ptr(), len(ps))
+                views = cache.get(id(P))
+                if views is None or views[0] != ck:
+                    mf, vf, off, ms, vs = st["exp_avg"].view(-1), st["exp_avg_sq"].view(-1), 0, [], []
+                    for q in ps:
+                        if q.data_ptr() != P.data_ptr() + 4 * off:
+                            raise DxmiError("dxmi_hip.optim.RAdam.step_sliced: a model parameter is not the slice of its master")
+                        ms.append(mf[off:off + q.numel()])
+                        vs.append(vf[off:off + q.numel()])
+                        off += q.numel()
+                    if off != P.numel():
+                        raise DxmiError("dxmi_hip.optim.RAdam.step_sliced: slices do not cover the master parameter")
+                    views = cache[id(P)] = (ck, ms, vs)
+                b = batches.setdefault((b1, b2, group["eps"], float(st["step"])), _Batch())
+                b.params += ps
+                b.grads += [q.grad for q in ps]
+                b.ms += views[1]
+                b.vs += views[2]
+                b.lrs += [group["lr"]] * len(ps)
+        for key, b in batches.items():
+            b1, b2, eps, t = key
+            bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+            rho_inf = 2 / (1 - b2) - 1
+            rho_t = rho_inf - 2 * t * (b2 ** t) / bc2
+            rect = -1.0
+            if rho_t > 5.0:
+                rect = ((rho_t - 4) * (rho_t - 2) * rho_inf / ((rho_inf - 4) * (rho_inf - 2) * rho_t)) ** 0.5
+            ops.radam_step(b.params, b.grads, b.ms, b.vs, b.lrs, b1, b2, eps, bc1, math.sqrt(bc2), rect, grad_scale=grad_scale,
+                           found_inf=found_inf, cache=_cache_for(self, key + ("sliced",), b))
+            _bump_versions(b.params)
+        return None
 
     def rollback_step(self):
-        """Undo the step counter of a step the device skipped (found_inf was set)."""
-        for st in self.state.values():
-            if "step" in st:
-                st["step"] -= 1
+        """Undo the step counter of a step the device skipped (found_inf was set): only of the parameters that took part in the
+        last step()/step_sliced() (a parameter whose gradient was None kept its count)."""
+        for st in self.__dict__.get("_dxmi_last_stepped", ()):
+            st["step"] -= 1

@@ -55,6 +55,10 @@ def master_params_to_model_params(param_groups_and_shapes, master_params):
     for master_param, (param_group, _) in zip(master_params, param_groups_and_shapes):
         if not param_group:
             continue
+        if param_group[0][1].data_ptr() == master_param.data_ptr():     # the model parameters ARE the master's slices:
+            # nothing to copy, but the packed-weight caches are keyed on the model tensors' version counters
+            torch.autograd.graph.increment_version([param for (_, param) in param_group])
+            continue
         dst = [param.detach() for (_, param) in param_group]
         src = list(unflatten_master_params(param_group, master_param.detach().view(-1)))
         torch._foreach_copy_(dst, src)
@@ -86,11 +90,32 @@ class MixedPrecisionTrainer:
         self.param_groups_and_shapes = None
         self.lg_loss_scale = initial_lg_loss_scale
         self.log = {}     # last grad_norm / param_norm / lg_loss_scale (the reference sends these to its logger)
+        self._aliased = False
         if self.use_fp16:
             self.param_groups_and_shapes = get_param_groups_and_shapes(self.model.named_parameters(), special_key=special_key)
             self.master_params = make_master_params(self.param_groups_and_shapes)
+            self._alias_model_params()
         from dxmi_hip.dist import FlatGradSync
         self._sync = FlatGradSync(model)
+
+    def _alias_model_params(self):
+        """On the HIP path the model parameters are fp32 like their masters, so the two copies the reference keeps (fp16 model,
+        fp32 flat masters: fp16_util.py:96-115) can be ONE storage: every model parameter becomes the view of its slice of the
+        flat master tensor.  `master_params_to_model_params` then has nothing to copy, and `optimize` can step the masters
+        tensor by tensor on the model gradients (dxmi_hip.optim.RAdam.step_sliced).  Device tensors only (the CPU tests keep
+        the reference's two-copy bookkeeping)."""
+        if not all(p.is_cuda and p.dtype == torch.float32 for p in self.model_params):
+            return
+        self._slices = {}
+        for master, (group, _) in zip(self.master_params, self.param_groups_and_shapes):
+            flat, off, ps = master.detach().view(-1), 0, []
+            for _, p in group:
+                p.data = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                ps.append(p)
+            self._slices[master] = ps
+        torch.autograd.graph.increment_version(self.model_params)      # packed-weight caches are keyed on (data_ptr, _version)
+        self._aliased = True
 
     def zero_grad(self):
         zero_grad(self.model_params)
@@ -105,7 +130,35 @@ class MixedPrecisionTrainer:
         self._sync()   # data-parallel mean of the gradients (no-op on one process)
         return self._optimize_fp16(opt) if self.use_fp16 else self._optimize_normal(opt)
 
+    def _optimize_fp16_sliced(self, opt):
+        """`_optimize_fp16` without its five passes over the 1.2 GB of parameters (flatten the gradients, two norm passes with a
+        host sync each, `grad.mul_(1 / scale)`, copy the masters back): the norm kernel reads the model gradients where
+        autograd left them, the overflow flag stays on the device and the RAdam kernel — skipped there when the flag is set —
+        un-scales the gradient as it reads it.  One host read (norms + flag) per call, for the loss-scale bookkeeping."""
+        from dxmi_hip import ops
+        self.log["lg_loss_scale"] = self.lg_loss_scale
+        for p in self.model_params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)            # param_grad_or_zeros(): a zero gradient still decays the moments
+        scale = 2.0 ** self.lg_loss_scale
+        gstat = ops.gradnorm_clip([p.grad for p in self.model_params], 0.0)        # (norm of the SCALED gradient, -, non-finite flag)
+        pstat = ops.gradnorm_clip([m.detach() for m in self.master_params], 0.0)
+        found = gstat[2:3]
+        inv = torch.full((1,), 1.0 / scale, dtype=torch.float32, device=found.device)
+        opt.step_sliced(self._slices, grad_scale=inv, found_inf=found)
+        gn, pn, flag = torch.stack([gstat[0], pstat[0], gstat[2]]).tolist()
+        zero_grad(self.model_params)
+        if flag != 0.0 or check_overflow(gn / scale):
+            opt.rollback_step()
+            self.lg_loss_scale -= 1
+            return False
+        self.log["grad_norm"], self.log["param_norm"] = gn / scale, pn
+        self.lg_loss_scale += self.fp16_scale_growth
+        return True
+
     def _optimize_fp16(self, opt):
+        if self._aliased and hasattr(opt, "step_sliced") and all(P in self._slices for g in opt.param_groups for P in g["params"]):
+            return self._optimize_fp16_sliced(opt)
         self.log["lg_loss_scale"] = self.lg_loss_scale
         model_grads_to_master_grads(self.param_groups_and_shapes, self.master_params)
         grad_norm, param_norm = self._compute_norms(grad_scale=2 ** self.lg_loss_scale)

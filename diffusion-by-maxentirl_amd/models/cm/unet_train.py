@@ -225,7 +225,7 @@ class _EDMUNetFn(torch.autograd.Function):
             conv_wb(m.proj_out, a.view(Nn, Hh, Ww, C), g, 1)
             d_a = ops.conv2d(g, pkt[id(m), "proj"])
             d_qkv = ops.attention_bwd(qkv.view(Nn, Hh * Ww, 3 * C), d_a.view(Nn, Hh * Ww, C), m.num_heads,
-                                      1.0 / math.sqrt(C // m.num_heads)).view(Nn, Hh, Ww, 3 * C)
+                                      1.0 / math.sqrt(C // m.num_heads), o=a.view(Nn, Hh * Ww, C)).view(Nn, Hh, Ww, 3 * C)
             conv_wb(m.qkv, hn, d_qkv, 1)
             d_hn = ops.conv2d(d_qkv, pkt[id(m), "qkv"])
             d_x, _, _ = gn_bwd(m.norm, xa, d_hn, add0=g, silu=False)

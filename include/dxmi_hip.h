@@ -190,6 +190,17 @@ int dxmi_bgemm_bf16(const void* A, const void* B, void* C, int32_t M, int32_t N,
 int dxmi_softmax_bwd(const float* S, const float* dP, void* P, void* dS, int64_t rows, int32_t T,
                      void* stream);
 
+/* Fused attention backward (round 4) for head dimension 64 (every attention block of the ADM / EDM nets,
+ * models/cm/unet.py:413-441): dqkv [N,T,3C] from qkv [N,T,3C], the forward output o [N,T,C] and its gradient dout [N,T,C]
+ * (bf16), without any [T,T] tensor in HBM: the probabilities are recomputed from the row log-sum-exp (first kernel, which also
+ * forms delta = <dO, O> and dQ), then dK / dV per key block (second kernel).  Fixed summation orders: bitwise reproducible.
+ * workspace: dxmi_attention_bwd_workspace_bytes(N, T, heads) bytes.  dxmi_attention_bwd_supported: 1 when C / heads == 64
+ * (other head sizes: the dxmi_bgemm_bf16 / dxmi_softmax_bwd sequence above). */
+int dxmi_attention_bwd_supported(int32_t T, int32_t C, int32_t heads);
+int64_t dxmi_attention_bwd_workspace_bytes(int32_t N, int32_t T, int32_t heads);
+int dxmi_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, void* workspace, int32_t N, int32_t T,
+                       int32_t C, int32_t heads, float scale, void* stream);
+
 /* Backward of dxmi_pool_act: din = (pool ? 0.25 * upsample2(g) : g), g = dout * (act_out > 0 ? 1 : slope);
  * dout/act_out: [N,OH,OW,C], din: [N,H,W,C] (H = 2*OH when pool). */
 int dxmi_pool_act_bwd(const void* dout, const void* act_out, void* din, int32_t N, int32_t H, int32_t W,

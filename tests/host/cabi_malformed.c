@@ -119,6 +119,12 @@ int main(void) {
     expect_einval("colsum_f32(B = 0)", dxmi_colsum_f32((const float*)FAKE(1), (float*)FAKE(2), 0, 4, 128, NULL));
     expect_einval("edm_step_fwd(NULL sigma)", dxmi_edm_step_fwd((const float*)FAKE(1), (const float*)FAKE(2), (const float*)FAKE(3), NULL, (const float*)FAKE(4), (const float*)FAKE(5), (float*)FAKE(6), (float*)FAKE(7), 4, 12288, 0.5f, NULL));
 
+    expect_einval("attention_bwd(NULL o)", dxmi_attention_bwd(FAKE(1), NULL, FAKE(2), FAKE(3), FAKE(4), 2, 256, 128, 2, 0.125f, NULL));
+    expect_einval("attention_bwd(head dim 32)", dxmi_attention_bwd(FAKE(1), FAKE(5), FAKE(2), FAKE(3), FAKE(4), 2, 256, 128, 4, 0.125f, NULL));
+    expect_einval("attention_bwd(T = 0)", dxmi_attention_bwd(FAKE(1), FAKE(5), FAKE(2), FAKE(3), FAKE(4), 2, 0, 128, 2, 0.125f, NULL));
+    if (dxmi_attention_bwd_supported(256, 256, 1) != 0 || dxmi_attention_bwd_supported(1024, 384, 6) != 1 || dxmi_attention_bwd_workspace_bytes(0, 256, 2) != 0) { printf("FAIL attention_bwd queries\n"); ++failures; }
+    else printf("ok   attention_bwd_supported / workspace_bytes\n");
+
     /* ---- FID statistics ------------------------------------------------------------------------------------------ */
     expect_einval("fid_stats(NULL act)", dxmi_fid_stats(NULL, 100, 64, (double*)FAKE(1), (double*)FAKE(2), FAKE(3), NULL));
     expect_einval("fid_stats(N = 1)", dxmi_fid_stats((const float*)FAKE(1), 1, 64, (double*)FAKE(1), (double*)FAKE(2), FAKE(3), NULL));

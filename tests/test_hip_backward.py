@@ -196,6 +196,38 @@ def test_groupnorm_silu_bwd(ops, N, C0, C1, H, silu):
     assert rel_l2(dg.cpu(), gamma.grad) < 1e-4 and rel_l2(db.cpu(), beta.grad) < 1e-4
 
 
+@pytest.mark.parametrize("N,T,C,heads", [(2, 1024, 384, 6), (3, 256, 576, 9), (2, 64, 128, 2), (2, 200, 128, 2), (1, 40, 64, 1)])
+def test_attention_bwd_fused_heads64(ops, N, T, C, heads):
+    """Round 4: fused backward for 64-wide heads (the ADM / EDM attention blocks: models/cm/unet.py:413-441) — the probabilities
+    are recomputed from the row log-sum-exp, no [T,T] tensor in HBM — against autograd through the fp32 attention on the
+    bf16-rounded inputs (1e-2), against the five-GEMM path (same tolerance class), ragged T, and bitwise reproducibility."""
+    g = torch.Generator().manual_seed(T + C)
+    qkv = bf(torch.randn(N, T, 3 * C, generator=g)).requires_grad_(True)
+    do = bf(torch.randn(N, T, C, generator=g))
+    D = C // heads
+    assert D == 64
+    scale = 1.0 / math.sqrt(D)
+    q, k, v = qkv.split(C, dim=2)
+    q = q.view(N, T, heads, D).transpose(1, 2)
+    k = k.view(N, T, heads, D).transpose(1, 2)
+    v = v.view(N, T, heads, D).transpose(1, 2)
+    o = (torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1) @ v).transpose(1, 2).reshape(N, T, C)
+    o.backward(do)
+    qd, dd = qkv.detach().to(torch.bfloat16).to(DEV), do.to(torch.bfloat16).to(DEV)
+    od = ops.attention(qd, heads, scale)                              # the forward output the training graph keeps
+    assert rel_l2(od.float().cpu(), o.detach()) < 1e-2
+    got = ops.attention_bwd(qd, dd, heads, scale, o=od)
+    for name, sl in (("dq", slice(0, C)), ("dk", slice(C, 2 * C)), ("dv", slice(2 * C, 3 * C))):
+        e = rel_l2(got[:, :, sl].float().cpu(), qkv.grad[:, :, sl])
+        assert e < 1e-2, (name, e)
+    old = ops.attention_bwd(qd, dd, heads, scale)                     # no o: the five-GEMM path
+    assert rel_l2(got.float().cpu(), old.float().cpu()) < 1e-2
+    assert torch.equal(got, ops.attention_bwd(qd, dd, heads, scale, o=od))
+    # an image's gradient does not depend on the batch it rides in
+    one = ops.attention_bwd(qd[1:2].contiguous(), dd[1:2].contiguous(), heads, scale, o=od[1:2].contiguous()) if N > 1 else None
+    assert one is None or torch.equal(one[0], got[1])
+
+
 @pytest.mark.parametrize("N,T,C,heads", [(2, 256, 256, 1), (3, 16, 256, 1), (2, 64, 128, 2)])
 def test_attention_bwd(ops, N, T, C, heads):
     g = torch.Generator().manual_seed(T + C)

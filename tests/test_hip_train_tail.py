@@ -93,6 +93,56 @@ def test_fused_radam_found_inf_skips_on_device():
     assert not torch.equal(ps[0].detach(), before[0])
 
 
+def test_mixed_precision_trainer_sliced_step_is_bitwise_the_flat_path():
+    """MixedPrecisionTrainer on the HIP path (round 4): the model parameters are the slices of their flat masters and
+    `optimize` steps the masters tensor by tensor on the model gradients (no flatten / mul_ / copy-back passes).  Parameters,
+    both moment tensors, lg_loss_scale and the logged norms must equal the reference-shaped flat path (fp16_util.py:204-223:
+    flatten, norms, grad.mul_(1 / scale), opt.step on the flat masters) bit for bit over rectified and un-rectified steps, with
+    an overflow step in the middle (skipped on the device, step counters rolled back, loss scale lowered) and a parameter
+    that never receives a gradient."""
+    import copy
+    from dxmi_hip.optim import RAdam
+    from models.cm.fp16_util import MixedPrecisionTrainer
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3), torch.nn.GroupNorm(4, 16), torch.nn.Conv2d(16, 8, 1), torch.nn.Linear(5, 7)).to(DEV)
+    net.register_parameter("log_betas", torch.nn.Parameter(torch.linspace(-2, 0, 4, device=DEV)))
+    nets = [net, copy.deepcopy(net)]
+    mps = [MixedPrecisionTrainer(model=m, use_fp16=True, initial_lg_loss_scale=12, special_key="log_betas") for m in nets]
+    assert all(mp._aliased for mp in mps)
+    for mp, m in zip(mps, nets):          # every model parameter IS its master's slice
+        for master, (group, _) in zip(mp.master_params, mp.param_groups_and_shapes):
+            off = 0
+            for _, q in group:
+                assert q.data_ptr() == master.data_ptr() + 4 * off
+                off += q.numel()
+    opts = [RAdam([{"params": mp.master_params[1:], "lr": 1e-3}, {"params": mp.master_params[0:1], "lr": 1e-2}]) for mp in mps]
+    mps[1]._aliased = False               # second trainer: the flat path (its copy-back finds nothing to copy, only bumps versions)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for step in range(9):
+        grads = [torch.randn(q.shape, generator=g).to(DEV) * 4096.0 for q in nets[0].parameters()]
+        if step == 4:
+            grads[2].view(-1)[3] = float("inf")
+        for m in nets:
+            for i, (q, gr) in enumerate(zip(m.parameters(), grads)):
+                q.grad = None if i == 5 else gr.clone()         # parameter 5 never gets a gradient (zeros, as the reference)
+        v0 = [q._version for q in nets[0].parameters()]
+        ok = [mp.optimize(opt) for mp, opt in zip(mps, opts)]
+        assert ok[0] == ok[1] == (step != 4)
+        assert mps[0].lg_loss_scale == mps[1].lg_loss_scale
+        for a, b in zip(nets[0].parameters(), nets[1].parameters()):
+            assert torch.equal(a.detach(), b.detach()), step
+        for Ma, Mb in zip(mps[0].master_params, mps[1].master_params):
+            sa, sb = opts[0].state[Ma], opts[1].state[Mb]
+            assert float(sa["step"]) == float(sb["step"]) == (step + 1 if step < 4 else step)
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+        if ok[0]:
+            assert mps[0].log["grad_norm"] == pytest.approx(mps[1].log["grad_norm"], rel=2e-6)
+            assert mps[0].log["param_norm"] == pytest.approx(mps[1].log["param_norm"], rel=2e-6)
+            assert all(q._version > v for q, v in zip(nets[0].parameters(), v0))       # packed-weight caches see the update
+        assert all(q.grad is None for q in nets[0].parameters())
+    assert abs(mps[0].lg_loss_scale - (12 - 1 + 8 * 1e-3)) < 1e-9
+
+
 @pytest.mark.parametrize("max_norm", [0.1, 1e6])
 def test_gradnorm_clip_vs_torch(max_norm):
     from dxmi_hip import ops

@@ -3,7 +3,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "diffusion-by-maxentirl_amd")]
 import torch
-from torch.optim import Adam, RAdam
+from dxmi_hip.optim import Adam, RAdam          # the shipped optimisers (train_image_large.py)
 import configs_builtin, dxmi_config
 from models.cm.fp16_util import MixedPrecisionTrainer
 from models.cm.script_util import create_model_and_diffusion
