@@ -84,6 +84,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     float m = -INFINITY, l = 0.f;
+    const float sc2 = p.scale * 1.4426950408889634f;      // logits in the log2 domain: exp(x) = exp2(x log2 e)
 
     const int nkb = (p.T + KB - 1) / KB;
     constexpr int PIECES = KB * (D / 8);   // 16-byte pieces per operand block
@@ -141,35 +142,53 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
                 s[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s[kh], 0, 0, 0);
             }
         }
-        // ---- online softmax (query on the lane; this lane holds 32 of the 64 keys)
+        // ---- online softmax (query on the lane; this lane holds 32 of the 64 keys).  Round 4: the kernel is VALU-bound on the
+        // narrow heads (32 exponentials per lane and block beside 16 MFMAs), so the per-element work is trimmed: logits in the
+        // log2 domain (scale * log2(e) folded into one multiply, v_exp_f32 directly), the key mask only in a ragged last block,
+        // the accumulator rescale skipped when no lane's maximum moved.
         float mx = -INFINITY;
+        if ((kb + 1) * KB <= p.T) {
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
+            for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb * KB + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float v = (key < p.T) ? s[kh][r] * p.scale : -INFINITY;
-                s[kh][r] = v;
-                mx = fmaxf(mx, v);
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const float v = s[kh][r] * sc2;
+                    s[kh][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+        } else {
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * KB + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = (key < p.T) ? s[kh][r] * sc2 : -INFINITY;
+                    s[kh][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m, mx);
-        const float alpha = __expf(m - m_new);  // m = -inf on the first block -> 0
         float psum = 0.f;
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __expf(s[kh][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(s[kh][r] - m_new);
                 s[kh][r] = e;
                 psum += e;
             }
-        l = l * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(m_new != m) != 0) {      // some lane's running maximum moved: rescale (always on the first block)
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);  // m = -inf on the first block -> 0
+            l = l * alpha + psum;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        } else {
+            l += psum;
+        }
         m = m_new;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
 
         // ---- O^T += V^T . P^T ; 4 k-steps of 16 keys
 #pragma unroll

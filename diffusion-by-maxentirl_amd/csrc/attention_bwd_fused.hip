@@ -8,7 +8,7 @@
 // the other operand read through transposing loads in the accumulators' k order):
 //
 //   attn_bwd_dq_kernel   one workgroup = 128 queries of one (image, head), wave = 32 queries, lane = query.
-//       sweep 1 over the key blocks:  S^T = K Q^T, online (max, sum)  ->  L[q] = max + log(sum)   (log-sum-exp of the row)
+//       sweep 1 over the key blocks:  S^T = K Q^T, online (max, sum)  ->  L[q] = max + log2(sum)  (log-sum-exp of the row, log2 domain)
 //                                     delta[q] = <dO[q], O[q]>  (= sum_k P[q][k] dP[q][k])
 //       sweep 2:  S^T again, P^T = exp(scale S^T - L), dP^T = V dO^T, dS^T = P^T o (dP^T - delta),
 //                 dQ^T[d][q] += K^T dS^T        (A = K^T by transposing LDS loads, B = dS^T from the accumulators)
@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int h = lane >> 5;
     const int query = qb * 128 + wave * 32 + (lane & 31);
     const bool qvalid = query < p.T;
+    const float sc2 = p.scale * 1.4426950408889634f;      // logits in the log2 domain
 
     // B-operand fragments of this lane's query: elements d = ks*16 + 8h + j
     bf16x8 qf[AB_DK], dof[AB_DK];
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kb * AB_KB + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float v = (key < p.T) ? s[kh][r] * p.scale : -INFINITY;
+                const float v = (key < p.T) ? s[kh][r] * sc2 : -INFINITY;
                 s[kh][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -148,12 +149,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) psum += __expf(s[kh][r] - m_new);
-        l = l * __expf(m - m_new) + psum;
+            for (int r = 0; r < 16; ++r) psum += __builtin_amdgcn_exp2f(s[kh][r] - m_new);
+        l = l * __builtin_amdgcn_exp2f(m - m_new) + psum;
         m = m_new;
     }
     l += __shfl_xor(l, 32, 64);
-    const float lse = m + __logf(l);
+    const float lse = m + __log2f(l);          // log2 domain throughout (both kernels): P = exp2(sc2 S - L)
     if (qvalid && h == 0) {
         const size_t si = ((size_t)n * p.heads + hd) * p.T + query;
         p.lse[si] = lse;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kb * AB_KB + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float pv = (key < p.T) ? __expf(s[kh][r] * p.scale - lse) : 0.f;
+                const float pv = (key < p.T) ? __builtin_amdgcn_exp2f(s[kh][r] * sc2 - lse) : 0.f;
                 s[kh][r] = pv * (dp[kh][r] - delta);          // dS^T
             }
         }
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
     const int h = lane >> 5;
     const int key = kbk * 128 + wave * 32 + (lane & 31);
     const bool kvalid = key < p.T;
+    const float sc2 = p.scale * 1.4426950408889634f;
     const float* lse_g = p.lse + ((size_t)n * p.heads + hd) * p.T;
     const float* del_g = p.delta + ((size_t)n * p.heads + hd) * p.T;
 
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
-                    const float pv = __expf(s[qh][r] * p.scale - lv[e]);
+                    const float pv = __builtin_amdgcn_exp2f(s[qh][r] * sc2 - lv[e]);
                     s[qh][r] = pv;                                  // P
                     dp[qh][r] = pv * (dp[qh][r] - dl[e]);           // dS
                 }

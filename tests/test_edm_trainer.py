@@ -7,6 +7,9 @@ import numpy as np
 import pytest
 import torch
 
+# round 4: tightened from 5e-2 / 0.97 (measured: logs 8.4e-3, update cosines >= 0.9937; the GPU test prints them)
+LOG_TOL, UPDATE_COS = 1e-2, 0.99
+
 EDM_KW = dict(image_size=32, class_cond=True, learn_sigma=False, num_channels=64, num_res_blocks=1, channel_mult="1,2",
               num_heads=4, num_head_channels=64, num_heads_upsample=-1, attention_resolutions="16", dropout=0.0,
               use_checkpoint=False, use_scale_shift_norm=True, resblock_updown=True, use_fp16=True,
@@ -170,7 +173,8 @@ def test_hip_edm_trainer_step_vs_reference(golden_dir):
     opt.step = orig_step
     ge, gs = golden_logs(g, "energy"), golden_logs(g, "sampler")
     assert list(le.keys()) == list(ge.keys()) and list(ls.keys()) == list(gs.keys())
-    bad = [(k, got[k], ref[k]) for got, ref in ((le, ge), (ls, gs)) for k in ref if abs(got[k] - ref[k]) > 5e-2 * max(1.0, abs(ref[k]))]
+    bad = [(k, got[k], ref[k]) for got, ref in ((le, ge), (ls, gs)) for k in ref if abs(got[k] - ref[k]) > LOG_TOL * max(1.0, abs(ref[k]))]
+    print("edm trainer logs, worst relative deviation:", max(abs(got[k] - ref[k]) / max(1.0, abs(ref[k])) for got, ref in ((le, ge), (ls, gs)) for k in ref))
     assert not bad, bad
     np.testing.assert_allclose(trainer.betas_for_q.cpu().numpy(), g["betas_for_q"], rtol=5e-3)
     assert abs(mp.lg_loss_scale - float(g["lg_loss_scale_after"])) < 1e-9
@@ -189,9 +193,10 @@ def test_hip_edm_trainer_step_vs_reference(golden_dir):
     print("edm master gradients:", report)
     worst = [r for r in report if r[2] < 0.995 or abs(r[3] - 1) > 0.05]
     assert not worst, worst
+    print("edm update cosines:", [round(_cos((P[k].detach() - w0[k]).cpu().numpy(), g[f"delta_{i}"]), 4) for i, k in enumerate(pick)])
     for i, k in enumerate(pick):
         got, ref = (P[k].detach() - w0[k]).cpu().numpy(), g[f"delta_{i}"]
-        assert _cos(got, ref) > 0.97, (k, _cos(got, ref))
+        assert _cos(got, ref) > UPDATE_COS, (k, _cos(got, ref))
 
 
 @pytest.mark.gpu
