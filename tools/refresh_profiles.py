@@ -1,5 +1,5 @@
-"""Rebuild profiles/<tag>_* from the gpurun_out/ directories written by tools/r02_profile.sh / r03_profile.sh:
-    python tools/refresh_profiles.py r03"""
+"""Rebuild profiles/<tag>_* from the gpurun_out/ directories written by tools/r0N_profile.sh:
+    python tools/refresh_profiles.py r04"""
 import glob, json, os, shutil, subprocess, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 run = lambda *a: subprocess.run(["python", *a], capture_output=True, text=True).stdout
