@@ -505,3 +505,129 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
             for t in range(len(sigma)):
                 logs[f"sigma/sigma_{t}_"] = sigma[t]
         return self._to_floats(logs)
+
+
+class DxMI_Trainer_EV(DxMI_Trainer):
+    """Separate energy `f(x)` and time-dependent value `v(x, t)` (reference :865-1078; no config of the snapshot selects it).
+    The reference's arithmetic on the HIP modules: contrastive energy step on `f` with its gradient clipped at 0.1, T TD steps
+    whose transition is RE-DRAWN with `sampler.sample_step` (:976-978) and whose target is `v(x', t + 1)` for non-terminal
+    steps and `f(x')` for the last one, plus `tau2 * running_cost - tau1 * log sigma` (:985-987); policy step on one random
+    minibatch of buffered states per `n_generator` with the same mixed terminal value (:1037-1060).  Same helpers as
+    DxMI_Trainer: device-side index path (one stable sort instead of T `nonzero`s on the ring), device-side clip, one log sync,
+    flat RCCL gradient exchange; `f` and `v` are frozen inside the policy step (the reference accumulates and discards their
+    gradients)."""
+
+    def __init__(self, batchsize, tau1=0.0, tau2=0.0, q_beta_schedule="constant", q_beta_start=1.0, q_beta_end=1.0, adavelreg=None,
+                 n_timesteps=10, use_sampler_beta=False):
+        self.batchsize, self.n_timesteps = batchsize, n_timesteps
+        self.tau1, self.tau2 = tau1, tau2
+        self.q_beta_schedule, self.q_beta_start, self.q_beta_end = q_beta_schedule, q_beta_start, q_beta_end
+        self.adavelreg, self.use_sampler_beta = adavelreg, use_sampler_beta
+
+    def set_models(self, v, sampler, optimizer, optimizer_v, f=None, optimizer_fstar=None):
+        """reference :899-919 (note the argument order: v first)."""
+        self.f, self.v, self.sampler = f, v, sampler
+        self.optimizer, self.optimizer_fstar, self.optimizer_v = optimizer, optimizer_fstar, optimizer_v
+        from dxmi_hip.dist import FlatGradSync
+        self.sync_v = FlatGradSync(v) if v is not None else (lambda: None)
+        self.sync_f = FlatGradSync(f) if f is not None else (lambda: None)
+        self.sync_sampler = FlatGradSync(sampler) if sampler is not None else (lambda: None)
+        if self.use_sampler_beta:
+            net = self.sampler.net.module if hasattr(self.sampler.net, "module") else self.sampler.net
+            if hasattr(net, "log_betas"):
+                self.betas_for_q = torch.exp(net.log_betas).detach()
+        else:
+            self.betas_for_q = make_beta_schedule(schedule=self.q_beta_schedule, n_timesteps=self.n_timesteps,
+                                                  start=self.q_beta_start, end=self.q_beta_end)
+
+    def get_running_cost(self, state, next_state, t):           # reference :921-927
+        return DxMI_Trainer.get_running_cost(self, state, next_state, None, None, t)
+
+    def _terminal_mix(self, next_state, t):
+        """v(x', t + 1) where the step is not the last, f(x') where it is (:985-986, :1049-1050)."""
+        non_terminal = (t < self.n_timesteps - 1).float()
+        return self.v(next_state, t + 1).squeeze() * non_terminal + self.f(next_state).squeeze() * (1 - non_terminal)
+
+    def update_f_v(self, img, d_sample, state_dict):
+        """reference :945-1028."""
+        if self.adavelreg is not None:
+            self.update_adaptive_vel_reg(d_sample)
+        x0 = d_sample["l_sample"][-1]
+        n_steps, batchsize, device = self.n_timesteps, self.batchsize, img.device
+        self.optimizer_fstar.zero_grad()
+        self.f.train()
+        output = self.f(torch.cat((img.detach(), x0.detach()), 0))
+        pos_e, neg_e = output[:x0.shape[0]], output[x0.shape[0]:]
+        d_loss = pos_e.mean() - neg_e.mean()
+        d_loss.backward()
+        self.sync_f()
+        self._clip(self.f.parameters(), 0.1)
+        self.optimizer_fstar.step()
+        self.optimizer_fstar.zero_grad()
+        self.f.eval()
+        self.optimizer_v.zero_grad()
+        permutation = torch.randperm(batchsize * n_steps)                     # CPU generator, as the reference
+        indices = (permutation + (buffer_rows(state_dict) - batchsize * n_steps)).to(device)
+        rows_all, ts_all = self._td_rows(state_dict, indices, n_steps, batchsize)
+        d_running_cost = {}
+        running_cost = v_loss = None
+        for i in range(n_steps):
+            update_t = n_steps - i - 1
+            rows, timestep = rows_all[update_t], ts_all[update_t]
+            state = buffer_gather(state_dict, "state", rows)
+            with torch.no_grad():                                              # the target is detached (:990): result-neutral
+                d_step = self.sampler.sample_step(state, timestep)
+                next_state, pred_std = d_step["sample"], d_step["sigma"]
+                running_cost = self.get_running_cost(state, next_state, timestep)
+                entropy = torch.log(pred_std.squeeze())
+                self.v.eval()
+                target = self._terminal_mix(next_state, timestep) + running_cost * self.tau2 - entropy * self.tau1
+            self.v.train()
+            v_xt = self.v(state, timestep).squeeze()
+            v_loss = F.mse_loss(v_xt, target.detach())
+            v_loss.backward()
+            self.sync_v()
+            self.optimizer_v.step()
+            self.optimizer_v.zero_grad()
+            d_running_cost[f"running_cost/step_{update_t}_"] = running_cost.detach().mean()
+        logs = {"ebm/d_loss_": d_loss.detach(), "ebm/v_loss_": v_loss.detach(), "ebm/pos_e_": pos_e.detach().mean(),
+                "ebm/neg_e_": neg_e.detach().mean(), "ebm/running_cost_": running_cost.detach().mean()}
+        logs.update(d_running_cost)
+        if self.adavelreg is not None:
+            for t, beta in enumerate(self.betas_for_q):
+                logs[f"adavelreg/beta_for_q_{t}_"] = beta
+        return self._to_floats(logs)
+
+    def update_sampler(self, state_dict, n_generator):
+        """reference :1030-1078."""
+        self.f.eval()
+        self.v.eval()
+        self.sampler.train()
+        permutation = torch.randperm(buffer_rows(state_dict))
+        batchsize = self.batchsize
+        n_data = min(len(permutation), batchsize * n_generator)
+        device = state_dict.device if isinstance(state_dict, TransitionRing) else state_dict["state"].device
+        for m in range(0, n_data, batchsize):
+            self.optimizer.zero_grad()
+            indices = permutation[m:m + batchsize].to(device)
+            state = buffer_gather(state_dict, "state", indices)
+            t = buffer_gather(state_dict, "timestep", indices)
+            d_step = self.sampler.sample_step(state, t)
+            next_state, pred_std = d_step["sample"], d_step["sigma"]
+            running_cost = self.get_running_cost(state, next_state, t).mean()
+            causal_entropy = torch.log(pred_std.squeeze()).mean()
+            with self._frozen(self.v), self._frozen(self.f):
+                sampler_value_loss = self._terminal_mix(next_state, t).mean()
+            sampler_loss = sampler_value_loss + running_cost * self.tau2 - causal_entropy * self.tau1
+            sampler_loss.backward()
+            self.sync_sampler()
+            self._clip(self.sampler.parameters(), 0.1)
+            self.optimizer.step()
+        logs = {"sampler/sampler_loss_": sampler_loss.detach(), "sampler/sampler_value_loss_": sampler_value_loss.detach(),
+                "sampler/running_cost_": running_cost.detach(), "sampler/causal_entropy_": causal_entropy.detach()}
+        if self.sampler.trainable_beta:
+            net = self.sampler.net.module if hasattr(self.sampler.net, "module") else self.sampler.net
+            betas = torch.exp(net.log_betas.detach())
+            for t in range(len(betas)):
+                logs[f"beta/beta_{t}_"] = betas[t]
+        return self._to_floats(logs)

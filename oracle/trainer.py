@@ -168,3 +168,93 @@ class OracleDxMI:
         for k, s in enumerate(torch.exp(self.net["log_betas"].detach())):
             logs[f"sigma/sigma_{k}_"] = s.item()
         return logs
+
+
+class OracleDxMI_EV(OracleDxMI):
+    """models/DxMI/trainer.py:865-1078 (DxMI_Trainer_EV): a separate energy f(x) next to the value v(x, t).  `energy_sd` holds
+    the IGEBMEncoderV2 weights of f without the value wrapper's "net." prefix; v is the time-independent wrapper of the same
+    architecture (t is ignored, models/value.py:8-12).  Differences from the parent are the reference's own: the contrastive
+    step runs on f with its gradient clipped at 0.1 and no regulariser (:956-973); every TD step re-draws the transition with
+    `sample_step` (:976-978, gradient enabled but cut by the detached target) and its target is v(x', t+1) for the non-terminal
+    steps, f(x') for the last, plus tau2 * running_cost - tau1 * log sigma (:983-987); the policy step uses the same mixed
+    terminal value (:1047-1056); log keys as in :1003-1017 and :1062-1076."""
+
+    def __init__(self, net_sd, value_sd, energy_sd, sched, B, T, f_lr=1e-5, **kw):
+        super().__init__(net_sd, value_sd, sched, B, T, **kw)
+        self.fsd = {k: v.clone().requires_grad_(True) for k, v in energy_sd.items()}
+        self.opt_f = torch.optim.Adam(list(self.fsd.values()), lr=f_lr)
+        self.betas_for_q = torch.exp(self.net["log_betas"]).detach()              # :912-914 (use_sampler_beta)
+
+    def f(self, x):
+        return ovalue.forward(self.fsd, x, self.prec, prefix="")
+
+    def _mix(self, next_state, t):
+        non_terminal = (t < self.T - 1).float()
+        return self.v(next_state).squeeze() * non_terminal + self.f(next_state).squeeze() * (1 - non_terminal)
+
+    def update_f_v(self, img, d, buf):
+        samples = torch.stack(d["l_sample"])
+        diff = ((samples[1:] - samples[:-1]) ** 2).view(samples.shape[0] - 1, -1).mean(dim=1).flip(0)
+        self.betas_for_q = (self.betas_for_q * self.adavelreg + (1 - self.adavelreg) * diff).detach()
+        x0 = d["l_sample"][-1]
+        self.opt_f.zero_grad()
+        out = self.f(torch.cat((img.detach(), x0.detach()), 0))
+        pos_e, neg_e = out[:x0.shape[0]], out[x0.shape[0]:]
+        d_loss = pos_e.mean() - neg_e.mean()
+        d_loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(self.fsd.values()), 0.1)
+        if self.record is not None:
+            self.record["f_grads"] = {k: p.grad.detach().clone() for k, p in self.fsd.items()}
+        self.opt_f.step()
+        self.opt_f.zero_grad()
+        self.opt_v.zero_grad()
+        T, B = self.T, self.B
+        permutation = torch.randperm(B * T)
+        indices = permutation + (buf["state"].shape[0] - B * T)
+        d_rc = {}
+        for i in range(T):
+            update_t = T - i - 1
+            train_indices = torch.nonzero(buf["timestep"][indices] == update_t).flatten()
+            state = buf["state"][indices][train_indices]
+            timestep = buf["timestep"][indices][train_indices]
+            ds = ovs.sample_step(self.unet, self.sched, self.net["log_betas"], state, timestep, torch.randn_like(state))
+            next_state = ds["sample"]
+            rc = self.running_cost(state, next_state, timestep)
+            ent = torch.log(ds["sigma"].squeeze())
+            target = self._mix(next_state, timestep) + rc * self.tau2 - ent * self.tau1
+            v_xt = self.v(state).squeeze()
+            v_loss = F.mse_loss(v_xt, target.detach())
+            for p in self.val.values():
+                p.grad = None
+            v_loss.backward(inputs=list(self.val.values()))
+            self._rec_v()
+            self.opt_v.step()
+            self.opt_v.zero_grad()
+            d_rc[f"running_cost/step_{update_t}_"] = rc.mean().item()
+        logs = {"ebm/d_loss_": d_loss.item(), "ebm/v_loss_": v_loss.item(), "ebm/pos_e_": pos_e.mean().item(),
+                "ebm/neg_e_": neg_e.mean().item(), "ebm/running_cost_": rc.mean().item()}
+        logs.update(d_rc)
+        for t, b in enumerate(self.betas_for_q):
+            logs[f"adavelreg/beta_for_q_{t}_"] = b.item()
+        return logs
+
+    def update_sampler(self, buf, z):
+        permutation = torch.randperm(buf["state"].shape[0])
+        self.opt.zero_grad()
+        idx = permutation[: self.B]
+        state, t = buf["state"][idx], buf["timestep"][idx]
+        d = ovs.sample_step(self.unet, self.sched, self.net["log_betas"], state, t, z)
+        rc = self.running_cost(state, d["sample"], t).mean()
+        ent = torch.log(d["sigma"].squeeze()).mean()
+        sv = self._mix(d["sample"], t).mean()
+        loss = sv + rc * self.tau2 - ent * self.tau1
+        loss.backward(inputs=[p for p in self.net.values() if p.requires_grad])
+        torch.nn.utils.clip_grad_norm_([p for k, p in self.net.items() if p.requires_grad], 0.1)
+        if self.record is not None:
+            self.record["net_grads"] = {k: p.grad.detach().clone() for k, p in self.net.items() if p.grad is not None}
+        self.opt.step()
+        logs = {"sampler/sampler_loss_": loss.item(), "sampler/sampler_value_loss_": sv.item(),
+                "sampler/running_cost_": rc.item(), "sampler/causal_entropy_": ent.item()}
+        for k, s in enumerate(torch.exp(self.net["log_betas"].detach())):
+            logs[f"beta/beta_{k}_"] = s.item()
+        return logs

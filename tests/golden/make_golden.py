@@ -34,7 +34,13 @@ tv.transforms = tvt
 # call calculate_frechet_distance, which touches none of them): any attribute of the stub is torch.nn.Module
 tvm = types.ModuleType("torchvision.models")
 tvmi = types.ModuleType("torchvision.models.inception")
-tvmi.__getattr__ = lambda name: torch.nn.Module
+def _tv_inception_attr(name):
+    if name.startswith("__"):          # __file__, __path__ ...: torch._dynamo inspects modules it finds in sys.modules
+        raise AttributeError(name)
+    return torch.nn.Module
+
+
+tvmi.__getattr__ = _tv_inception_attr
 tvm.inception = tvmi
 tv.models = tvm
 sys.modules.setdefault("torchvision", tv)
@@ -258,6 +264,58 @@ def gen_trainer_step_T4_resample():
     _trainer_step("trainer_step_T4_resample", 4, 4, 1357, 556, tau1=0.1, tau2=0.01, gamma=1, use_sampler_beta=True,
                   time_cost=0, time_cost_sig=1, entropy_in_value=None, velocity_in_value=None, value_resample=True,
                   adavelreg=0.99)
+
+
+def gen_trainer_ev():
+    """One full reference DxMI_Trainer_EV step (trainer.py:865-1078: separate energy f, value v(x, t)) at B=4, T=4 on the
+    DDPM backbone: f = IGEBMEncoderV2, v = TimeIndependentValue(IGEBMEncoderV2) (the time-dependent value nets the class was
+    written for are not in the snapshot; any v(x, t) plugs in), dropout 0, CPU generator seeded as in _trainer_step."""
+    import models.DxMI.trainer as ref_tr
+    T, B, seed = 4, 4, 97531
+    torch.manual_seed(0)
+    kw = dict(UNET_KW)
+    kw["dropout"] = 0.0
+    net = ref_unet.Model(**kw)
+    sampler = ref_vs.VARSampler(net, T, [3, 32, 32], trainable_beta="fix_last")
+    net.load_state_dict(formula_state_dict(net.state_dict()))
+    v = build_value()
+    f = ref_modules.IGEBMEncoderV2(in_chan=3, out_chan=1, use_spectral_norm=False, keepdim=False, out_activation="linear",
+                                   avg_pool_dim=1, learn_out_scale=True, nh=128)
+    from oracle.weights import formula_tensor
+    f.load_state_dict({k: formula_tensor("energy." + k, t.shape).to(t.dtype) for k, t in f.state_dict().items()})      # != v's weights
+    params_not_beta = [p for n, p in net.named_parameters() if "log_betas" not in n]
+    opt = torch.optim.Adam([{"params": net.log_betas, "lr": 1e-5}, {"params": params_not_beta, "lr": 1e-7}])
+    opt_v = torch.optim.Adam(v.parameters(), lr=1e-5)
+    opt_f = torch.optim.Adam(f.parameters(), lr=1e-5)
+    trainer = ref_tr.DxMI_Trainer_EV(batchsize=B, tau1=0.1, tau2=0.01, adavelreg=0.99, n_timesteps=T, use_sampler_beta=True)
+    trainer.set_models(v=v, sampler=sampler, optimizer=opt, optimizer_v=opt_v, f=f, optimizer_fstar=opt_f)
+    g = torch.Generator().manual_seed(557)
+    img = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    torch.manual_seed(seed)
+    sampler.eval()
+    d_sample = sampler.sample(B, device="cpu")
+    buf = ref_tr.append_buffer(ref_tr.reset_buffer("cpu"), d_sample)
+    w0 = {n: p.detach().clone() for n, p in net.named_parameters()}
+    v0 = {n: p.detach().clone() for n, p in v.named_parameters()}
+    f0 = {n: p.detach().clone() for n, p in f.named_parameters()}
+    d_energy = trainer.update_f_v(img, d_sample, buf)
+    d_sampler = trainer.update_sampler(buf, 1)
+    named, vnamed, fnamed = dict(net.named_parameters()), dict(v.named_parameters()), dict(f.named_parameters())
+    extra = {}
+    for i, (n, c) in enumerate(NET_PICK):
+        extra[f"net_grad_{i}"] = _cut(named[n].grad, c)
+        extra[f"net_delta_{i}"] = _cut(named[n].detach() - w0[n], c)
+    for i, (n, c) in enumerate(VAL_PICK):
+        extra[f"val_delta_{i}"] = _cut(vnamed[n].detach() - v0[n], c)
+        fn = n[len("net."):]
+        extra[f"f_delta_{i}"] = _cut(fnamed[fn].detach() - f0[fn], c)
+    save("trainer_ev_step", seed=seed, B=B, T=T, img=img,
+         energy_keys=np.array(list(d_energy.keys())), energy_vals=np.array(list(d_energy.values()), dtype=np.float64),
+         sampler_keys=np.array(list(d_sampler.keys())), sampler_vals=np.array(list(d_sampler.values()), dtype=np.float64),
+         betas_for_q=trainer.betas_for_q, log_betas_after=net.state_dict()["log_betas"],
+         net_pick=np.array([n for n, _ in NET_PICK]), net_pick_rows=np.array([-1 if c is None else c for _, c in NET_PICK]),
+         val_pick=np.array([n for n, _ in VAL_PICK]), val_pick_rows=np.array([-1 if c is None else c for _, c in VAL_PICK]),
+         **extra)
 
 
 def gen_log_prob_step():
@@ -493,7 +551,7 @@ def gen_fid():
     save("fid_stats", **out)
 
 
-GENS = {"fid": gen_fid, "schedule": gen_schedule, "unet": gen_unet_forward, "var_sampling": gen_var_sampling,
+GENS = {"trainer_ev": gen_trainer_ev, "fid": gen_fid, "schedule": gen_schedule, "unet": gen_unet_forward, "var_sampling": gen_var_sampling,
         "sample_step": gen_sample_step, "value": gen_value, "trainer": gen_trainer_step, "trainer_T4": gen_trainer_step_T4_resample, "log_prob": gen_log_prob_step, "output": gen_output_stage, "guidance": gen_guidance, "edm": gen_edm, "edm_trainer": gen_edm_trainer}
 
 if __name__ == "__main__":

@@ -104,6 +104,68 @@ def test_oracle_trainer_step_matches_reference(golden_dir, fixture):
     np.testing.assert_allclose(rec["net_grads"]["log_betas"].numpy(), g["log_betas_grad"], rtol=2e-3, atol=1e-9)
 
 
+def build_energy():
+    """f of DxMI_Trainer_EV: the IGEBM encoder without the value wrapper, weights from formula_tensor("energy." + key)."""
+    from models.modules import IGEBMEncoderV2
+    from oracle.weights import formula_tensor
+    f = IGEBMEncoderV2(in_chan=3, out_chan=1, use_spectral_norm=False, keepdim=False, out_activation="linear", avg_pool_dim=1,
+                       learn_out_scale=True, nh=128)
+    f.load_state_dict({k: formula_tensor("energy." + k, t.shape) for k, t in f.state_dict().items()})
+    return f
+
+
+def test_oracle_trainer_ev_step_matches_reference(golden_dir):
+    """OracleDxMI_EV against one step of the reference's DxMI_Trainer_EV (trainer.py:865-1078; separate energy f, mixed
+    terminal value, re-drawn TD transitions) at B=4, T=4: every logged scalar, the adaptive q-betas, log_betas after the
+    policy step, the clipped U-Net gradients and the Adam updates of v and f."""
+    from oracle import schedule as osched
+    from oracle.trainer import OracleDxMI_EV
+    import oracle.var_sampler as ovs
+    torch.set_num_threads(8)
+    g = load(golden_dir, "trainer_ev_step")
+    B, T = int(g["B"]), int(g["T"])
+    net, sampler, v = build_models(T)
+    f = build_energy()
+    s = osched.var_schedule(T)
+    sched = {k: torch.from_numpy(np.asarray(val, dtype=np.float32)) for k, val in s.items() if k != "user_defined_eta"}
+    rec = {}
+    o = OracleDxMI_EV({k: t.detach() for k, t in net.state_dict().items()}, {k: t.detach() for k, t in v.state_dict().items()},
+                      {k: t.detach() for k, t in f.state_dict().items()}, sched, B, T, eta=s["user_defined_eta"], record=rec)
+    v0 = {k: t.detach().clone() for k, t in o.val.items()}
+    f0 = {k: t.detach().clone() for k, t in o.fsd.items()}
+    img = torch.from_numpy(g["img"])
+    torch.manual_seed(int(g["seed"]))
+    noise = [torch.randn(B, 3, 32, 32) for _ in range(T + 1)]
+    d = o.sample(noise)
+    buf = o.append_buffer(o.reset_buffer(), d)
+    le = o.update_f_v(img, d, buf)
+    orig = ovs.sample_step
+
+    def patched(net_fn, sched_, lb, x, t, zz, **kw):          # the policy step's randn_like, drawn after its randperm
+        return orig(net_fn, sched_, lb, x, t, torch.randn_like(x), **kw)
+    ovs.sample_step = patched
+    try:
+        ls = o.update_sampler(buf, None)
+    finally:
+        ovs.sample_step = orig
+    ge, gs = golden_logs(g, "energy"), golden_logs(g, "sampler")
+    assert list(le.keys()) == list(ge.keys()) and list(ls.keys()) == list(gs.keys())
+    for got, ref in ((le, ge), (ls, gs)):
+        for k in ref:
+            assert abs(got[k] - ref[k]) <= 2e-4 * max(1.0, abs(ref[k])), (k, got[k], ref[k])
+    np.testing.assert_allclose(o.betas_for_q.numpy(), g["betas_for_q"], rtol=1e-5)
+    np.testing.assert_allclose(o.net["log_betas"].detach().numpy(), g["log_betas_after"], rtol=1e-5, atol=1e-6)
+    for i, got in enumerate(_pick(rec["net_grads"], g["net_pick"], g["net_pick_rows"])):
+        ref = g[f"net_grad_{i}"]
+        assert _cos(got, ref) > 0.9999 and abs(np.linalg.norm(got) / np.linalg.norm(ref) - 1) < 5e-3, g["net_pick"][i]
+    # Adam updates (T steps on v, one clipped step on f): direction of the update = sign pattern of the gradients
+    for i, got in enumerate(_pick({k: o.val[k].detach() - v0[k] for k in v0}, g["val_pick"], g["val_pick_rows"])):
+        assert _cos(got, g[f"val_delta_{i}"]) > 0.999, ("v", g["val_pick"][i], _cos(got, g[f"val_delta_{i}"]))
+    fnames = [str(n)[len("net."):] for n in g["val_pick"]]
+    for i, got in enumerate(_pick({k: o.fsd[k].detach() - f0[k] for k in f0}, fnames, g["val_pick_rows"])):
+        assert _cos(got, g[f"f_delta_{i}"]) > 0.999, ("f", fnames[i], _cos(got, g[f"f_delta_{i}"]))
+
+
 def test_buffer_and_td_indexing_match_reference_expressions():
     """Product host logic (CPU): append_buffer layout and the single-gather TD row selection equal the
     reference's torch.cat-per-step layout and `buf[key][indices][train_indices]` double index."""
@@ -238,6 +300,67 @@ def test_hip_trainer_step_vs_reference(golden_dir, fixture, fused):
     lb = net.log_betas.detach().cpu().numpy()
     assert np.allclose(lb, g["log_betas_after"], atol=3e-5), (lb, g["log_betas_after"])
     print(f"{fixture}:", ", ".join(f"{r[0]}={r[1]:.4f}" for r in report))
+
+
+@pytest.mark.gpu
+def test_hip_trainer_ev_step_vs_reference(golden_dir):
+    """DxMI_Trainer_EV on the HIP modules against the reference's golden step (trainer.py:865-1078), shipped optimisers
+    (dxmi_hip.optim.Adam).  bf16 activations / gradients against the reference's fp32: logged scalars within 5e-2 relative
+    (|.|<1: absolute), betas_for_q 2e-3, log_betas 3e-5; clipped U-Net gradients by cosine > 0.995 and norm within 5 %;
+    update directions of the U-Net, of v (T Adam steps) and of f (one clipped Adam step) by cosine > 0.97."""
+    from models.DxMI.trainer import DxMI_Trainer_EV, append_buffer, reset_buffer
+    from dxmi_hip.optim import Adam
+    DEV = "cuda:0"
+    g = load(golden_dir, "trainer_ev_step")
+    B, T = int(g["B"]), int(g["T"])
+    net, sampler, v = build_models(T)
+    f = build_energy().to(DEV)
+    sampler, v = sampler.to(DEV), v.to(DEV)
+    params_not_beta = [p for n, p in net.named_parameters() if "log_betas" not in n]
+    opt = Adam([{"params": net.log_betas, "lr": 1e-5}, {"params": params_not_beta, "lr": 1e-7}])
+    opt_v, opt_f = Adam(v.parameters(), lr=1e-5), Adam(f.parameters(), lr=1e-5)
+    trainer = DxMI_Trainer_EV(batchsize=B, tau1=0.1, tau2=0.01, adavelreg=0.99, n_timesteps=T, use_sampler_beta=True)
+    trainer.set_models(v=v, sampler=sampler, optimizer=opt, optimizer_v=opt_v, f=f, optimizer_fstar=opt_f)
+    np.testing.assert_allclose(trainer.betas_for_q.cpu().numpy(), np.exp(net.log_betas.detach().cpu().numpy()), rtol=1e-6)
+    img = torch.from_numpy(g["img"]).to(DEV)
+    torch.manual_seed(int(g["seed"]))
+    noise = [torch.randn(B, 3, 32, 32) for _ in range(T + 1)]
+    sampler.eval()
+    d = sampler.sample(B, device=DEV, noise=noise)
+    buf = append_buffer(reset_buffer(DEV), d)
+    nnamed, vnamed, fnamed = dict(net.named_parameters()), dict(v.named_parameters()), dict(f.named_parameters())
+    w0 = {n: p.detach().clone() for n, p in nnamed.items()}
+    v0 = {n: p.detach().clone() for n, p in vnamed.items()}
+    f0 = {n: p.detach().clone() for n, p in fnamed.items()}
+    orig = sampler.sample_step
+    sampler.sample_step = lambda x, t, y=None: orig(x, t, noise=torch.randn(x.shape).to(x.device))   # the reference's CPU draws
+    le = trainer.update_f_v(img, d, buf)
+    ls = trainer.update_sampler(buf, 1)
+    ge, gs = golden_logs(g, "energy"), golden_logs(g, "sampler")
+    assert list(le.keys()) == list(ge.keys()) and list(ls.keys()) == list(gs.keys())
+    bad = [(k, got[k], ref[k]) for got, ref in ((le, ge), (ls, gs)) for k in ref if abs(got[k] - ref[k]) > 5e-2 * max(1.0, abs(ref[k]))]
+    assert not bad, bad
+    np.testing.assert_allclose(trainer.betas_for_q.cpu().numpy(), g["betas_for_q"], rtol=2e-3)
+    assert np.allclose(net.log_betas.detach().cpu().numpy(), g["log_betas_after"], atol=3e-5)
+    report = []
+    for i, got in enumerate(_pick({n: p.grad for n, p in nnamed.items()}, g["net_pick"], g["net_pick_rows"])):
+        c, nr = _cos(got, g[f"net_grad_{i}"]), np.linalg.norm(got) / np.linalg.norm(g[f"net_grad_{i}"])
+        report.append((f"net/{g['net_pick'][i]}", c))
+        assert c > 0.995 and abs(nr - 1) < 0.05, (g["net_pick"][i], c, nr)
+    for i, got in enumerate(_pick({n: p.detach() - w0[n] for n, p in nnamed.items()}, g["net_pick"], g["net_pick_rows"])):
+        c = _cos(got, g[f"net_delta_{i}"])
+        report.append((f"net-update/{g['net_pick'][i]}", c))
+        assert c > 0.97, (g["net_pick"][i], c)
+    for i, got in enumerate(_pick({n: p.detach() - v0[n] for n, p in vnamed.items()}, g["val_pick"], g["val_pick_rows"])):
+        c = _cos(got, g[f"val_delta_{i}"])
+        report.append((f"v-update/{g['val_pick'][i]}", c))
+        assert c > 0.97, (g["val_pick"][i], c)
+    fnames = [str(n)[len("net."):] for n in g["val_pick"]]
+    for i, got in enumerate(_pick({n: p.detach() - f0[n] for n, p in fnamed.items()}, fnames, g["val_pick_rows"])):
+        c = _cos(got, g[f"f_delta_{i}"])
+        report.append((f"f-update/{fnames[i]}", c))
+        assert c > 0.97, (fnames[i], c)
+    print("trainer_ev_step:", ", ".join(f"{r[0]}={r[1]:.4f}" for r in report))
 
 
 def test_oracle_sample_guidance_matches_reference(golden_dir):
