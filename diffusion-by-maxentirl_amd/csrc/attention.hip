@@ -37,8 +37,11 @@ struct AttnArgs {
     float* gn_stats;        // optional: GroupNorm block statistics of the output, [N][8][128][2] (a partial per 32 tokens)
 };
 
+#ifndef ATTN_WPE
+#define ATTN_WPE 3
+#endif
 template <int D, bool PF>
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, D == 64 ? ATTN_WPE : 1) void attention_kernel(AttnArgs p) {
     constexpr int KB = 64;               // keys per block
     constexpr int DK = D / 16;           // k-steps over d
     constexpr int DB = D / 32;           // 32-row blocks of O^T

@@ -1,6 +1,7 @@
 // C-ABI glue: error text, version, device probe.  No torch types, no exceptions.
 #include "common.h"
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -15,6 +16,53 @@ void dxmi_set_error(const char* fmt, ...) {
 extern "C" const char* dxmi_last_error(void) { return g_err; }
 
 extern "C" int dxmi_version(void) { return 100; }
+
+// Kernel-selection knobs (dxmi_set_tuning / dxmi_get_tuning): process-wide, first read from the environment.
+namespace {
+struct Knob {
+    const char* name;
+    const char* env;
+    int value;
+    bool init;
+};
+Knob g_knobs[] = {
+    {"conv_ws_min_tiles", "DXMI_CONV_WS_MIN_TILES", 96, false},   // conv_ws.hip: fewer (256-pixel, 128-cout) tiles -> conv_pipe_kernel
+    {"conv_sm_mask", "DXMI_CONV_SM", 5, false},                   // conv_sm.hip: bit 0 4x4 maps, bit 1 every 8x8 map, bit 2 8x8 maps on under-filled grids
+};
+Knob* find_knob(const char* name) {
+    if (!name) return nullptr;
+    for (Knob& k : g_knobs)
+        if (strcmp(k.name, name) == 0) {
+            if (!k.init) {
+                const char* e = getenv(k.env);
+                if (e) k.value = atoi(e);
+                k.init = true;
+            }
+            return &k;
+        }
+    return nullptr;
+}
+}  // namespace
+
+int dxmi_tuning(const char* name) {       // internal: the launch paths read their knob through this
+    Knob* k = find_knob(name);
+    return k ? k->value : 0;
+}
+
+extern "C" int dxmi_set_tuning(const char* name, int32_t value) {
+    Knob* k = find_knob(name);
+    DXMI_CHECK_ARG(k != nullptr, "dxmi_set_tuning: unknown knob '%s'", name ? name : "(null)");
+    DXMI_CHECK_ARG(value >= 0, "dxmi_set_tuning: %s = %d must be >= 0", name, value);
+    k->value = value;
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_get_tuning(const char* name, int32_t* value) {
+    Knob* k = find_knob(name);
+    DXMI_CHECK_ARG(k != nullptr && value != nullptr, "dxmi_get_tuning: unknown knob '%s' / null result pointer", name ? name : "(null)");
+    *value = k->value;
+    return DXMI_OK;
+}
 
 extern "C" int dxmi_device_check(void) {
     int n = 0;

@@ -718,6 +718,12 @@ int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     const int nchunks = (a.C0 + a.C1) / 32;
     if ((9 * nchunks) % WS_RING != 0 || nchunks % 2 != 0) return 1;   // ring slot / halo image of a step must not depend on the tile
     if (nchunks < 4) return 1;   // the tile switch is spread over nchunks-1 chunks at <= 12 pieces per chunk
+    // fewer (256-pixel, 128-cout) tiles than ~a third of the CUs (the EDM nets' 16x16 maps at the train batch of 16: 80 tiles):
+    // conv_pipe_kernel's 64-pixel tiles fill the chip better (576 -> 576 @16x16, B = 16: 48.1 us here, 41.1 us there; at 192
+    // tiles this kernel is 40 % ahead)
+    // (knob "conv_ws_min_tiles" / DXMI_CONV_WS_MIN_TILES; the kernel's own edge-case tests set it to 0)
+    const int min_tiles = dxmi_tuning("conv_ws_min_tiles");
+    if ((long)a.N * (a.OH / TH) * (a.OW / TW) * ((a.Cout + 127) / 128) < min_tiles) return 1;
     // 32-bit byte offsets inside either input part (the movers' per-tile source tables)
     if ((long)a.N * a.IH * a.IW * (a.C0 > a.C1 ? a.C0 : a.C1) * 2 >= (1L << 31)) return 1;
     if (kernel_id) {

@@ -39,6 +39,8 @@ SIGNATURES = {
     "dxmi_last_error": (ctypes.c_char_p, []),
     "dxmi_version": (c_int, []),
     "dxmi_device_check": (c_int, []),
+    "dxmi_set_tuning": (c_int, [ctypes.c_char_p, c_int]),
+    "dxmi_get_tuning": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_int)]),
     "dxmi_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
     "dxmi_conv2d_kernel_id": (c_int, [ctypes.POINTER(ConvDesc)]),
     "dxmi_conv2d_gn_stats_partials": (c_int, [ctypes.POINTER(ConvDesc)]),

@@ -36,6 +36,19 @@ def device_check():
     check(load().dxmi_device_check(), "dxmi_device_check")
 
 
+def set_tuning(name, value):
+    """Kernel-selection knob of the library (include/dxmi_hip.h: dxmi_set_tuning); returns the previous value."""
+    old = get_tuning(name)
+    check(load().dxmi_set_tuning(name.encode(), int(value)), "dxmi_set_tuning")
+    return old
+
+
+def get_tuning(name):
+    v = ctypes.c_int(0)
+    check(load().dxmi_get_tuning(name.encode(), ctypes.byref(v)), "dxmi_get_tuning")
+    return v.value
+
+
 class PackedConvWeight:
     """bf16 MFMA-fragment-ordered copy of an OIHW fp32 weight."""
 

@@ -52,6 +52,15 @@ const char* dxmi_last_error(void);
 int dxmi_version(void);
 /* 0 when a gfx950 device is usable; DXMI_ENODEV otherwise (never falls back to CPU). */
 int dxmi_device_check(void);
+/* Kernel-selection knobs (process-wide; initial value from the environment variable in brackets).  They choose between kernels
+ * that compute the same convolution, never a result-changing mode; unknown names return DXMI_EINVAL.
+ *   "conv_ws_min_tiles" [DXMI_CONV_WS_MIN_TILES, 96]: 3x3 convs with fewer (256-pixel, 128-cout) tiles run on the 64-pixel-tile
+ *                        kernel instead of the wave-specialised one (small batches leave most CUs without a tile);
+ *   "conv_sm_mask"      [DXMI_CONV_SM, 5]: bit 0 4x4 maps, bit 1 every 8x8 map, bit 2 8x8 maps whose 256-pixel-tile grid is
+ *                        under-filled, on the feed-tiled small-map kernel.
+ * No reference counterpart (the reference leaves algorithm choice to cuDNN). */
+int dxmi_set_tuning(const char* name, int32_t value);
+int dxmi_get_tuning(const char* name, int32_t* value);
 
 /* ------------------------------------------------------------------------------------------
  * Convolution as MFMA implicit GEMM (bf16 operands, fp32 accumulate), fused epilogue.

@@ -134,6 +134,22 @@ int main(void) {
     if (dxmi_fid_stats_workspace_bytes(-5, 64) != 0 || dxmi_fid_stats_workspace_bytes(100, -64) != 0) { printf("FAIL fid_stats_workspace_bytes(bad)\n"); ++failures; }
     else printf("ok   fid_stats_workspace_bytes(bad) == 0\n");
 
+    /* ---- kernel-selection knobs ---------------------------------------------------------------------------------- */
+    {
+        int32_t v = -1;
+        expect_einval("set_tuning(NULL name)", dxmi_set_tuning(NULL, 1));
+        expect_einval("set_tuning(unknown knob)", dxmi_set_tuning("no_such_knob", 1));
+        expect_einval("set_tuning(negative value)", dxmi_set_tuning("conv_ws_min_tiles", -3));
+        expect_einval("get_tuning(NULL result)", dxmi_get_tuning("conv_ws_min_tiles", NULL));
+        expect_einval("get_tuning(unknown knob)", dxmi_get_tuning("", &v));
+        if (dxmi_set_tuning("conv_ws_min_tiles", 7) != 0 || dxmi_get_tuning("conv_ws_min_tiles", &v) != 0 || v != 7) { printf("FAIL tuning round trip\n"); ++failures; }
+        else printf("ok   set_tuning / get_tuning round trip\n");
+        d = good_conv();                /* 16 tiles: the knob decides between the two kernels, neither may touch the fake pointers */
+        dxmi_set_tuning("conv_ws_min_tiles", 0);
+        expect_negative("conv2d_fwd(valid desc on the wave-specialised kernel, no device)", dxmi_conv2d_fwd(&d, NULL));
+        dxmi_set_tuning("conv_ws_min_tiles", 96);
+    }
+
     printf("%d failure(s)\n", failures);
     return failures > 99 ? 99 : failures;
 }

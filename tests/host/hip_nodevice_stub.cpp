@@ -14,7 +14,9 @@ void** __hipRegisterFatBinary(const void*) { return &g_module; }
 void __hipUnregisterFatBinary(void**) {}
 void __hipRegisterFunction(void**, const void*, char*, const char*, unsigned int, void*, void*, void*, void*, int*) {}
 void __hipRegisterVar(void**, void*, char*, char*, int, size_t, int, int) {}
-hipError_t __hipPushCallConfiguration(dim3, dim3, size_t, hipStream_t) { return hipSuccess; }
+// a launch fails where it starts: the configuration push reports the missing device (the kernel's host stub is then skipped,
+// as `kernel<<<...>>>(...)` prescribes) and hipGetLastError() hands the error to DXMI_CHECK_LAUNCH
+hipError_t __hipPushCallConfiguration(dim3, dim3, size_t, hipStream_t) { return g_last = hipErrorNoDevice; }
 hipError_t __hipPopCallConfiguration(dim3* g, dim3* b, size_t* s, hipStream_t* st) {
     *g = dim3(1); *b = dim3(1); *s = 0; *st = nullptr;
     return hipSuccess;

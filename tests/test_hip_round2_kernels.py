@@ -18,6 +18,16 @@ def ops():
     o.device_check()
     return o
 
+@pytest.fixture(scope="module", autouse=True)
+def kernels_under_test(ops):
+    """These cases put deliberately small grids (one tile, a handful of images) on the wave-specialised kernels: switch off the
+    library's small-grid re-routing (include/dxmi_hip.h: dxmi_set_tuning) for this module; test_small_grid_routing covers it."""
+    old = ops.set_tuning("conv_ws_min_tiles", 0), ops.set_tuning("conv_sm_mask", 1)
+    yield
+    ops.set_tuning("conv_ws_min_tiles", old[0])
+    ops.set_tuning("conv_sm_mask", old[1])
+
+
 
 def bf(x):
     return x.to(torch.bfloat16).to(torch.float32)
@@ -143,6 +153,29 @@ def test_conv1x1_rw(ops, N, C0, C1, Cout, H, fuse):
     y, ref, kid = run_conv(ops, N, C0, C1, Cout, H, 1, False, fuse)
     assert kid >= 500000, f"expected conv1x1_rw_kernel, got kernel id {kid}"
     assert rel_l2(nchw(y), ref) < 4e-3
+
+
+def test_small_grid_routing(ops):
+    """Round 4: with the library's default knobs a 3x3 conv whose (256-pixel, 128-cout) grid leaves most CUs idle runs on a
+    kernel with smaller tiles (the EDM nets at the train batch of 16), larger grids stay on the wave-specialised kernels; every
+    route agrees with the fp32 reference."""
+    old = ops.set_tuning("conv_ws_min_tiles", 96), ops.set_tuning("conv_sm_mask", 5)
+    try:
+        assert ops.get_tuning("conv_ws_min_tiles") == 96 and ops.get_tuning("conv_sm_mask") == 5
+        for (N, C, Cout, H, want) in [(16, 576, 576, 16, "pipe"),     # 80 tiles
+                                      (16, 768, 768, 8, "sm"),        # 24 conv_ws8 tiles -> 192 feed-tiled workgroups
+                                      (16, 384, 384, 32, "ws"),       # 192 tiles
+                                      (100, 768, 768, 8, "ws8"),      # 150 tiles
+                                      (24, 576, 576, 16, "ws")]:      # 120 tiles
+            y, ref, kid = run_conv(ops, N, C, 0, Cout, H, 3, False, "bias+res")
+            got = "ws8" if kid == 400008 else "ws" if 400000 <= kid < 400100 else "sm" if 450000 <= kid < 460000 else "pipe" if kid < 400000 else kid
+            assert got == want, (N, C, Cout, H, kid)
+            assert rel_l2(nchw(y), ref) < 4e-3, (N, C, Cout, H)
+        with pytest.raises(Exception, match="unknown knob"):
+            ops.set_tuning("no_such_knob", 1)
+    finally:
+        ops.set_tuning("conv_ws_min_tiles", old[0])
+        ops.set_tuning("conv_sm_mask", old[1])
 
 
 def test_round2_kernels_out_of_scope_shapes_fall_back(ops):

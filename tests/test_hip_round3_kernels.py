@@ -27,6 +27,17 @@ def ops():
     return o
 
 
+@pytest.fixture(scope="module", autouse=True)
+def kernels_under_test(ops):
+    """These cases put deliberately small grids (one tile, a handful of images) on the wave-specialised kernels: switch off the
+    library's small-grid re-routing (include/dxmi_hip.h: dxmi_set_tuning) for this module; test_small_grid_routing covers it."""
+    old = ops.set_tuning("conv_ws_min_tiles", 0), ops.set_tuning("conv_sm_mask", 1)
+    yield
+    ops.set_tuning("conv_ws_min_tiles", old[0])
+    ops.set_tuning("conv_sm_mask", old[1])
+
+
+
 def _torch_block_stats(y):
     """y NHWC bf16 -> [N, C/2, 2] fp64 (sum, sum of squares) of the stored values per channel pair."""
     N, H, W, C = y.shape
