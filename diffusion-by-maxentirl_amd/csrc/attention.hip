@@ -239,6 +239,176 @@ __global__ __launch_bounds__(256, D == 64 ? ATTN_WPE : 1) void attention_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// 64-wide heads on long sequences (the ADM nets' 32x32 and 16x16 AttentionBlocks: T = 1024 / 256, models/cm/unet.py:413-441), round 4.
+// attention_kernel<64> pays per key block for two barriers and an exposed global load, with 32 queries per wave.  Here:
+//   * a wave owns 64 queries (two 32-query tiles): every K fragment read from LDS feeds two MFMAs and the per-block costs
+//     (barrier, staging) are shared by twice the work;
+//   * the K / V images are double-buffered: block kb + 1 is requested into registers before block kb is computed and written
+//     to the other buffer after it, ONE barrier per block;
+//   * logits stay raw in the accumulators: the running maximum is taken on them and scale * log2(e) rides the one FMA in front
+//     of the exponential (exp2(s * c - m)), a multiply and a subtract less per element.
+// Measured (N = 100, T = 1024, 6 heads): 335 us on attention_kernel<64> at three waves per SIMD -> 290 us.  The kernel is bound by
+// its per-wave dependency chain (S MFMAs -> maximum -> exponentials -> PV MFMAs, two waves per SIMD), not by an execution unit:
+// timing-only builds without the exponentials take as long, without the S MFMAs or without staging + barrier 24 % less each.  Two
+// re-orderings that hipcc accepted did not shorten it: the two tiles skewed by half a block over a three-image K
+// ring (308 us), and that skew with sched_group_barrier slots "one K read, one MFMA, an eighth of the exponentials" (the
+// scheduler clustered the MFMAs regardless and spilled 16 registers).
+// Layouts (fragment orders, transposing V reads, padded pitches) are attention_kernel's.  T % 256 == 0 (a workgroup = 256 queries).
+constexpr int AT64_KPITCH = 64 * 2 + 16, AT64_VPITCH = 64 * 2 + 64, AT64_KIMG = 64 * AT64_KPITCH, AT64_BUF = AT64_KIMG + 64 * AT64_VPITCH;
+constexpr int AT64_LDS = 2 * AT64_BUF;
+__global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs p) {
+    constexpr int D = 64, KB = 64, KPITCH = AT64_KPITCH, VPITCH = AT64_VPITCH, KIMG = AT64_KIMG, BUF = AT64_BUF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int trg = lane >> 4, trq = (lane & 15) >> 2, trp = lane & 3;
+    const int tr_doff = (16 * (trg & 1) + 4 * trp) * 2;
+    const int tr_krow = 4 * (trg >> 1) + trq;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qblocks = p.T >> 8;
+    const int qb = blockIdx.x % qblocks;
+    const int hd = (blockIdx.x / qblocks) % p.heads;
+    const int n = blockIdx.x / (qblocks * p.heads);
+    const int C3 = 3 * p.C;
+    const bf16* base = p.qkv + (size_t)n * p.T * C3;
+    const int qc = p.q_off + hd * p.head_stride, kc = p.k_off + hd * p.head_stride, vc = p.v_off + hd * p.head_stride;
+    const int h = lane >> 5;
+    const int query0 = qb * 256 + wave * 64 + (lane & 31);      // tile t: query0 + 32 t
+
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[t][ks] = *reinterpret_cast<const bf16x8*>(base + (size_t)(query0 + 32 * t) * C3 + qc + ks * 16 + 8 * h);
+
+    f32x16 o[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][db][r] = 0.f;
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    const float sc2 = p.scale * 1.4426950408889634f;      // exp(x * scale) = exp2(x * sc2); scale > 0
+
+    const int nkb = p.T / KB;
+    const int key0 = tid >> 3, pc = tid & 7;               // staging: pieces tid and tid + 256 (keys key0 and key0 + 32)
+    const bf16* const gk = base + (size_t)key0 * C3 + kc + pc * 8;
+    const bf16* const gv = base + (size_t)key0 * C3 + vc + pc * 8;
+    bf16x8 kreg[2], vreg[2];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            kreg[q] = *reinterpret_cast<const bf16x8*>(gk + (size_t)(kb * KB + 32 * q) * C3);
+            vreg[q] = *reinterpret_cast<const bf16x8*>(gv + (size_t)(kb * KB + 32 * q) * C3);
+        }
+    };
+    auto lstore = [&](char* buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            *reinterpret_cast<bf16x8*>(buf + (key0 + 32 * q) * KPITCH + pc * 16) = kreg[q];
+            *reinterpret_cast<bf16x8*>(buf + KIMG + (key0 + 32 * q) * VPITCH + pc * 16) = vreg[q];
+        }
+    };
+    gload(0);
+    lstore(smem);
+    // every load so far (the Q fragments too) has landed before the loop: hipcc's wait-count pass otherwise carries the pending Q
+    // loads into the loop and waits, in every trip, for counts that drain the NEXT block's prefetch in front of the first MFMAs
+    __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
+    __syncthreads();
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        const char* const kimg = smem + (kb & 1) * BUF;
+        const char* const vimg = kimg + KIMG;
+        if (kb + 1 < nkb) gload(kb + 1);
+        // ---- S^T = K . Q^T: 2 x 32 keys against both query tiles (each K fragment is read once)
+        f32x16 s[2][2];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[t][kh][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(kimg + (kh * 32 + (lane & 31)) * KPITCH + ks * 32 + h * 16);
+                s[0][kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][ks], s[0][kh], 0, 0, 0);
+                s[1][kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[1][ks], s[1][kh], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            // ---- online softmax of tile t (query on the lane; this lane holds 32 of the block's 64 keys)
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][kh][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m[t], mx * sc2);
+            float psum = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][kh][r], sc2, -m_new));
+                    s[t][kh][r] = e;
+                    psum += e;
+                }
+            if (__builtin_amdgcn_ballot_w64(m_new != m[t]) != 0) {      // some lane's running maximum moved (always on the first block)
+                const float alpha = __builtin_amdgcn_exp2f(m[t] - m_new);
+                l[t] = l[t] * alpha + psum;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[t][db][r] *= alpha;
+            } else {
+                l[t] += psum;
+            }
+            m[t] = m_new;
+            // ---- O^T += V^T . P^T ; 4 k-steps of 16 keys
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int kh = st >> 1, sl = st & 1;
+                bf16x8 pb;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pb[jj] = (bf16)s[t][kh][8 * sl + jj];
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const char* row = vimg + (kh * 32 + 16 * sl + tr_krow) * VPITCH + db * 64 + tr_doff;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(row));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_S16X4(row + 8 * VPITCH));
+                    bf16x8 a;
+                    short* as = reinterpret_cast<short*>(&a);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { as[e] = lo[e]; as[4 + e] = hi[e]; }
+                    o[t][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, o[t][db], 0, 0, 0);
+                }
+            }
+        }
+        if (kb + 1 < nkb) {
+            lstore(smem + ((kb + 1) & 1) * BUF);      // last read in block kb - 1: every wave passed the barrier that ended it
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float lt = l[t] + __shfl_xor(l[t], 32, 64);
+        const float inv = 1.f / lt;
+        bf16* orow = p.out + ((size_t)n * p.T + query0 + 32 * t) * p.C + hd * D;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = (bf16)(o[t][db][4 * g + e] * inv);
+                *reinterpret_cast<bf16x4*>(orow + db * 32 + 8 * g + 4 * h) = ov;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Single-head 256-token x 256-channel attention (the CIFAR-10 U-Net's 16x16 AttnBlocks, unet_small.py:175-187): one
 // workgroup of 8 waves per image, wave w owns queries 32w..32w+31.
 //   * every operand block (64 rows x 512 B of Q, K or V) travels global -> LDS by DMA (global_load_lds, no staging
@@ -633,7 +803,21 @@ extern "C" int dxmi_attention_fwd(const void* qkv, void* out, int32_t N, int32_t
     if (D == 256 && T == 256 && heads == 1 && !v1) return launch_attn256(a, st);
     if (D == 256) return launch_attn<256>(a, st);
     if (D == 128) return launch_attn<128>(a, st);
-    if (D == 64) return launch_attn<64>(a, st);
+    if (D == 64) {
+        // long sequences of 64-wide heads: two query tiles per wave, one barrier per key block (attention64_kernel); DXMI_ATTN64=0: generic kernel
+        static const int v64 = getenv("DXMI_ATTN64") ? atoi(getenv("DXMI_ATTN64")) : 1;
+        if (v64 && T % 256 == 0 && scale > 0.f) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(attention64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(attention64_kernel, dim3(N * heads * (T / 256)), dim3(256), AT64_LDS, st, a);
+            DXMI_CHECK_LAUNCH("dxmi_attention_fwd(64)");
+            return DXMI_OK;
+        }
+        return launch_attn<64>(a, st);
+    }
     dxmi_set_error("dxmi_attention_fwd: head dim %d unsupported (64, 128, 256)", D);
     return DXMI_EINVAL;
 }

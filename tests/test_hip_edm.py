@@ -174,6 +174,26 @@ def test_attention_multi_head_legacy_layout(ops):
     assert rel_l2(y.float().cpu().permute(0, 2, 1), ref) < 6e-3
 
 
+@pytest.mark.parametrize("N,T,heads,amp", [(3, 256, 9, 1.0), (2, 1024, 6, 1.0), (2, 512, 2, 4.0), (1, 1024, 1, 0.05)])
+def test_attention64_long_sequences(ops, N, T, heads, amp):
+    """attention64_kernel (64-wide heads, T % 256 == 0: the ADM nets' 16x16 / 32x32 blocks, unet.py:413-441): against fp32 softmax
+    attention on the same bf16 operands, with logits from flat (amp 0.05) to peaked (amp 4: the running maximum moves and the
+    rescale branch runs); bitwise reproducible and independent of the batch an image rides in."""
+    g = torch.Generator().manual_seed(31 + T + heads)
+    D = 64
+    C = heads * D
+    qkv = bf(torch.randn(N, T, 3 * C, generator=g) * amp)
+    q, k, v = [z.view(N, T, heads, D).transpose(1, 2) for z in qkv.split(C, dim=2)]
+    scale = 1 / math.sqrt(D)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1) @ v).transpose(1, 2).reshape(N, T, C)
+    x = qkv.to(torch.bfloat16).to(DEV)
+    y = ops.attention(x, heads, scale)
+    assert rel_l2(y.float().cpu(), ref) < 8e-3, rel_l2(y.float().cpu(), ref)
+    assert torch.equal(y, ops.attention(x, heads, scale))
+    i = N - 1
+    assert torch.equal(ops.attention(x[i:i + 1].contiguous(), heads, scale)[0], y[i])
+
+
 def test_edm_precond_and_step_kernels(ops):
     g = torch.Generator().manual_seed(9)
     N, shape = 5, (3, 16, 16)
