@@ -334,6 +334,8 @@ def edm_train_leg(device, name="imagenet64_T10", B=16, steps=2):
         ls = trainer.update_sampler_mixed_precision(buf, mp_trainer=mp)
         return le, ls
 
+    from dxmi_hip import ops
+    ops.tune_for_throughput(True)              # train_image_large.py's setting: under-filled conv grids on smaller tiles
     step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -341,6 +343,7 @@ def edm_train_leg(device, name="imagenet64_T10", B=16, steps=2):
         le, ls = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    ops.tune_for_throughput(False)
     assert all(x == x for x in le.values())
     out = {"workload": f"{name}: DxMI_Trainer_Cond step, per-GPU batch {B}, T={sampler.n_timesteps}, fused RAdam / Adam, loss scale 2^20",
            "train_steps_per_sec": round(1 / dt, 3), "ms_per_step": round(dt * 1e3, 1), "timed_steps": steps,
@@ -465,6 +468,7 @@ def main():
     train_sps, train_summ, t_train_step = None, None, None
     if args.train_steps > 0:
         from models.DxMI.replay import TransitionRing
+        ops.tune_for_throughput(True)          # as train_cifar10.py / train_image_large.py do (the generation legs keep the defaults)
         tr = build_trainer(sampler, device, B, T)
         ring = TransitionRing(1, T, B, (3, 32, 32), device)
         gimg = torch.Generator(device=device).manual_seed(112233 + rank)
@@ -487,6 +491,7 @@ def main():
             torch.cuda.synchronize()
             ops.PROFILER = None
             train_summ = prof.summary()
+        ops.tune_for_throughput(False)
         sync_all()
 
     if rank != 0:

@@ -40,7 +40,16 @@ def set_tuning(name, value):
     """Kernel-selection knob of the library (include/dxmi_hip.h: dxmi_set_tuning); returns the previous value."""
     old = get_tuning(name)
     check(load().dxmi_set_tuning(name.encode(), int(value)), "dxmi_set_tuning")
+    _STATS_P.clear()          # per-shape answers of the selection queries (statistics partials, fused GroupNorm) depend on the knobs
     return old
+
+
+def tune_for_throughput(on=True):
+    """Training entry points: route convs whose 256-pixel-tile grid leaves most CUs idle (small per-GPU batches) to kernels with
+    smaller tiles.  Off (the library default), every layer shape runs one kernel whatever the batch size, which keeps an image's
+    result bitwise independent of the batch it rides in (generation scripts, parity tests)."""
+    set_tuning("conv_ws_min_tiles", 96 if on else 0)
+    set_tuning("conv_sm_mask", 5 if on else 1)
 
 
 def get_tuning(name):

@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--run", type=str, default="run")
     ap.add_argument("--synthetic_data", action="store_true")
     ap.add_argument("--max_iters", type=int, default=None, help="stop after this many iterations (smoke runs)")
+    ap.add_argument("--batch_invariant", action="store_true",
+                    help="keep one conv kernel per layer shape whatever the batch size (bitwise batch-independent results) instead of "
+                         "routing under-filled grids to smaller tiles (dxmi_hip.ops.tune_for_throughput)")
     args, unknown = ap.parse_known_args()
     d_cmd_cfg = cmd.parse_nested_args(cmd.parse_unknown_args(unknown))
     print0("Overriding", d_cmd_cfg)
@@ -103,6 +106,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(device)
+    if not args.batch_invariant:
+        from dxmi_hip import ops as _ops
+        _ops.tune_for_throughput()
     seed = cfg.training.seed
     torch.manual_seed(seed + local_rank)
     np.random.seed(seed + local_rank)

@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--run", type=str, required=True)
     ap.add_argument("--synthetic_data", action="store_true")
     ap.add_argument("--max_iters", type=int, default=None, help="stop after this many iterations (smoke runs)")
+    ap.add_argument("--batch_invariant", action="store_true",
+                    help="keep one conv kernel per layer shape whatever the batch size (bitwise batch-independent results) instead of "
+                         "routing under-filled grids to smaller tiles (dxmi_hip.ops.tune_for_throughput)")
     ap.add_argument("--fid_extractor", type=str, default=None,
                     help="'module:attribute' of the FID feature extractor (the reference builds pytorch_fid's InceptionV3, whose weights "
                          "this image cannot download); with --fid_stats it enables the periodic fid() of training.fid_every")
@@ -92,6 +95,9 @@ def main():
 
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(device)
+    if not args.batch_invariant:
+        from dxmi_hip import ops as _ops
+        _ops.tune_for_throughput()
     seed = cfg.training.seed
     torch.manual_seed(seed + local_rank)
     np.random.seed(seed + local_rank)

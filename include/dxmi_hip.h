@@ -53,11 +53,15 @@ int dxmi_version(void);
 /* 0 when a gfx950 device is usable; DXMI_ENODEV otherwise (never falls back to CPU). */
 int dxmi_device_check(void);
 /* Kernel-selection knobs (process-wide; initial value from the environment variable in brackets).  They choose between kernels
- * that compute the same convolution, never a result-changing mode; unknown names return DXMI_EINVAL.
- *   "conv_ws_min_tiles" [DXMI_CONV_WS_MIN_TILES, 96]: 3x3 convs with fewer (256-pixel, 128-cout) tiles run on the 64-pixel-tile
+ * that compute the same convolution (same operands, fp32 accumulation; the summation order inside a K extent differs between
+ * kernels, i.e. results agree to rounding, not bit for bit); unknown names return DXMI_EINVAL.
+ *   "conv_ws_min_tiles" [DXMI_CONV_WS_MIN_TILES, 0]: 3x3 convs with fewer (256-pixel, 128-cout) tiles run on the 64-pixel-tile
  *                        kernel instead of the wave-specialised one (small batches leave most CUs without a tile);
- *   "conv_sm_mask"      [DXMI_CONV_SM, 5]: bit 0 4x4 maps, bit 1 every 8x8 map, bit 2 8x8 maps whose 256-pixel-tile grid is
+ *   "conv_sm_mask"      [DXMI_CONV_SM, 1]: bit 0 4x4 maps, bit 1 every 8x8 map, bit 2 8x8 maps whose 256-pixel-tile grid is
  *                        under-filled, on the feed-tiled small-map kernel.
+ * Defaults: one kernel per layer shape whatever the batch size, so an image's result does not depend on the batch it rides in.
+ * The training entry points set 96 / 5 (throughput at small per-GPU batches; +5..8 % on the EDM train step).  The answers of
+ * dxmi_conv2d_gn_stats_partials / dxmi_conv2d_gn_fuse_supported depend on the knobs: query again after changing one.
  * No reference counterpart (the reference leaves algorithm choice to cuDNN). */
 int dxmi_set_tuning(const char* name, int32_t value);
 int dxmi_get_tuning(const char* name, int32_t* value);

@@ -3,6 +3,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "diffusion-by-maxentirl_amd")]
 import torch
+from dxmi_hip import ops
 from dxmi_hip.optim import Adam, RAdam          # the shipped optimisers (train_image_large.py)
 import configs_builtin, dxmi_config
 from models.cm.fp16_util import MixedPrecisionTrainer
@@ -10,6 +11,8 @@ from models.cm.script_util import create_model_and_diffusion
 from models.DxMI.openai_diffusion import OpenAIDiffusion
 from models.DxMI.trainer import append_buffer, reset_buffer
 
+if os.environ.get("DXMI_BATCH_INVARIANT", "0") != "1":
+    ops.tune_for_throughput()          # train_image_large.py's default
 name, B = sys.argv[1], int(sys.argv[2])
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 dev = "cuda:0"
