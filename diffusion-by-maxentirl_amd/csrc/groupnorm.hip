@@ -1168,11 +1168,13 @@ extern "C" int64_t dxmi_groupnorm_generic_bwd_workspace_bytes(int32_t N, int32_t
 }
 
 // g_out: fp32 [2][N][C] (G0, G1 above).  dx1 / add0 / add1 / scale_shift may be NULL.
-extern "C" int dxmi_groupnorm_generic_bwd(const void* in0, int32_t C0, const void* in1, int32_t C1, const void* dy,
-                                          const void* add0, const void* add1, const float* gamma, const float* beta,
-                                          const float* scale_shift, int32_t ss_ld, void* dx0, void* dx1, float* g_out,
-                                          void* workspace, int32_t N, int32_t HW, int32_t groups, float eps,
-                                          int32_t apply_silu, void* stream) {
+// fwd_stats: the statistics partials the forward left at the start of ITS workspace (dxmi_groupnorm_generic_workspace_bytes of
+// them), kept by the caller — the statistics pass over the input is then skipped; NULL: recomputed here.
+extern "C" int dxmi_groupnorm_generic_bwd_saved(const void* in0, int32_t C0, const void* in1, int32_t C1, const void* dy,
+                                                const void* add0, const void* add1, const float* gamma, const float* beta,
+                                                const float* scale_shift, int32_t ss_ld, void* dx0, void* dx1, float* g_out,
+                                                const float* fwd_stats, void* workspace, int32_t N, int32_t HW, int32_t groups,
+                                                float eps, int32_t apply_silu, void* stream) {
     DXMI_CHECK_ARG(in0 && dy && gamma && beta && dx0 && g_out && workspace, "dxmi_groupnorm_generic_bwd: null pointer");
     DXMI_CHECK_ARG(N > 0 && HW > 0 && C0 > 0 && C1 >= 0, "dxmi_groupnorm_generic_bwd: empty or negative shape (N %d, HW %d, C %d+%d)", N, HW, C0, C1);
     const int C = C0 + C1;
@@ -1186,18 +1188,30 @@ extern "C" int dxmi_groupnorm_generic_bwd(const void* in0, int32_t C0, const voi
     f.chunks = chunks; f.rows_per_chunk = (HW + chunks - 1) / chunks; f.eps = eps; f.silu = apply_silu;
     GnGenBwdArgs a;
     a.in0 = (const bf16*)in0; a.in1 = (const bf16*)in1; a.dy = (const bf16*)dy; a.add0 = (const bf16*)add0; a.add1 = (const bf16*)add1;
-    a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.dx0 = (bf16*)dx0; a.dx1 = (bf16*)dx1; a.part = part;
+    a.gamma = gamma; a.beta = beta; a.ss = scale_shift; a.dx0 = (bf16*)dx0; a.dx1 = (bf16*)dx1;
+    a.part = fwd_stats ? const_cast<float*>(fwd_stats) : part;      // read-only in the backward kernels
     a.gpart = part + (size_t)N * chunks * 32 * 2; a.g_out = g_out;
     a.C0 = C0; a.C1 = C1; a.HW = HW; a.groups = groups; a.cpg = C / groups; a.chunks = chunks; a.rows_per_chunk = f.rows_per_chunk;
     a.ss_ld = ss_ld; a.N = N; a.eps = eps; a.silu = apply_silu;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_gen_stats_kernel, dim3(N * chunks), dim3(256), 0, st, f);
-    DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_bwd(stats)");
+    if (!fwd_stats) {
+        hipLaunchKernelGGL(gn_gen_stats_kernel, dim3(N * chunks), dim3(256), 0, st, f);
+        DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_bwd(stats)");
+    }
     hipLaunchKernelGGL(gn_gen_bwd_reduce_kernel, dim3(N * chunks), dim3(256), 0, st, a);
     DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_bwd(reduce)");
     hipLaunchKernelGGL(gn_gen_bwd_apply_kernel, dim3(N * chunks), dim3(256), 0, st, a);
     DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_bwd(apply)");
     return DXMI_OK;
+}
+
+extern "C" int dxmi_groupnorm_generic_bwd(const void* in0, int32_t C0, const void* in1, int32_t C1, const void* dy,
+                                          const void* add0, const void* add1, const float* gamma, const float* beta,
+                                          const float* scale_shift, int32_t ss_ld, void* dx0, void* dx1, float* g_out,
+                                          void* workspace, int32_t N, int32_t HW, int32_t groups, float eps,
+                                          int32_t apply_silu, void* stream) {
+    return dxmi_groupnorm_generic_bwd_saved(in0, C0, in1, C1, dy, add0, add1, gamma, beta, scale_shift, ss_ld, dx0, dx1, g_out, nullptr,
+                                            workspace, N, HW, groups, eps, apply_silu, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

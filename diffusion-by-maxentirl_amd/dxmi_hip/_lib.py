@@ -87,6 +87,7 @@ SIGNATURES = {
     "dxmi_groupnorm_generic_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dxmi_groupnorm_generic_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "dxmi_groupnorm_generic_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "dxmi_groupnorm_generic_bwd_saved": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dxmi_upsample2x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_edm_precond": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "dxmi_edm_step_fwd": (c_int, [c_void_p] * 8 + [c_int, c_int, c_float, c_void_p]),

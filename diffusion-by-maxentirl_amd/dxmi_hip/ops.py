@@ -502,7 +502,7 @@ def groupnorm_apply(x, st, gamma, beta, *, in1=None, st1=None, groups=32, eps=1e
     return out
 
 
-def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, out=None, scale_shift=None, stats=None):
+def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, out=None, scale_shift=None, stats=None, saved=None):
     """GroupNorm(+SiLU).  stats = (BlockStats of x, BlockStats of in1 | None): the streaming apply kernel.  Otherwise the
     register-resident one-pass kernel serves channels-per-group % 4 == 0 slices that fit; everything else (EDM shapes,
     scale-shift norm) goes to the generic two-kernel path."""
@@ -514,7 +514,7 @@ def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, 
         return groupnorm_apply(x, stats[0], gamma, beta, in1=in1, st1=stats[1] if in1 is not None else None, groups=groups,
                                eps=eps, silu=silu, out=out, scale_shift=scale_shift)
     if scale_shift is not None or not load().dxmi_groupnorm_silu_supported(C0, C1, H * W, groups):
-        return groupnorm_generic(x, gamma, beta, in1=in1, groups=groups, eps=eps, silu=silu, out=out, scale_shift=scale_shift)
+        return groupnorm_generic(x, gamma, beta, in1=in1, groups=groups, eps=eps, silu=silu, out=out, scale_shift=scale_shift, saved=saved)
     assert x.dtype == torch.bfloat16 and x.is_contiguous()
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C0 + C1
     if out is None:
@@ -525,7 +525,9 @@ def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, 
     return out
 
 
-def groupnorm_generic(x, gamma, beta, *, in1=None, groups=32, eps=1e-5, silu=True, out=None, scale_shift=None):
+def groupnorm_generic(x, gamma, beta, *, in1=None, groups=32, eps=1e-5, silu=True, out=None, scale_shift=None, saved=None):
+    """saved: a list; the forward's statistics partials (a small fp32 tensor of its own instead of the shared workspace) are
+    appended to it for groupnorm_generic_bwd(fwd_stats=...), which then skips its statistics pass over the input."""
     _need_cuda(x, in1, gamma, beta, out, scale_shift)
     N, H, W, C0 = x.shape
     C1 = in1.shape[3] if in1 is not None else 0
@@ -538,16 +540,23 @@ def groupnorm_generic(x, gamma, beta, *, in1=None, groups=32, eps=1e-5, silu=Tru
         assert scale_shift.dtype == torch.float32 and scale_shift.stride(-1) == 1 and scale_shift.shape[1] == 2 * C
         ss_ld = scale_shift.stride(0)
     lib = load()
-    ws = _workspace(lib.dxmi_groupnorm_generic_workspace_bytes(N, H * W, C), x.device)
+    nbytes = lib.dxmi_groupnorm_generic_workspace_bytes(N, H * W, C)
+    if saved is not None:
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        saved.append(ws)
+    else:
+        ws = _workspace(nbytes, x.device)
     _prof("groupnorm", "generic", 0.0, 4.0 * N * H * W * C, lambda: check(
         lib.dxmi_groupnorm_generic_fwd(_ptr(x), C0, _ptr(in1), C1, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld, _ptr(out),
                                        _ptr(ws), N, H * W, groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_generic_fwd"))
     return out
 
 
-def groupnorm_generic_bwd(x, dy, gamma, beta, *, in1=None, add0=None, add1=None, groups=32, eps=1e-5, silu=True, scale_shift=None):
-    """-> (dx0, dx1 | None, dgamma [C], dbeta [C], d_scale_shift [N, 2C] | None)."""
-    _need_cuda(x, in1, dy, add0, add1, gamma, beta, scale_shift)
+def groupnorm_generic_bwd(x, dy, gamma, beta, *, in1=None, add0=None, add1=None, groups=32, eps=1e-5, silu=True, scale_shift=None,
+                          fwd_stats=None):
+    """-> (dx0, dx1 | None, dgamma [C], dbeta [C], d_scale_shift [N, 2C] | None).  fwd_stats: the tensor groupnorm_generic(saved=...)
+    kept for this input."""
+    _need_cuda(x, in1, dy, add0, add1, gamma, beta, scale_shift, fwd_stats)
     N, H, W, C0 = x.shape
     C1 = in1.shape[3] if in1 is not None else 0
     C = C0 + C1
@@ -558,9 +567,11 @@ def groupnorm_generic_bwd(x, dy, gamma, beta, *, in1=None, add0=None, add1=None,
     ss_ld = scale_shift.stride(0) if scale_shift is not None else 0
     lib = load()
     ws = _workspace(lib.dxmi_groupnorm_generic_bwd_workspace_bytes(N, H * W, C), x.device)
-    check(lib.dxmi_groupnorm_generic_bwd(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(add0), _ptr(add1), _ptr(gamma), _ptr(beta),
-                                         _ptr(scale_shift), ss_ld, _ptr(dx0), _ptr(dx1), _ptr(g), _ptr(ws), N, H * W, groups,
-                                         float(eps), int(silu), _stream()), "dxmi_groupnorm_generic_bwd")
+    if fwd_stats is not None:
+        assert fwd_stats.dtype == torch.float32 and fwd_stats.numel() * 4 == lib.dxmi_groupnorm_generic_workspace_bytes(N, H * W, C)
+    check(lib.dxmi_groupnorm_generic_bwd_saved(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(add0), _ptr(add1), _ptr(gamma), _ptr(beta),
+                                               _ptr(scale_shift), ss_ld, _ptr(dx0), _ptr(dx1), _ptr(g), _ptr(fwd_stats), _ptr(ws), N, H * W,
+                                               groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_generic_bwd")
     g0, g1 = g[0], g[1]
     if scale_shift is None:
         return dx0, dx1, colsum_f32(g1.contiguous()), colsum_f32(g0.contiguous()), None

@@ -80,9 +80,16 @@ class _EDMUNetFn(torch.autograd.Function):
         emb_all = ops.linear(emb, pk["emb_w"], pk["emb_b"], pre_act=ops.ACT_SILU)
         tape = []
 
+        def gn_fwd(norm, xin, **kw):
+            """GroupNorm(+SiLU) + the forward's statistics partials (generic path only; None otherwise): the backward then skips
+            its own statistics pass over `xin` (autograd saves mean / rstd the same way)."""
+            sv = []
+            out = ops.groupnorm_silu(xin, norm.weight, norm.bias, eps=norm.eps, saved=sv, **kw)
+            return out, (sv[0] if sv else None)
+
         def res(b, x0, x1):
             gn1, conv1, gn2, conv2 = b.in_layers[0], b.in_layers[2], b.out_layers[0], b.out_layers[3]
-            a1 = ops.groupnorm_silu(x0, gn1.weight, gn1.bias, in1=x1, eps=gn1.eps, silu=True)
+            a1, s1 = gn_fwd(gn1, x0, in1=x1, silu=True)
             a1p, xs = a1, x0
             if b.up:
                 xs = ops.upsample2x(x0)
@@ -92,23 +99,23 @@ class _EDMUNetFn(torch.autograd.Function):
             e = emb_all[:, off:off + eo]
             if b.use_scale_shift_norm:
                 h = ops.conv2d(a1p, pk[id(b), "conv1"], bias=conv1.bias, upsample=b.up)
-                a2 = ops.groupnorm_silu(h, gn2.weight, gn2.bias, eps=gn2.eps, silu=True, scale_shift=e)
+                a2, s2 = gn_fwd(gn2, h, silu=True, scale_shift=e)
             else:
                 h = ops.conv2d(a1p, pk[id(b), "conv1"], bias=conv1.bias, upsample=b.up, addvec=e)
-                a2 = ops.groupnorm_silu(h, gn2.weight, gn2.bias, eps=gn2.eps, silu=True)
+                a2, s2 = gn_fwd(gn2, h, silu=True)
             if (id(b), "skip") in pk:
                 xs = ops.conv2d(x0, pk[id(b), "skip"], in1=x1, bias=b.skip_connection.bias)
             out = ops.conv2d(a2, pk[id(b), "conv2"], bias=conv2.bias, residual=xs)
-            tape.append(("res", b, x0, x1, a1p, h, a2))
+            tape.append(("res", b, x0, x1, a1p, h, a2, s1, s2))
             return out
 
         def attn(m, xa):
             N, H, W, C = xa.shape
-            hn = ops.groupnorm_silu(xa, m.norm.weight, m.norm.bias, eps=m.norm.eps, silu=False)
+            hn, sn = gn_fwd(m.norm, xa, silu=False)
             qkv = ops.conv2d(hn, pk[id(m), "qkv"], bias=m.qkv.bias)
             a = ops.attention(qkv.view(N, H * W, 3 * C), heads=m.num_heads, scale=1.0 / math.sqrt(C // m.num_heads))
             out = ops.conv2d(a.view(N, H, W, C), pk[id(m), "proj"], bias=m.proj_out.bias, residual=xa)
-            tape.append(("attn", m, xa, hn, qkv, a))
+            tape.append(("attn", m, xa, hn, qkv, a, sn))
             return out
 
         def seq(mods, h, skip):
@@ -140,7 +147,7 @@ class _EDMUNetFn(torch.autograd.Function):
             tape.append(("skip", None, len(hs) - 1))
             h = seq(blk, h, hs.pop())
         gn = net.out[0]
-        a_out = ops.groupnorm_silu(h, gn.weight, gn.bias, eps=gn.eps, silu=True)
+        a_out, ctx.s_out = gn_fwd(gn, h, silu=True)
         out = ops.conv2d(a_out, pk["conv_out"], bias=net.out[2].bias, out_nchw_f32=True)
         ctx.net, ctx.tape, ctx.h_last, ctx.a_out, ctx.x, ctx.sinus, ctx.y = net, tape, h, a_out, x, sinus, y
         ctx.emb_all_shape = emb_all.shape
@@ -162,9 +169,9 @@ class _EDMUNetFn(torch.autograd.Function):
             dw, grads[conv.bias] = ops.conv2d_wgrad(x0, gy, k, in1=x1, with_bias=True, **kw)
             grads[conv.weight] = dw.reshape(conv.weight.shape)
 
-        def gn_bwd(norm, xin, dy, *, in1=None, add0=None, add1=None, silu=True, scale_shift=None):
+        def gn_bwd(norm, xin, dy, *, in1=None, add0=None, add1=None, silu=True, scale_shift=None, fwd_stats=None):
             dx0, dx1, dg, db, d_ss = ops.groupnorm_generic_bwd(xin, dy, norm.weight, norm.bias, in1=in1, add0=add0, add1=add1,
-                                                               eps=norm.eps, silu=silu, scale_shift=scale_shift)
+                                                               eps=norm.eps, silu=silu, scale_shift=scale_shift, fwd_stats=fwd_stats)
             grads[norm.weight], grads[norm.bias] = dg, db
             return dx0, dx1, d_ss
 
@@ -176,21 +183,21 @@ class _EDMUNetFn(torch.autograd.Function):
         grads[net.out[2].weight] = wg[: net.out_channels].contiguous()
         grads[net.out[2].bias] = d_out.float().sum((0, 2, 3))
         d_a = ops.conv2d(d_pad, pkt["conv_out"])
-        g, _, _ = gn_bwd(net.out[0], ctx.h_last, d_a)
+        g, _, _ = gn_bwd(net.out[0], ctx.h_last, d_a, fwd_stats=ctx.s_out)
 
         gskip = {}
 
         def res_bwd(entry, g):
-            _, b, x0, x1, a1p, h, a2 = entry
+            _, b, x0, x1, a1p, h, a2, s1, s2 = entry
             gn1, conv1, gn2, conv2 = b.in_layers[0], b.in_layers[2], b.out_layers[0], b.out_layers[3]
             conv_wb(conv2, a2, g, 3)
             d_a2 = ops.conv2d(g, pkt[id(b), "conv2"])
             off, eo = pk[id(b), "eoff"], b.emb_layers[1].out_features
             if b.use_scale_shift_norm:
-                d_h, _, d_ss = gn_bwd(gn2, h, d_a2, scale_shift=emb_all[:, off:off + eo])
+                d_h, _, d_ss = gn_bwd(gn2, h, d_a2, scale_shift=emb_all[:, off:off + eo], fwd_stats=s2)
                 d_emb_all[:, off:off + eo] = d_ss
             else:
-                d_h, _, _ = gn_bwd(gn2, h, d_a2)
+                d_h, _, _ = gn_bwd(gn2, h, d_a2, fwd_stats=s2)
                 d_emb_all[:, off:off + eo] = ops.colsum_per_image(d_h)
             conv_wb(conv1, a1p, d_h, 3, upsample=b.up)
             d_a1 = ops.conv2d(d_h, pkt[id(b), "conv1"])
@@ -202,7 +209,7 @@ class _EDMUNetFn(torch.autograd.Function):
                 sk = b.skip_connection
                 k = sk.weight.shape[-1]
                 conv_wb(sk, x0, g, k, x1=x1)
-                dxg0, dxg1, _ = gn_bwd(gn1, x0, d_a1, in1=x1)
+                dxg0, dxg1, _ = gn_bwd(gn1, x0, d_a1, in1=x1, fwd_stats=s1)
                 C0 = x0.shape[3]
                 w = sk.weight
                 if (id(b), "skip_t", C0) not in pkt:     # transposed fragments per concat source, cached with the other packs
@@ -216,11 +223,11 @@ class _EDMUNetFn(torch.autograd.Function):
                 return d_x0, d_x1
             assert x1 is None
             g_id = _up_sum(g) if b.up else (_pool_t(g) if b.down else g)
-            d_x0, _, _ = gn_bwd(gn1, x0, d_a1, add0=g_id)
+            d_x0, _, _ = gn_bwd(gn1, x0, d_a1, add0=g_id, fwd_stats=s1)
             return d_x0, None
 
         def attn_bwd(entry, g):
-            _, m, xa, hn, qkv, a = entry
+            _, m, xa, hn, qkv, a, sn = entry
             Nn, Hh, Ww, C = xa.shape
             conv_wb(m.proj_out, a.view(Nn, Hh, Ww, C), g, 1)
             d_a = ops.conv2d(g, pkt[id(m), "proj"])
@@ -228,7 +235,7 @@ class _EDMUNetFn(torch.autograd.Function):
                                       1.0 / math.sqrt(C // m.num_heads), o=a.view(Nn, Hh * Ww, C)).view(Nn, Hh, Ww, 3 * C)
             conv_wb(m.qkv, hn, d_qkv, 1)
             d_hn = ops.conv2d(d_qkv, pkt[id(m), "qkv"])
-            d_x, _, _ = gn_bwd(m.norm, xa, d_hn, add0=g, silu=False)
+            d_x, _, _ = gn_bwd(m.norm, xa, d_hn, add0=g, silu=False, fwd_stats=sn)
             return d_x
 
         i = len(tape) - 1

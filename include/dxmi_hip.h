@@ -355,6 +355,14 @@ int dxmi_groupnorm_generic_bwd(const void* in0, int32_t C0, const void* in1, int
                                const float* scale_shift, int32_t ss_ld, void* dx0, void* dx1, float* g_out,
                                void* workspace, int32_t N, int32_t HW, int32_t groups, float eps,
                                int32_t apply_silu, void* stream);
+/* Same with the forward's statistics kept by the caller: fwd_stats = the first dxmi_groupnorm_generic_workspace_bytes bytes of the
+ * workspace dxmi_groupnorm_generic_fwd was given (per-chunk group sums; untouched by the forward's second kernel), which saves the
+ * backward its own statistics pass over the input (autograd keeps mean / rstd the same way).  fwd_stats NULL: recomputed. */
+int dxmi_groupnorm_generic_bwd_saved(const void* in0, int32_t C0, const void* in1, int32_t C1, const void* dy,
+                                     const void* add0, const void* add1, const float* gamma, const float* beta,
+                                     const float* scale_shift, int32_t ss_ld, void* dx0, void* dx1, float* g_out,
+                                     const float* fwd_stats, void* workspace, int32_t N, int32_t HW, int32_t groups, float eps,
+                                     int32_t apply_silu, void* stream);
 int dxmi_upsample2x(const void* in, void* out, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
 int dxmi_edm_precond(const float* x, const float* sigma, float* x_in, float* t_out, int32_t N, int32_t CHW,
                      float sigma_data, void* stream);

@@ -134,6 +134,8 @@ int main(void) {
     if (dxmi_fid_stats_workspace_bytes(-5, 64) != 0 || dxmi_fid_stats_workspace_bytes(100, -64) != 0) { printf("FAIL fid_stats_workspace_bytes(bad)\n"); ++failures; }
     else printf("ok   fid_stats_workspace_bytes(bad) == 0\n");
 
+    expect_einval("groupnorm_generic_bwd_saved(NULL dy)", dxmi_groupnorm_generic_bwd_saved(FAKE(1), 192, NULL, 0, NULL, NULL, NULL, (const float*)FAKE(1), (const float*)FAKE(2), NULL, 0, FAKE(3), NULL, (float*)FAKE(4), (const float*)FAKE(5), FAKE(6), 2, 1024, 32, 1e-5f, 1, NULL));
+    expect_einval("groupnorm_generic_bwd_saved(HW = 0)", dxmi_groupnorm_generic_bwd_saved(FAKE(1), 192, NULL, 0, FAKE(2), NULL, NULL, (const float*)FAKE(1), (const float*)FAKE(2), NULL, 0, FAKE(3), NULL, (float*)FAKE(4), (const float*)FAKE(5), FAKE(6), 2, 0, 32, 1e-5f, 1, NULL));
     /* ---- kernel-selection knobs ---------------------------------------------------------------------------------- */
     {
         int32_t v = -1;

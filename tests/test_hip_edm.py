@@ -421,6 +421,15 @@ def test_groupnorm_generic_bwd(ops, N, C0, C1, H, silu, ss):
     assert rel_l2(dg.cpu(), gamma.grad) < 2e-3 and rel_l2(db.cpu(), beta.grad) < 2e-3
     if ss:
         assert rel_l2(dss.cpu(), sst.grad) < 2e-3
+    # with the forward's statistics kept (dxmi_groupnorm_generic_bwd_saved): bitwise the results of the recomputing form
+    saved = []
+    ops.groupnorm_generic(x0, gamma.detach().to(DEV), beta.detach().to(DEV), in1=x1, eps=1e-5, silu=silu,
+                          scale_shift=sst.detach().to(DEV) if ss else None, saved=saved)
+    assert len(saved) == 1
+    r2 = ops.groupnorm_generic_bwd(x0, nhwc(dy), gamma.detach().to(DEV), beta.detach().to(DEV), in1=x1, add0=a0, add1=a1, eps=1e-5,
+                                   silu=silu, scale_shift=sst.detach().to(DEV) if ss else None, fwd_stats=saved[0])
+    for a, b in zip((dx0, dx1, dg, db, dss), r2):
+        assert (a is None and b is None) or torch.equal(a, b)
 
 
 @pytest.mark.parametrize("tag", ["", "_plain"])
