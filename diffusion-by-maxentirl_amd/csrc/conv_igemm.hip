@@ -283,6 +283,39 @@ __device__ __forceinline__ void pack_unit_fast(const float* __restrict__ w, bf16
     }
 }
 
+// The data-gradient pack (transpose_flip: logical cout co = original Cin index, logical cin k = original Cout index, taps flipped)
+// of the same unit: source run (k0 + jj, co) is TAPS contiguous floats, the runs of the 32 couts of a half wave are adjacent (a half
+// wave reads 32 x TAPS x 4 contiguous bytes per jj), consecutive jj are Cout x TAPS floats apart.  All 8 x TAPS loads are issued
+// before the first conversion (round 4: this form had kept the one-float-per-load path with a tap loop around it and was ~3x the
+// time of the forward pack on the ADM nets: 1.35 ms against 0.4 ms per optimiser step).
+struct PackF3 {
+    float a, b, c;
+};
+template <int TAPS>
+__device__ __forceinline__ void pack_unit_fast_t(const float* __restrict__ w, long kstride, bf16* __restrict__ dst, long frag_stride, int lane) {
+    float buf[8][TAPS];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const float* src = w + jj * kstride;
+        if constexpr (TAPS == 9) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const PackF3 t = reinterpret_cast<const PackF3*>(src)[i];
+                buf[jj][3 * i] = t.a; buf[jj][3 * i + 1] = t.b; buf[jj][3 * i + 2] = t.c;
+            }
+        } else {
+            buf[jj][0] = src[0];
+        }
+    }
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+        bf16x8 o;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) o[jj] = (bf16)buf[jj][TAPS - 1 - tap];
+        *reinterpret_cast<bf16x8*>(dst + tap * frag_stride + lane * 8) = o;
+    }
+}
+
 __global__ void pack_conv_weights_kernel(PackItems P) {
     const dxmi_pack_item d = P.it[blockIdx.y];
     const int CB = (d.Cout + 31) / 32;
@@ -306,6 +339,12 @@ __global__ void pack_conv_weights_kernel(PackItems P) {
             const float* src = w + ((long)co * Cin + k0) * taps;
             if (taps == 9) pack_unit_fast<9>(src, fd, frag_stride, lane);
             else pack_unit_fast<1>(src, fd, frag_stride, lane);
+            continue;
+        }
+        if (!d.k27 && d.transpose_flip && (taps == 9 || taps == 1) && co < Cout && k0 + 8 <= Cin) {
+            const float* src = w + ((long)k0 * Cout + co) * taps;
+            if (taps == 9) pack_unit_fast_t<9>(src, (long)Cout * 9, fd, frag_stride, lane);
+            else pack_unit_fast_t<1>(src, (long)Cout, fd, frag_stride, lane);
             continue;
         }
         for (int tap = 0; tap < taps; ++tap) {
@@ -552,13 +591,17 @@ extern "C" int dxmi_conv2d_kernel_id(const dxmi_conv_desc* d) {
 // output tile, reads its weight fragments and its fp32 rows straight from global memory (no LDS, no barrier) with eight
 // k16 steps of loads in flight, so the launch is P/32 x M/128 workgroups of independent MFMA chains.
 namespace {
+// gridDim.z > 1: split K — slice z takes k16 steps [z * ksplit, (z + 1) * ksplit) and writes its partial product to out + z * P * M
+// (no bias, no activation: the caller adds the slices in slice order).  A skinny product with a long K (the data gradient of the ADM
+// nets' concatenated emb_layers: 16 rows x K = 30 k x 768 columns) was 24 waves walking 1 900 dependent k steps each.
 __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, const bf16* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ out, int P, int K,
-                                                          int M, int CB, int pre_act, int post_act) {
+                                                          int M, int CB, int pre_act, int post_act, int ksplit) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int cb = blockIdx.y * 4 + wave;
     if (cb >= CB) return;
+    out += (size_t)blockIdx.z * P * M;
     const int row = blockIdx.x * 32 + (lane & 31);
     const int h = lane >> 5;
     const bool rvalid = row < P;
@@ -568,9 +611,10 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int ksteps = K / 16;
+    const int kbeg = blockIdx.z * ksplit;
+    const int ksteps = kbeg + ksplit < K / 16 ? kbeg + ksplit : K / 16;
     constexpr int LU = 8;           // k16 steps of loads in flight (4: K = 768 was twelve dependent round trips per wave)
-    for (int k0 = 0; k0 < ksteps; k0 += LU) {
+    for (int k0 = kbeg; k0 < ksteps; k0 += LU) {
         bf16x8 a[LU];
         f32x4 lo[LU], hi[LU];
 #pragma unroll
@@ -619,7 +663,7 @@ extern "C" int dxmi_linear_fwd(const float* x, const void* wpacked, const float*
     if (P <= 4096 && M % 4 == 0) {   // row counts of the embedding MLPs (batch); larger row counts keep the tiled conv path
         const int CB = (M + 31) / 32;
         hipLaunchKernelGGL(linear_small_kernel, dim3((P + 31) / 32, (CB + 3) / 4), dim3(256), 0, (hipStream_t)stream, x,
-                           (const bf16*)wpacked, bias, out, P, K, M, CB, pre_act, post_act);
+                           (const bf16*)wpacked, bias, out, P, K, M, CB, pre_act, post_act, K / 16);
         DXMI_CHECK_LAUNCH("dxmi_linear_fwd(small)");
         return DXMI_OK;
     }
@@ -633,4 +677,30 @@ extern "C" int dxmi_linear_fwd(const float* x, const void* wpacked, const float*
     a.TWl = 5; a.THl = 3; a.SUBS = 1; a.HH = 8; a.HWd = 32;
     a.PT = (P + 255) / 256; a.CB = (M + 31) / 32; a.KST = K / 16;
     return dispatch_conv(a, 0, (hipStream_t)stream);
+}
+
+// Split-K form for skinny products with a long K: partials[s][P][M] = pre(x[:, slice s]) @ W[:, slice s]^T, s < nsplit = dxmi_linear_splitk_slices(P, K, M)
+// (>= 1); the caller sums the slices in order (deterministic) and adds bias / activation itself.  P <= 4096, M % 4 == 0, K % 32 == 0.
+extern "C" int dxmi_linear_splitk_slices(int32_t P, int32_t K, int32_t M) {
+    if (P <= 0 || K <= 0 || M <= 0 || K % 32 != 0 || P > 4096 || M % 4 != 0) return 0;
+    const long waves = (long)((P + 31) / 32) * ((M + 31) / 32);          // one 32 x 32 output tile per wave
+    if (K < 4096 || waves >= 1024) return 1;
+    int s = (int)(2048 / waves);                                         // ~2 k waves in flight
+    const int smax = K / 16 / 32;                                        // >= 32 k16 steps (four rounds of loads) per slice
+    if (s > smax) s = smax;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+
+extern "C" int dxmi_linear_splitk(const float* x, const void* wpacked, float* partials, int32_t P, int32_t K, int32_t M, int32_t pre_act,
+                                  void* stream) {
+    DXMI_CHECK_ARG(x && wpacked && partials, "dxmi_linear_splitk: null pointer");
+    const int S = dxmi_linear_splitk_slices(P, K, M);
+    DXMI_CHECK_ARG(S >= 1, "dxmi_linear_splitk: unsupported shape P=%d K=%d M=%d (P <= 4096, M %% 4 == 0, K %% 32 == 0)", P, K, M);
+    const int CB = (M + 31) / 32;
+    const int ksplit = ((K / 16 + S - 1) / S + 7) / 8 * 8;               // whole rounds of eight k16 steps
+    hipLaunchKernelGGL(linear_small_kernel, dim3((P + 31) / 32, (CB + 3) / 4, S), dim3(256), 0, (hipStream_t)stream, x, (const bf16*)wpacked,
+                       (const float*)nullptr, partials, P, K, M, CB, pre_act, DXMI_ACT_NONE, ksplit);
+    DXMI_CHECK_LAUNCH("dxmi_linear_splitk");
+    return DXMI_OK;
 }

@@ -77,6 +77,8 @@ SIGNATURES = {
     "dxmi_attention_proj_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dxmi_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "dxmi_linear_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "dxmi_linear_splitk_slices": (c_int, [c_int, c_int, c_int]),
+    "dxmi_linear_splitk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_var_step_fwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_void_p]),
     "dxmi_var_gather_sched": (c_int, [c_void_p] * 9 + [c_int, c_int, c_void_p]),
     "dxmi_pool_act": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

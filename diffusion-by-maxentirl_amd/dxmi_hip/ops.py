@@ -670,6 +670,12 @@ def linear(x, pw, bias=None, pre_act=ACT_NONE, post_act=ACT_NONE, out=None):
     _need_cuda(x, bias, out)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == pw.Cin
     P, K = x.shape
+    S = load().dxmi_linear_splitk_slices(P, K, pw.Cout) if post_act == ACT_NONE else 1
+    if S > 1:      # skinny product with a long K: slices of K in parallel, summed in slice order (deterministic)
+        part = torch.empty((S, P, pw.Cout), dtype=torch.float32, device=x.device)
+        check(load().dxmi_linear_splitk(_ptr(x), _ptr(pw.buf), _ptr(part), P, K, pw.Cout, pre_act, _stream()), "dxmi_linear_splitk")
+        res = part.sum(0) if bias is None else part.sum(0).add_(bias)
+        return res if out is None else out.copy_(res)
     if out is None:
         out = torch.empty((P, pw.Cout), dtype=torch.float32, device=x.device)
     check(load().dxmi_linear_fwd(_ptr(x), _ptr(pw.buf), _ptr(bias), _ptr(out), P, K, pw.Cout, pre_act, post_act,

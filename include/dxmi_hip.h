@@ -296,6 +296,12 @@ int dxmi_timestep_embedding(const float* t, float* out, int32_t N, int32_t dim, 
 int dxmi_linear_fwd(const float* x, const void* wpacked, const float* bias, float* out,
                     int32_t P, int32_t K, int32_t M, int32_t pre_act, int32_t post_act,
                     void* stream);
+/* Split-K form for skinny products with a long K (the data gradient of the ADM nets' concatenated emb_layers, models/cm/unet.py:249:
+ * 16 rows x K ~ 30 000 -> 768 columns): partials[s][P][M], s < dxmi_linear_splitk_slices(P, K, M) (0: unsupported shape, 1: no
+ * split pays), each slice the product over its K range; the caller sums the slices in order and adds bias / activation. */
+int dxmi_linear_splitk_slices(int32_t P, int32_t K, int32_t M);
+int dxmi_linear_splitk(const float* x, const void* wpacked, float* partials, int32_t P, int32_t K, int32_t M, int32_t pre_act,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused VAR sampler transition (models/DxMI/var_sampler.py:262-295 and :373-407):

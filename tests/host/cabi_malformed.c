@@ -136,6 +136,11 @@ int main(void) {
 
     expect_einval("groupnorm_generic_bwd_saved(NULL dy)", dxmi_groupnorm_generic_bwd_saved(FAKE(1), 192, NULL, 0, NULL, NULL, NULL, (const float*)FAKE(1), (const float*)FAKE(2), NULL, 0, FAKE(3), NULL, (float*)FAKE(4), (const float*)FAKE(5), FAKE(6), 2, 1024, 32, 1e-5f, 1, NULL));
     expect_einval("groupnorm_generic_bwd_saved(HW = 0)", dxmi_groupnorm_generic_bwd_saved(FAKE(1), 192, NULL, 0, FAKE(2), NULL, NULL, (const float*)FAKE(1), (const float*)FAKE(2), NULL, 0, FAKE(3), NULL, (float*)FAKE(4), (const float*)FAKE(5), FAKE(6), 2, 0, 32, 1e-5f, 1, NULL));
+    expect_einval("linear_splitk(NULL partials)", dxmi_linear_splitk((const float*)FAKE(1), FAKE(2), NULL, 16, 30720, 768, 0, NULL));
+    expect_einval("linear_splitk(M % 4 != 0)", dxmi_linear_splitk((const float*)FAKE(1), FAKE(2), (float*)FAKE(3), 16, 30720, 770, 0, NULL));
+    expect_einval("linear_splitk(K % 32 != 0)", dxmi_linear_splitk((const float*)FAKE(1), FAKE(2), (float*)FAKE(3), 16, 30700, 768, 0, NULL));
+    if (dxmi_linear_splitk_slices(-1, 4096, 64) != 0 || dxmi_linear_splitk_slices(16, 0, 64) != 0 || dxmi_linear_splitk_slices(16, 30720, 768) < 2) { printf("FAIL linear_splitk_slices\n"); ++failures; }
+    else printf("ok   linear_splitk_slices(bad) == 0, (16, 30720, 768) splits\n");
     /* ---- kernel-selection knobs ---------------------------------------------------------------------------------- */
     {
         int32_t v = -1;

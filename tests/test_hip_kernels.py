@@ -217,6 +217,25 @@ def test_linear(ops, P, K, M):
     assert rel_l2(got, ref) < 2e-3, rel_l2(got, ref)
 
 
+@pytest.mark.parametrize("P,K,M,bias", [(16, 30720, 768, False), (100, 8192, 192, True), (5, 4096, 64, False)])
+def test_linear_long_k_split(ops, P, K, M, bias):
+    """Skinny products with a long K (the data gradient of the ADM nets' concatenated emb_layers: 16 x 30 k -> 768) take the split-K
+    form (dxmi_linear_splitk: slices of K in parallel, summed in slice order): against fp32 on the same bf16 operands, bitwise
+    reproducible, and a shape that does not split is untouched."""
+    from dxmi_hip import _lib
+    S = _lib.load().dxmi_linear_splitk_slices(P, K, M)
+    assert S > 1 and _lib.load().dxmi_linear_splitk_slices(256, 512, 4992) == 1 and _lib.load().dxmi_linear_splitk_slices(16, 30720, 770) == 0
+    g = torch.Generator().manual_seed(P + K + M)
+    x = torch.randn(P, K, generator=g)
+    w = bf(torch.randn(M, K, generator=g) / math.sqrt(K))
+    b = torch.randn(M, generator=g) if bias else None
+    ref = F.linear(bf(x), w, b)
+    pw = ops.pack_conv_weight(w.to(DEV))
+    got = ops.linear(x.to(DEV), pw, b.to(DEV) if bias else None)
+    assert rel_l2(got.cpu(), ref) < 2e-3, rel_l2(got.cpu(), ref)
+    assert torch.equal(got, ops.linear(x.to(DEV), pw, b.to(DEV) if bias else None))
+
+
 def test_var_step_and_gather(ops):
     g = torch.Generator().manual_seed(3)
     N, T = 6, 10
