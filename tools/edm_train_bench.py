@@ -55,6 +55,28 @@ for _ in range(steps):
     dt, le, ls = step()
     tot = [a + b for a, b in zip(tot, dt)]
 tot = [x / steps for x in tot]
+if os.environ.get("DXMI_HOST_COST", "0") == "1":
+    # HOST cost of the same step: every dxmi_* kernel entry point stubbed out (returns DXMI_OK without launching; size / selection
+    # queries still answer), torch's own small ops still run.  Compare with the real step: host-bound where the two are close.
+    from dxmi_hip import _lib
+    real = _lib.load()
+
+    class Stub:
+        def __getattr__(self, name):
+            f = getattr(real, name)
+            if name.endswith(("_bytes", "_partials", "_supported", "_slices")) or name in ("dxmi_mt_blocks", "dxmi_last_error", "dxmi_conv2d_kernel_id",
+                                                                                                  "dxmi_device_check", "dxmi_version", "dxmi_get_tuning", "dxmi_set_tuning"):
+                return f
+            return lambda *a: 0
+    _lib._lib = Stub()
+    step()
+    th = [0, 0, 0]
+    for _ in range(steps):
+        dt, _, _ = step()
+        th = [a + b for a, b in zip(th, dt)]
+    _lib._lib = real
+    th = [x / steps for x in th]
+    print(f"host only (kernels stubbed): sample {th[0]*1e3:.0f} ms, update_f_v {th[1]*1e3:.0f} ms, update_sampler {th[2]*1e3:.0f} ms = {sum(th)*1e3:.0f} ms per step")
 print(f"{name} B={B}: sample {tot[0]*1e3:.0f} ms, update_f_v {tot[1]*1e3:.0f} ms, update_sampler {tot[2]*1e3:.0f} ms -> {1/sum(tot):.3f} steps/s; "
       f"v_loss {le['ebm/v_loss_']:.4f} sampler_loss {ls['sampler/sampler_loss_']:.4f} lg_loss_scale {mp.lg_loss_scale:.3f} "
       f"peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB")
