@@ -366,7 +366,10 @@ def class_rooflines(summ, step_seconds):
         if sec <= 0:
             continue
         # conv_other = conv_out (128 -> 3 channels): one read of the activation per 3 outputs, AI ~26 FLOP/B -> HBM-graded
-        mfma = cls in ("conv3x3", "conv1x1", "wgrad")
+        # attention: graded by its own arithmetic intensity against the ridge (2.5 PFLOP/s / 8 TB/s = 312 FLOP/B): the CIFAR net's
+        # single 256-token head (AI ~128) is HBM-bound, the ADM nets' 1024-token blocks (AI = T / 2 = 512) are MFMA-bound
+        ridge = MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)
+        mfma = cls in ("conv3x3", "conv1x1", "wgrad") or (cls == "attention" and c["bytes"] > 0 and c["flops"] / c["bytes"] > ridge)
         e = {"bound": "mfma" if mfma else "hbm", "launches": c["launches"], "ms_per_step": round(c["ms"], 3),
              "share_of_step_time": round(sec / step_seconds, 4),
              "algorithmic_tflops": round(c["flops"] / sec / 1e12, 1), "algorithmic_gbps": round(c["bytes"] / sec / 1e9, 1)}
