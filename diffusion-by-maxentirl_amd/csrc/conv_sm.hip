@@ -350,13 +350,17 @@ __global__ __launch_bounds__(256 + 64 * NL) void conv_sm_kernel(ConvArgs p) {
 
 // Launches the small-map kernel when the shape is in its scope; returns 1 otherwise (caller falls back).
 int conv_sm_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
-    // bit 0: 4x4 maps (32-cout tiles), bit 1: every 8x8 map, bit 2: 8x8 maps whose conv_ws8 grid (256-pixel x 128-cout tiles) would
+    // bit 0: 4x4 maps (32-cout tiles), bit 1: every 8x8 map, bit 3: see below, bit 2: 8x8 maps whose conv_ws8 grid (256-pixel x 128-cout tiles) would
     // leave more than half of the CUs idle (round 4: the EDM nets at the train batch of 16 - 24 tiles; 768 -> 768 measured 40.0 us
     // on conv_ws8_kernel, 18.6 us here with 192 workgroups; at 150 tiles conv_ws8_kernel is 5-9 % ahead); 0: conv_ws8 / conv_pipe
     // (knob "conv_sm_mask" / DXMI_CONV_SM)
     const int enabled = dxmi_tuning("conv_sm_mask");
     const bool small_grid8 = a.OW == 8 && (long)((a.N * 64 + 255) / 256) * ((a.Cout + 127) / 128) < 128;
-    if (!((a.OW == 4 && (enabled & 1)) || (a.OW == 8 && ((enabled & 2) || ((enabled & 4) && small_grid8))))) return 1;
+    // bit 3 (on by default, a rule on the LAYER SHAPE only, so an image's result stays independent of its batch): 8x8 maps with
+    // >= 1024 channels in and out — the bottom of the LSUN-256 net, whose per-GPU batch of 16 is 32 conv_ws8 tiles; at batch 100
+    // this kernel is ~5 % behind conv_ws8_kernel on such layers, at batch 16 it is 2x ahead
+    const bool wide8 = a.OW == 8 && a.C0 + a.C1 >= 1024 && a.Cout >= 1024;
+    if (!((a.OW == 4 && (enabled & 1)) || (a.OW == 8 && ((enabled & 2) || ((enabled & 4) && small_grid8) || ((enabled & 8) && wide8))))) return 1;
     if (a.in_mode != DXMI_IN_NHWC_BF16 || a.out_mode != DXMI_OUT_NHWC_BF16) return 1;
     if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups != 0 || (a.mask_src && a.residual) || a.act == DXMI_ACT_SILU || a.gn_stats) return 1;   // a mask alone rides the residual path
     if (a.OH != a.OW || (a.OW != 4 && a.OW != 8) || a.IH != a.OH || a.IW != a.OW) return 1;

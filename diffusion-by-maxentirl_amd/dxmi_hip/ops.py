@@ -49,7 +49,7 @@ def tune_for_throughput(on=True):
     smaller tiles.  Off (the library default), every layer shape runs one kernel whatever the batch size, which keeps an image's
     result bitwise independent of the batch it rides in (generation scripts, parity tests)."""
     set_tuning("conv_ws_min_tiles", 96 if on else 0)
-    set_tuning("conv_sm_mask", 5 if on else 1)
+    set_tuning("conv_sm_mask", 13 if on else 9)
 
 
 def get_tuning(name):

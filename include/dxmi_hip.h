@@ -57,10 +57,11 @@ int dxmi_device_check(void);
  * kernels, i.e. results agree to rounding, not bit for bit); unknown names return DXMI_EINVAL.
  *   "conv_ws_min_tiles" [DXMI_CONV_WS_MIN_TILES, 0]: 3x3 convs with fewer (256-pixel, 128-cout) tiles run on the 64-pixel-tile
  *                        kernel instead of the wave-specialised one (small batches leave most CUs without a tile);
- *   "conv_sm_mask"      [DXMI_CONV_SM, 1]: bit 0 4x4 maps, bit 1 every 8x8 map, bit 2 8x8 maps whose 256-pixel-tile grid is
- *                        under-filled, on the feed-tiled small-map kernel.
+ *   "conv_sm_mask"      [DXMI_CONV_SM, 9]: bit 0 4x4 maps, bit 1 every 8x8 map, bit 2 8x8 maps whose 256-pixel-tile grid is
+ *                        under-filled, bit 3 8x8 maps with >= 1024 channels in and out (a rule on the layer shape, not on the
+ *                        batch), on the feed-tiled small-map kernel.
  * Defaults: one kernel per layer shape whatever the batch size, so an image's result does not depend on the batch it rides in.
- * The training entry points set 96 / 5 (throughput at small per-GPU batches; +5..8 % on the EDM train step).  The answers of
+ * The training entry points set 96 / 13 (throughput at small per-GPU batches; +5..8 % on the EDM train step).  The answers of
  * dxmi_conv2d_gn_stats_partials / dxmi_conv2d_gn_fuse_supported depend on the knobs: query again after changing one.
  * No reference counterpart (the reference leaves algorithm choice to cuDNN). */
 int dxmi_set_tuning(const char* name, int32_t value);

@@ -178,6 +178,26 @@ def test_small_grid_routing(ops):
         ops.set_tuning("conv_sm_mask", old[1])
 
 
+def test_wide_8x8_layers_take_the_feed_tiled_kernel(ops):
+    """Library defaults (knobs 0 / 9): the one shape rule that is on by default depends on the LAYER only — 8x8 maps with >= 1024
+    channels in and out (the bottom of the LSUN-256 net) run on conv_sm_kernel at every batch size, so a sub-batch reproduces
+    the rows of the full batch bit for bit; narrower 8x8 layers stay on conv_ws8_kernel."""
+    old = ops.set_tuning("conv_ws_min_tiles", 0), ops.set_tuning("conv_sm_mask", 9)
+    try:
+        for (N, C, want) in [(16, 1024, "sm"), (3, 1024, "sm"), (16, 768, "ws8")]:
+            y, ref, kid = run_conv(ops, N, C, 0, C, 8, 3, False, "bias+res")
+            assert (450000 <= kid < 460000) == (want == "sm") and (kid == 400008) == (want == "ws8"), (N, C, kid)
+            assert rel_l2(nchw(y), ref) < 4e-3
+        g = torch.Generator().manual_seed(77)
+        x = torch.randn(16, 8, 8, 1024, generator=g).to(torch.bfloat16).to(DEV)
+        pw = ops.pack_conv_weight((torch.randn(1024, 1024, 3, 3, generator=g) * 0.01).to(DEV))
+        full = ops.conv2d(x, pw)
+        assert torch.equal(ops.conv2d(x[5:8].contiguous(), pw), full[5:8])
+    finally:
+        ops.set_tuning("conv_ws_min_tiles", old[0])
+        ops.set_tuning("conv_sm_mask", old[1])
+
+
 def test_round2_kernels_out_of_scope_shapes_fall_back(ops):
     """shapes just outside the new kernels' scope still run (on the round-1 kernels) and agree with the reference"""
     for (N, C0, C1, Cout, H, k, fuse) in [(2, 128, 0, 96, 32, 3, "bias"),       # Cout % 64 != 0

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "diffusion-by-ma
 from dxmi_hip import ops
 dev = "cuda:0"
 B = int(os.environ.get("B", 16))
-SHAPES = ((192, 192, 64), (384, 192, 64), (384, 384, 32), (768, 384, 32), (576, 576, 16), (1152, 576, 16), (768, 768, 8), (1536, 768, 8))
+SHAPES = tuple(tuple(int(v) for v in t.split(",")) for t in os.environ["SHAPES"].split(";")) if "SHAPES" in os.environ else ((192, 192, 64), (384, 192, 64), (384, 384, 32), (768, 384, 32), (576, 576, 16), (1152, 576, 16), (768, 768, 8), (1536, 768, 8))
 for (cin, cout, h) in SHAPES:
     x = torch.randn(B, h, h, cin, device=dev).to(torch.bfloat16)
     pw = ops.pack_conv_weight(torch.randn(cout, cin, 3, 3, device=dev) * 0.05)
