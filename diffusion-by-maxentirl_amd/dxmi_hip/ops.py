@@ -17,8 +17,32 @@ IN_NHWC_BF16, IN_NCHW_F32_K27 = 0, 1
 OUT_NHWC_BF16, OUT_NCHW_F32 = 0, 1
 
 
+# torch.cuda.current_stream() costs ~9 us of Python per call (device-index and availability checks, a Stream object) and sits in
+# front of every launch: a train step spent 14 ms of its 57 ms of host time there (tools/host_profile.py).  The raw handle of the
+# same stream comes from two C calls.
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+        return ctypes.c_void_p(_RAW_STREAM(_GET_DEVICE()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def fast_parameters(module):
+    """module.parameters() without nn.Module's name-building / de-duplication machinery (a U-Net's `tuple(... for p in
+    net.parameters())` was ~1 ms of Python per forward): the submodules that own parameters are listed once (the module tree is fixed
+    after construction), their `_parameters` dictionaries are read live, in the order `parameters()` yields.  No parameter of
+    these nets is shared between two modules."""
+    mods = module.__dict__.get("_dxmi_param_modules")
+    if mods is None:
+        mods = [m for m in module.modules() if m._parameters]
+        module.__dict__["_dxmi_param_modules"] = mods
+    for m in mods:
+        for prm in m._parameters.values():
+            if prm is not None:
+                yield prm
 
 
 def _ptr(t):

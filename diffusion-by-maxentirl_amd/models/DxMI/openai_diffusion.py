@@ -79,7 +79,7 @@ class OpenAIDiffusion:
             sigma_up = s
         x = x.contiguous().float()
         z = torch.randn_like(x) if noise is None else noise
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in ops.fast_parameters(self.net)):
             return self._sample_step_grad(x, z, sigma, sigma_down, sigma_up, model_kwargs)
         x_in, rescaled_t = ops.edm_precond(x, sigma.contiguous(), self.diffusion.sigma_data)
         model_output = self.net(x_in, rescaled_t, **model_kwargs)

@@ -26,6 +26,15 @@ from ..diffusion import extract, make_beta_schedule
 from .replay import TransitionRing, buffer_gather, buffer_rows
 
 
+def _set_mode(module, training):
+    """module.train() / module.eval() when the mode actually changes: the recursive flag walk over the module tree ran 24 times per
+    train step (the reference toggles the value net around every TD target), ~2 ms of host time."""
+    if getattr(module, "training", None) is None:          # OpenAIDiffusion: a plain object forwarding train() / eval() to its net
+        (module.train if training else module.eval)()
+    elif module.training != training:
+        module.train(training)
+
+
 def reset_buffer(device, ring=None):
     """Empty transition buffer (reference :58-70).  ring: a TransitionRing to recycle (its rows are dropped)."""
     if ring is not None:
@@ -131,7 +140,7 @@ class DxMI_Trainer:
         self.optimizer_v.zero_grad()
         x0 = x_seq[-1]
         n_steps, batchsize, device = self.n_timesteps, self.batchsize, img.device
-        self.v.train()
+        _set_mode(self.v, True)
         # energy step: the last value step is the energy
         Tt = n_steps * torch.ones(len(img) + len(x0), dtype=torch.long, device=device)
         output = self.v(torch.cat((img.detach(), x0.detach()), 0), Tt)
@@ -170,7 +179,7 @@ class DxMI_Trainer:
             running_cost = self.get_running_cost(state, next_state, pred_mean, pred_std, timestep)
             if need_entropy:
                 entropy = torch.log(pred_std.squeeze())
-            self.v.eval()
+            _set_mode(self.v, False)
             with torch.no_grad():
                 target = self.v(next_state, timestep + 1).squeeze()
             target = target + self._time_cost_terms(timestep)
@@ -181,13 +190,13 @@ class DxMI_Trainer:
             if self.entropy_in_value or self.entropy_in_value == 0:
                 assert isinstance(self.entropy_in_value, int), "self.entropy_in_value should be interger"
                 target = target - entropy * self.tau1 * (timestep < n_steps - self.entropy_in_value).float()
-            self.v.train()
+            _set_mode(self.v, True)
             v_xt = self.v(state, timestep).squeeze()
             v_loss = F.mse_loss(v_xt, target.detach())
             v_loss.backward()
             self.sync_v()
             if self.value_grad_clip:
-                self._clip(self.v.parameters(), 0.1)
+                self._clip(ops.fast_parameters(self.v), 0.1)
             self.optimizer_v.step()
             self.optimizer_v.zero_grad()
             d_running_cost[f"running_cost/step_{update_t}_"] = running_cost.detach().mean()
@@ -204,8 +213,8 @@ class DxMI_Trainer:
     # ------------------------------------------------------------------ policy update
     def update_sampler(self, state_dict, n_generator, d_sample=None):
         """reference :348-408."""
-        self.v.eval()
-        self.sampler.train()
+        _set_mode(self.v, False)
+        _set_mode(self.sampler, True)
         permutation = torch.randperm(buffer_rows(state_dict))
         batchsize = self.batchsize
         n_data = min(len(permutation), batchsize * n_generator)
@@ -225,7 +234,7 @@ class DxMI_Trainer:
             sampler_loss = (sampler_value_loss + (running_cost * self.tau2 - causal_entropy * self.tau1) * non_terminal).mean()
             sampler_loss.backward()
             self.sync_sampler()   # the value net's side-effect gradients of this backward are discarded, not reduced
-            self._clip(self.sampler.parameters(), 0.1)
+            self._clip(ops.fast_parameters(self.sampler), 0.1)
             self.optimizer.step()
         logs = {"sampler/sampler_loss_": sampler_loss.detach(), "sampler/sampler_value_loss_": sampler_value_loss.detach().mean(),
                 "sampler/running_cost_": running_cost.detach().mean(), "sampler/causal_entropy_": causal_entropy.detach().mean()}
@@ -244,7 +253,7 @@ class DxMI_Trainer:
         from torch.distributions import Normal
         from ..modules import process_single_t
         assert guidance_scale is not None, "guidance_scale must be given"
-        self.v.eval()
+        _set_mode(self.v, False)
         if x0 is None:
             x0 = self._guidance_x0_scale(torch.randn(n_sample, *self.sampler.sample_shape, device=device))
         x0 = x0.to(device)
@@ -284,7 +293,7 @@ class DxMI_Trainer:
         accumulates and then discards them, trainer.py:235 / :387 — skipping the weight-gradient kernels changes nothing)."""
 
         def __init__(self, module):
-            self.ps = [p for p in module.parameters() if p.requires_grad]
+            self.ps = [p for p in ops.fast_parameters(module) if p.requires_grad]
 
         def __enter__(self):
             for p in self.ps:
@@ -385,7 +394,7 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
         x0 = d_sample["l_sample"][-1]
         n_steps, batchsize, device = self.n_timesteps, self.batchsize, img.device
         self.optimizer_v.zero_grad()
-        self.v.train()
+        _set_mode(self.v, True)
         Tt = n_steps * torch.ones(len(img) + len(x0), dtype=torch.long, device=device)
         ys = torch.cat((y, y), 0) if y is not None else None
         output = self.v(torch.cat((img.detach(), x0.detach()), 0), Tt, y=ys)
@@ -432,7 +441,7 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
                 running_cost = self.get_running_cost(state, next_state, pred_mean, pred_std, timestep)
                 if self.entropy_in_value is not None:
                     entropy = torch.log(pred_std.squeeze() / self.sigma_scale) if self.sigma_scale is not None else torch.log(pred_std.squeeze())
-                self.v.eval()
+                _set_mode(self.v, False)
                 with torch.no_grad():
                     target = self.v(next_state, timestep + 1, y=y).squeeze()
                 if self.time_cost is not None:
@@ -446,13 +455,13 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
                 if self.entropy_in_value is not None:
                     assert isinstance(self.entropy_in_value, int), "self.entropy_in_value should be interger"
                     target = target - entropy * self.tau1 * (timestep < n_steps - self.entropy_in_value).float() * self.entropy_value_scale
-                self.v.train()
+                _set_mode(self.v, True)
                 v_xt = self.v(state, timestep, y=y).squeeze()
                 v_loss = F.mse_loss(v_xt, target.detach())
                 v_loss.backward()
                 self.sync_v()
                 if self.value_grad_clip:
-                    self._clip(self.v.parameters(), 0.1)
+                    self._clip(ops.fast_parameters(self.v), 0.1)
                 self.optimizer_v.step()
                 self.optimizer_v.zero_grad()
                 d_running_cost[f"running_cost/step_{update_t}_"] = running_cost.detach().mean()
@@ -476,8 +485,8 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
 
     def update_sampler_mixed_precision(self, state_dict, mp_trainer, d_sample=None):
         """reference :693-746: one optimiser step per `batchsize` slice of ALL buffered transitions."""
-        self.v.eval()
-        self.sampler.train()
+        _set_mode(self.v, False)
+        _set_mode(self.sampler, True)
         permutation = torch.randperm(buffer_rows(state_dict))
         batchsize = self.batchsize
         device = state_dict.device if isinstance(state_dict, TransitionRing) else state_dict["state"].device
@@ -555,16 +564,16 @@ class DxMI_Trainer_EV(DxMI_Trainer):
         x0 = d_sample["l_sample"][-1]
         n_steps, batchsize, device = self.n_timesteps, self.batchsize, img.device
         self.optimizer_fstar.zero_grad()
-        self.f.train()
+        _set_mode(self.f, True)
         output = self.f(torch.cat((img.detach(), x0.detach()), 0))
         pos_e, neg_e = output[:x0.shape[0]], output[x0.shape[0]:]
         d_loss = pos_e.mean() - neg_e.mean()
         d_loss.backward()
         self.sync_f()
-        self._clip(self.f.parameters(), 0.1)
+        self._clip(ops.fast_parameters(self.f), 0.1)
         self.optimizer_fstar.step()
         self.optimizer_fstar.zero_grad()
-        self.f.eval()
+        _set_mode(self.f, False)
         self.optimizer_v.zero_grad()
         permutation = torch.randperm(batchsize * n_steps)                     # CPU generator, as the reference
         indices = (permutation + (buffer_rows(state_dict) - batchsize * n_steps)).to(device)
@@ -580,9 +589,9 @@ class DxMI_Trainer_EV(DxMI_Trainer):
                 next_state, pred_std = d_step["sample"], d_step["sigma"]
                 running_cost = self.get_running_cost(state, next_state, timestep)
                 entropy = torch.log(pred_std.squeeze())
-                self.v.eval()
+                _set_mode(self.v, False)
                 target = self._terminal_mix(next_state, timestep) + running_cost * self.tau2 - entropy * self.tau1
-            self.v.train()
+            _set_mode(self.v, True)
             v_xt = self.v(state, timestep).squeeze()
             v_loss = F.mse_loss(v_xt, target.detach())
             v_loss.backward()
@@ -600,9 +609,9 @@ class DxMI_Trainer_EV(DxMI_Trainer):
 
     def update_sampler(self, state_dict, n_generator):
         """reference :1030-1078."""
-        self.f.eval()
-        self.v.eval()
-        self.sampler.train()
+        _set_mode(self.f, False)
+        _set_mode(self.v, False)
+        _set_mode(self.sampler, True)
         permutation = torch.randperm(buffer_rows(state_dict))
         batchsize = self.batchsize
         n_data = min(len(permutation), batchsize * n_generator)
@@ -621,7 +630,7 @@ class DxMI_Trainer_EV(DxMI_Trainer):
             sampler_loss = sampler_value_loss + running_cost * self.tau2 - causal_entropy * self.tau1
             sampler_loss.backward()
             self.sync_sampler()
-            self._clip(self.sampler.parameters(), 0.1)
+            self._clip(ops.fast_parameters(self.sampler), 0.1)
             self.optimizer.step()
         logs = {"sampler/sampler_loss_": sampler_loss.detach(), "sampler/sampler_value_loss_": sampler_value_loss.detach(),
                 "sampler/running_cost_": running_cost.detach(), "sampler/causal_entropy_": causal_entropy.detach()}

@@ -180,7 +180,7 @@ class Model(nn.Module):
 
     def _param_key(self):
         # torch bumps _version on every in-place update (optimizer.step, load_state_dict, .to())
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in ops.fast_parameters(self))
 
     def _pack(self):
         """(Re)build the bf16 MFMA weight fragments from the fp32 master parameters."""
@@ -296,7 +296,7 @@ class Model(nn.Module):
         assert x.shape[2] == x.shape[3] == self.resolution
         if not x.is_cuda:
             raise DxmiError("models.DxMI.unet_small.Model runs only on the HIP device path (no CPU fallback)")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in ops.fast_parameters(self))):
             from .unet_small_train import forward_with_grad  # autograd wrapper around the HIP kernels
             return forward_with_grad(self, x, t)
         return self.forward_inference(x, t, temb_rows=temb_rows)

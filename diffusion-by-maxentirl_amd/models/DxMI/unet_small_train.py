@@ -281,4 +281,4 @@ class _UNetFn(torch.autograd.Function):
 
 
 def forward_with_grad(net, x, t):
-    return _UNetFn.apply(net, x, t, *list(net.parameters()))
+    return _UNetFn.apply(net, x, t, *ops.fast_parameters(net))

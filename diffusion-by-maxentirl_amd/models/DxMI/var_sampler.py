@@ -243,7 +243,7 @@ class VARSampler(nn.Module):
             raise DxmiError("VARSampler.sample_step runs only on the HIP device path")
         self._check_t(t)
         t = process_single_t(x, t)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in ops.fast_parameters(self.net)):
             from .var_sampler_train import sample_step_with_grad
             return sample_step_with_grad(self, x, t, noise)
         z = torch.randn_like(x) if noise is None else noise

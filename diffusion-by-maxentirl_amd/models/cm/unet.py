@@ -169,7 +169,7 @@ class UNetModel(nn.Module):
 
     # ------------------------------------------------------------------ weight fragments
     def _param_key(self):
-        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return tuple((p.data_ptr(), p._version) for p in ops.fast_parameters(self))
 
     def _pack(self):
         with ops.pack_batch():            # every pack below runs in a few multi-tensor launches
@@ -278,7 +278,7 @@ class UNetModel(nn.Module):
             "must specify y if and only if the model is class-conditional"
         if not x.is_cuda:
             raise DxmiError("models.cm.unet.UNetModel runs only on the HIP device path (no CPU fallback)")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in ops.fast_parameters(self))):
             from .unet_train import forward_with_grad  # autograd wrapper around the HIP kernels
             return forward_with_grad(self, x, timesteps, y)
         return self.forward_inference(x, timesteps, y)

@@ -317,4 +317,4 @@ class _EDMUNetFn(torch.autograd.Function):
 
 
 def forward_with_grad(net, x, timesteps, y=None):
-    return _EDMUNetFn.apply(net, x, timesteps, y, *list(net.parameters()))
+    return _EDMUNetFn.apply(net, x, timesteps, y, *ops.fast_parameters(net))

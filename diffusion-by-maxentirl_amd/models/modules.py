@@ -81,7 +81,7 @@ class IGEBMEncoderV2(nn.Module):
 
     # ---- bf16 weight fragments, rebuilt when a parameter's version changes
     def packed(self):
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in ops.fast_parameters(self))
         if self._packed is None or key != self._packed_key:
             with ops.pack_batch():             # one multi-tensor launch for the net's weights
                 pk = {"conv1": ops.pack_conv_weight(self.conv1.weight, k27=(self.in_chan == 3))}
@@ -95,7 +95,7 @@ class IGEBMEncoderV2(nn.Module):
 
     def packed_transposed(self):
         """Transpose-flipped fragments: the data-gradient operators of the block convs."""
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in ops.fast_parameters(self))
         if self._packed_t is None or key != self._packed_t_key:
             pk = {}
             with ops.pack_batch():
@@ -110,7 +110,7 @@ class IGEBMEncoderV2(nn.Module):
     def forward(self, input, y=None):
         if not input.is_cuda:
             raise DxmiError("models.modules.IGEBMEncoderV2 runs only on the HIP device path (no CPU fallback)")
-        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in ops.fast_parameters(self))):
             from .value_train import forward_with_grad  # autograd wrapper around the HIP kernels
             return forward_with_grad(self, input)
         return self.forward_inference(input)

@@ -108,4 +108,4 @@ class _ValueNetFn(torch.autograd.Function):
 
 
 def forward_with_grad(net, x):
-    return _ValueNetFn.apply(net, x, *list(net.parameters()))
+    return _ValueNetFn.apply(net, x, *ops.fast_parameters(net))

@@ -47,3 +47,24 @@ cores = bench.usable_cores()
 print(f"generation step (256 images x T=10): GPU wall {w_real*1e3:.1f} ms; host time to queue it {h_real*1e3:.1f} ms; "
       f"host time with kernels stubbed {w_stub*1e3:.1f} ms  -> one rank keeps {w_stub/w_real:.2f} of a core busy; "
       f"8 ranks on {cores} usable cores: {8*w_stub/w_real/cores:.2f} of the host")
+
+
+# ---- the DxMI train step (bench.py's second leg): host time with the kernels stubbed against the real step
+from models.DxMI.replay import TransitionRing
+ops.tune_for_throughput(True)
+tr = bench.build_trainer(sampler, dev, B, 10)
+ring = TransitionRing(1, 10, B, (3, 32, 32), dev)
+imgs = torch.rand(B, 3, 32, 32, device=dev) * 2 - 1
+
+
+def train():
+    return bench.train_step(tr, sampler, imgs, dev, ring)
+
+
+for _ in range(2):
+    train()
+h_real, w_real = timed(train, 4)
+_lib._lib = Stub()
+h_stub, w_stub = timed(train, 4)
+_lib._lib = real
+print(f"train step: GPU wall {w_real*1e3:.1f} ms; host time with kernels stubbed {w_stub*1e3:.1f} ms -> {w_stub/w_real:.2f} of a core per rank")
