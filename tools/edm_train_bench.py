@@ -70,6 +70,13 @@ if os.environ.get("DXMI_HOST_COST", "0") == "1":
             return lambda *a: 0
     _lib._lib = Stub()
     step()
+    if os.environ.get("DXMI_HOST_PROFILE", "0") == "1":
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        step()
+        pr.disable()
+        pstats.Stats(pr).sort_stats("tottime").print_stats(30)
     th = [0, 0, 0]
     for _ in range(steps):
         dt, _, _ = step()
