@@ -159,6 +159,7 @@ class UNetModel(nn.Module):
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
         self.out = nn.Sequential(normalization(ch), nn.SiLU(), zero_module(conv_nd(dims, input_ch, out_channels, 3, padding=1)))
         self._packed, self._packed_key = None, None
+        self._pack_plan, self._fp32_params = None, False
 
     def convert_to_fp16(self):
         """Accepted for script compatibility (generate_large.py:129-130): activations are bf16 in the HIP
@@ -172,11 +173,14 @@ class UNetModel(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in ops.fast_parameters(self))
 
     def _pack(self):
-        with ops.pack_batch():            # every pack below runs in a few multi-tensor launches
+        with ops.pack_batch() as pb:      # every pack below runs in a few multi-tensor launches
             pk = {"te0": ops.pack_conv_weight(self.time_embed[0].weight), "te2": ops.pack_conv_weight(self.time_embed[2].weight)}
             blocks = [m for m in self.modules() if isinstance(m, ResBlock)]
-            pk["emb_w"] = ops.pack_conv_weight(torch.cat([b.emb_layers[1].weight for b in blocks], 0))
-            pk["emb_b"] = torch.cat([b.emb_layers[1].bias for b in blocks], 0).detach().float().contiguous()
+            # the concatenated emb_layers operands live in buffers of their own, refreshed in place by _repack()
+            self._emb_w_cat = torch.cat([b.emb_layers[1].weight.detach() for b in blocks], 0).float().contiguous()
+            pk["emb_w"] = ops.pack_conv_weight(self._emb_w_cat)
+            pk["emb_b"] = torch.cat([b.emb_layers[1].bias.detach() for b in blocks], 0).float().contiguous()
+            self._emb_blocks = blocks
             off = 0
             for b in blocks:
                 pk[id(b), "eoff"] = off
@@ -196,12 +200,27 @@ class UNetModel(nn.Module):
             conv_in = self.input_blocks[0][0]
             pk["conv_in"] = ops.pack_conv_weight(conv_in.weight, k27=(self.in_channels == 3))
             pk["conv_out"] = ops.pack_conv_weight(self.out[2].weight)
+        self._pack_plan = pb.plan
         return pk
+
+    def _repack(self):
+        """Parameters updated in place (an optimiser step: same addresses, new versions): the same sources into the same fragment
+        buffers, one call (ops.PackPlan)."""
+        torch.cat([b.emb_layers[1].weight.detach() for b in self._emb_blocks], 0, out=self._emb_w_cat)
+        torch.cat([b.emb_layers[1].bias.detach() for b in self._emb_blocks], 0, out=self._packed["emb_b"])
+        self._pack_plan.replay()
 
     def packed(self):
         key = self._param_key()
         if self._packed is None or key != self._packed_key:
-            self._packed, self._packed_key = self._pack(), key
+            moved = self._packed is None or getattr(self, "_pack_plan", None) is None or \
+                len(key) != len(self._packed_key) or any(a[0] != b[0] for a, b in zip(key, self._packed_key))
+            if moved or not self._fp32_params or not ops.PACK_PLAN_REPLAY:
+                self._packed = self._pack()
+                self._fp32_params = all(p.dtype == torch.float32 and p.is_contiguous() for p in ops.fast_parameters(self))
+            else:
+                self._repack()
+            self._packed_key = key
         return self._packed
 
     # ------------------------------------------------------------------ fused blocks

@@ -28,8 +28,23 @@ def _pack_t(net):
     if getattr(net, "_packed_t", None) is not None and net._packed_t_key == key:
         return net._packed_t
     from .unet import AttentionBlock, Downsample, ResBlock, Upsample
+    old = getattr(net, "_packed_t", None)
+    if ops.PACK_PLAN_REPLAY and old is not None and getattr(net, "_pack_t_plan", None) is not None and net._fp32_params and len(key) == len(net._packed_t_key) \
+            and all(a[0] == b[0] for a, b in zip(key, net._packed_t_key)):
+        # parameters updated in place: the same sources into the same buffers (ops.PackPlan); the padded conv_out source and the
+        # concatenated emb_layers operand are refreshed in place first
+        w = net.out[2].weight
+        net._wpad_t[: w.shape[0]] = w.detach()
+        if "emb_t" in old:
+            torch.cat([b.emb_layers[1].weight.detach() for b in net._emb_blocks], 0, out=net._emb_w_cat_t)
+            net._pack_t_plan2.replay()
+        net._pack_t_plan.replay()
+        for k in [k for k in old if k not in net._pack_t_planned]:
+            del old[k]                      # packed on demand by the backward (conv_in_t, the per-source skip_t pairs): stale now
+        net._packed_t_key = key
+        return old
     pk = {}
-    with ops.pack_batch():            # a few multi-tensor launches instead of one per layer
+    with ops.pack_batch() as pb:      # a few multi-tensor launches instead of one per layer
         for m in net.modules():
             if isinstance(m, ResBlock):
                 pk[id(m), "conv1"] = ops.pack_conv_weight(m.in_layers[2].weight, transpose_flip=True)
@@ -45,7 +60,10 @@ def _pack_t(net):
         w = net.out[2].weight
         wpad = torch.zeros((64,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device)
         wpad[: w.shape[0]] = w.detach()
+        net._wpad_t = wpad
         pk["conv_out"] = ops.pack_conv_weight(wpad, transpose_flip=True)
+    net._pack_t_plan, net._pack_t_plan2 = pb.plan, None
+    net._pack_t_planned = set(pk.keys()) | {"emb_t", "te2_t"}      # what the two plans refresh
     net._packed_t, net._packed_t_key = pk, key
     return pk
 
@@ -294,8 +312,11 @@ class _EDMUNetFn(torch.autograd.Function):
             emb = emb + net.label_emb.weight.detach()[ctx.y]
         s_e = F.silu(emb)
         if "emb_t" not in pkt:
-            pkt["emb_t"] = ops.pack_conv_weight(torch.cat([b.emb_layers[1].weight for b in blocks], 0), transpose_flip=True)
-            pkt["te2_t"] = ops.pack_conv_weight(l2.weight, transpose_flip=True)
+            with ops.pack_batch() as pb2:
+                net._emb_w_cat_t = torch.cat([b.emb_layers[1].weight.detach() for b in blocks], 0).float().contiguous()
+                pkt["emb_t"] = ops.pack_conv_weight(net._emb_w_cat_t, transpose_flip=True)
+                pkt["te2_t"] = ops.pack_conv_weight(l2.weight, transpose_flip=True)
+            net._pack_t_plan2 = pb2.plan
         ds, dw_cat, db_cat = ops.linear_bwd(s_e, d_emb_all, pkt["emb_t"])
         off = 0
         for b in blocks:

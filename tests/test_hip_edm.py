@@ -433,6 +433,62 @@ def test_groupnorm_generic_bwd(ops, N, C0, C1, H, silu, ss):
 
 
 @pytest.mark.parametrize("tag", ["", "_plain"])
+def test_pack_plan_replay_equals_a_fresh_pack(ops, tag):
+    """After an in-place parameter update (an optimiser step: same addresses, new versions) the nets re-pack by REPLAYING the
+    descriptor array of their first pack into the same fragment buffers (ops.PackPlan).  Every buffer — forward fragments,
+    transposed fragments of the backward, the concatenated emb_layers operands, the bias row — must equal a pack built from scratch,
+    also for the items the backward packs on demand."""
+    from models.cm.unet_train import _pack_t, forward_with_grad
+    net, _, _ = build(TINY_KW, PLAIN if tag else None)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 16, 16, generator=g).to(DEV).requires_grad_(True)
+    t = torch.tensor([700.0, -900.0], device=DEV)
+    y = None if tag else torch.tensor([5, 321], device=DEV)
+
+    def fwd_bwd():
+        for p in net.parameters():
+            p.grad = None
+        out = forward_with_grad(net, x, t, y)
+        out.float().square().mean().backward()
+
+    names = {id(m): n for n, m in net.named_modules()}
+
+    def snapshot():
+        pk, pkt = net.packed(), _pack_t(net)
+        snap = {}
+        for name, d in (("f", pk), ("t", pkt)):
+            for k, v in d.items():
+                mod = "" if isinstance(k, str) else names[k[0]]          # keys are strings or (id(module), role)
+                kk = k if isinstance(k, str) else k[1:]
+                if isinstance(v, ops.PackedConvWeight):
+                    snap[(name, mod, kk)] = v.buf.clone()
+                elif torch.is_tensor(v):
+                    snap[(name, mod, kk)] = v.clone()
+                elif isinstance(v, tuple):                                 # the per-source transposed skip packs
+                    for j, e in enumerate(v):
+                        if isinstance(e, ops.PackedConvWeight):
+                            snap[(name, mod, kk, j)] = e.buf.clone()
+                else:
+                    assert isinstance(v, int), (k, type(v))
+        return snap
+
+    fwd_bwd()                                   # first pack (plans recorded), on-demand items created
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(torch.randn(p.shape, generator=g).to(DEV) * 0.01)      # in place: versions bump, addresses stay
+    fwd_bwd()                                   # re-pack by replay
+    assert net._pack_plan is not None and net._pack_t_plan is not None
+    replayed = snapshot()
+    net._pack_plan = net._pack_t_plan = None    # force packs from scratch of the same parameters
+    net._packed = net._packed_t = None
+    fwd_bwd()
+    fresh = snapshot()
+    assert set(replayed) == set(fresh) and len(fresh) > 10
+    for k in fresh:
+        assert torch.equal(replayed[k], fresh[k]), k
+
+
+@pytest.mark.parametrize("tag", ["", "_plain"])
 def test_unet_backward_vs_oracle(golden_dir, tag):
     """Every parameter gradient of the shrunken ADM U-Net (both variants) against torch autograd through the pinned
     oracle in fp32; the bound is the oracle's own bf16-storage-model noise floor (as for the DDPM U-Net)."""
