@@ -107,6 +107,18 @@ class IGEBMEncoderV2(nn.Module):
             self._packed_t, self._packed_t_key = pk, key
         return self._packed_t
 
+    def train(self, mode=True):
+        """The trainers switch the value net between eval() and train() around every TD target (reference trainer.py:288-295), 24
+        recursive walks of ~50 modules per train step; no module of this encoder reads the flag (no dropout, no batch statistics,
+        spectral norm unsupported), so the flags are set through a flat list."""
+        mods = self.__dict__.get("_dxmi_all_modules")
+        if mods is None:
+            mods = list(self.modules())
+            self.__dict__["_dxmi_all_modules"] = mods
+        for m in mods:
+            m.__dict__["training"] = mode
+        return self
+
     def forward(self, input, y=None):
         if not input.is_cuda:
             raise DxmiError("models.modules.IGEBMEncoderV2 runs only on the HIP device path (no CPU fallback)")
