@@ -294,7 +294,7 @@ def edm_generation_leg(device, name, B, reps=2, events=True):
     return out
 
 
-def edm_train_leg(device, name="imagenet64_T10", B=16, steps=2):
+def edm_train_leg(device, name="imagenet64_T10", B=16, steps=4):
     """One DxMI_Trainer_Cond step (models/DxMI/trainer.py:693-746 through MixedPrecisionTrainer, models/cm/fp16_util.py) on the
     ImageNet-64 EDM net at per-GPU batch `B` (synthetic images / labels): sample T + update_f_v + update_sampler_mixed_precision."""
     import torch
