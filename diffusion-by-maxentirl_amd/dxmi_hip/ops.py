@@ -32,12 +32,13 @@ def _stream():
 
 def fast_parameters(module):
     """module.parameters() without nn.Module's name-building / de-duplication machinery (a U-Net's `tuple(... for p in
-    net.parameters())` was ~1 ms of Python per forward): the submodules that own parameters are listed once (the module tree is fixed
+    net.parameters())` was ~1 ms of Python per forward): the submodules are listed once (the module tree is fixed
     after construction), their `_parameters` dictionaries are read live, in the order `parameters()` yields.  No parameter of
     these nets is shared between two modules."""
     mods = module.__dict__.get("_dxmi_param_modules")
     if mods is None:
-        mods = [m for m in module.modules() if m._parameters]
+        # every submodule, also those without parameters today: the samplers register `log_betas` on a net after construction
+        mods = list(module.modules())
         module.__dict__["_dxmi_param_modules"] = mods
     for m in mods:
         for prm in m._parameters.values():

@@ -183,3 +183,19 @@ def test_train_image_large_config_to_optimizer_groups_dry_run():
     mp, opt, opt_v = train_image_large.build_optimizers(cfg, unet, v)
     assert [g["lr"] for g in opt.param_groups] == [1e-8, 1e-6] and [g["lr"] for g in opt_v.param_groups] == [1e-5]
     assert opt.param_groups[1]["params"][0].numel() == 10 and mp.lg_loss_scale == 20
+
+
+def test_fast_parameters_matches_module_parameters():
+    """ops.fast_parameters (the weight-pack cache keys and the autograd argument lists of the HIP nets) yields exactly
+    `module.parameters()`, in its order, also for a parameter registered on the net after the first call (the samplers add
+    `log_betas` to a finished net, reference var_sampler.py / openai_diffusion.py)."""
+    import torch
+    from dxmi_hip import ops
+    from models.DxMI.unet_small import Model
+    net = Model(ch=32, out_ch=3, ch_mult=(1, 2), num_res_blocks=1, attn_resolutions=[16], dropout=0.0, in_channels=3, resolution=32)
+    a, b = list(ops.fast_parameters(net)), list(net.parameters())
+    assert len(a) == len(b) and all(x is y for x, y in zip(a, b))
+    net.log_betas = torch.nn.Parameter(torch.zeros(10))
+    net.mid.block_1.conv1.weight = torch.nn.Parameter(torch.zeros_like(net.mid.block_1.conv1.weight))      # replaced, not updated
+    a, b = list(ops.fast_parameters(net)), list(net.parameters())
+    assert len(a) == len(b) and all(x is y for x, y in zip(a, b))
