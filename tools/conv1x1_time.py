@@ -6,7 +6,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "diffusion-by-ma
 from dxmi_hip import ops
 dev = "cuda:0"
 B = int(os.environ.get("B", 256))
-for (c0, c1, cout, h, res) in ((256, 0, 768, 16, False), (256, 0, 256, 16, True), (256, 256, 256, 16, True), (128, 0, 256, 16, True),
+SH = os.environ.get("SHAPES")
+CASES = [tuple(int(v) for v in t.split(",")) for t in SH.split(";")] if SH else None
+for (c0, c1, cout, h, res) in CASES or ((256, 0, 768, 16, False), (256, 0, 256, 16, True), (256, 256, 256, 16, True), (128, 0, 256, 16, True),
                                (256, 128, 256, 16, True), (128, 128, 128, 32, True), (256, 128, 128, 32, True), (192, 0, 384, 16, False)):
     cin = c0 + c1
     x0 = torch.randn(B, h, h, c0, device=dev).to(torch.bfloat16)
