@@ -75,6 +75,10 @@ SIGNATURES = {
     "dxmi_attention_proj_supported": (c_int, [c_int, c_int, c_int]),
     "dxmi_pack_attn_proj_weight": (c_int, [c_void_p, c_void_p, c_void_p]),
     "dxmi_attention_proj_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "dxmi_attn_block_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "dxmi_attn_block_packed_bytes": (c_int64, []),
+    "dxmi_attn_block_pack": (c_int, [c_void_p] * 7 + [c_float, c_void_p, c_void_p]),
+    "dxmi_attn_block_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dxmi_timestep_embedding": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "dxmi_linear_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_linear_splitk_slices": (c_int, [c_int, c_int, c_int]),

@@ -698,6 +698,41 @@ def attention_proj(qkv, wproj_packed, bias, residual, heads, scale, out=None, wa
     return (out, stats) if want_stats else out
 
 
+def attn_block_supported(T, C, heads, groups=32):
+    return bool(load().dxmi_attn_block_supported(T, C, heads, groups))
+
+
+def attn_block_pack(wq, bq, wk, wv, bv, wproj, bproj, scale):
+    """Folded + packed weights of a whole AttnBlock (include/dxmi_hip.h: dxmi_attn_block_pack): G = scale Wk^T Wq, W' = Wproj Wv,
+    g = scale Wk^T bq, b' = bproj + Wproj bv.  The k bias has no effect on the block (constant along the key axis of the softmax)."""
+    ws = [t.detach().float().reshape(t.shape[0], -1).contiguous() for t in (wq, wk, wv, wproj)]
+    bs = [t.detach().float().contiguous() for t in (bq, bv, bproj)]
+    _need_cuda(*ws, *bs)
+    assert all(tuple(w.shape) == (256, 256) for w in ws) and all(b.numel() == 256 for b in bs)
+    dst = torch.empty(int(load().dxmi_attn_block_packed_bytes()), dtype=torch.uint8, device=ws[0].device)
+    check(load().dxmi_attn_block_pack(_ptr(ws[0]), _ptr(bs[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(bs[1]), _ptr(ws[3]), _ptr(bs[2]),
+                                      float(scale), _ptr(dst), _stream()), "dxmi_attn_block_pack")
+    return dst
+
+
+def attn_block(x, stats, gamma, beta, packed, eps=1e-6, out=None, want_stats=False):
+    """x + proj_out(attention(q, k, v of GroupNorm(x))) in ONE launch (reference unet_small.py:167-191; dxmi_attn_block_fwd).
+    x [N,16,16,256] or [N,256,256] bf16, stats = its BlockStats; want_stats: -> (out, BlockStats of out)."""
+    _need_cuda(x, stats.buf, gamma, beta, packed, out)
+    shape = x.shape
+    N, C = shape[0], shape[-1]
+    T = x.numel() // (N * C)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(stats.buf.shape) == (N, stats.P, C // 2, 2)
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C and beta.numel() == C
+    if out is None:
+        out = torch.empty_like(x)
+    st = BlockStats(torch.empty((N, 8, C // 2, 2), dtype=torch.float32, device=x.device), 8) if want_stats else None
+    _prof("attention", f"block_T{T}_C{C}", 8.0 * N * T * C * C, 4.0 * N * T * C, lambda: check(
+        load().dxmi_attn_block_fwd(_ptr(x), _ptr(stats.buf), stats.P, _ptr(gamma), _ptr(beta), float(eps), _ptr(packed), _ptr(out),
+                                   st.buf.data_ptr() if want_stats else None, N, T, C, _stream()), "dxmi_attn_block_fwd"))
+    return (out, st) if want_stats else out
+
+
 def timestep_embedding(t, dim, order=0, max_period=10000.0, out=None):
     _need_cuda(t, out)
     t = t.float().contiguous()

@@ -209,6 +209,9 @@ class Model(nn.Module):
                     pk[id(m), "proj"] = ops.pack_conv_weight(m.proj_out.weight)
                     if m.in_channels == 256:      # the 16x16 blocks: proj_out fused behind the attention (ops.attention_proj)
                         pk[id(m), "proj_attn"] = ops.pack_attn_proj_weight(m.proj_out.weight)
+                        # ... and the whole block as one launch (round 5: ops.attn_block, folded Wk^T Wq / Wproj Wv)
+                        pk[id(m), "block"] = ops.attn_block_pack(m.q.weight, m.q.bias, m.k.weight, m.v.weight, m.v.bias,
+                                                                 m.proj_out.weight, m.proj_out.bias, float(int(m.in_channels) ** (-0.5)))
                 elif isinstance(m, (Upsample, Downsample)):
                     pk[id(m), "conv"] = ops.pack_conv_weight(m.conv.weight)
             pk["conv_in"] = ops.pack_conv_weight(self.conv_in.weight, k27=(self.in_channels == 3))
@@ -227,6 +230,7 @@ class Model(nn.Module):
     # GroupNorm block statistics of what it stores, so every Normalize() on them is one streaming read + write
     # (ops.groupnorm_apply).  Smaller maps (8x8, 4x4: 8 % of the GroupNorm bytes) keep the one-pass resident kernel.
     FUSE_ATTN_PROJ = True             # proj_out + residual of the 16x16 AttnBlocks behind the attention kernel
+    FUSE_ATTN_BLOCK = True            # the 16x16 AttnBlocks as ONE launch (norm, q|k|v, attention, proj_out, residual: ops.attn_block)
     FUSE_GN_SMALL = True              # norm2 of the 4x4 ResnetBlocks from conv1's epilogue (instance override: A-B timing)
     FUSE_GN_16 = False                # ... and of the 16x16 ResnetBlocks (conv_ws_gn_kernel): parity-green but 4 % SLOWER end to end
     STREAM_GN_MIN_HW = 256            # instance attribute override (tests / A-B timing): 1 << 30 = one-pass GroupNorm everywhere
@@ -280,6 +284,8 @@ class Model(nn.Module):
 
     def _attn(self, pk, m, x, sx=None):
         N, H, W, C = x.shape
+        if self.FUSE_ATTN_BLOCK and (id(m), "block") in pk and isinstance(sx, ops.BlockStats) and ops.attn_block_supported(H * W, C, 1):
+            return ops.attn_block(x, sx, m.norm.weight, m.norm.bias, pk[id(m), "block"], eps=1e-6, want_stats=True)
         if isinstance(sx, _Normed):
             assert sx.norm is m.norm
             hn = sx.y

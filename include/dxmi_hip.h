@@ -281,6 +281,23 @@ int dxmi_attention_proj_fwd(const void* qkv, const void* wproj_packed, const flo
 /* gn_stats (optional): GroupNorm block statistics of `out`, fp32 [N][8][C/2][2] — one partial per 32 tokens, the layout
  * dxmi_groupnorm_apply reads (P = 8). */
 
+/* The whole AttnBlock in ONE launch (round 5; reference models/DxMI/unet_small.py:167-191: h_ = norm(x); q, k, v = 1x1 convs of
+ * h_; w_ = softmax(q^T k * C^-0.5); h_ = proj_out(v w_^T); return x + h_), for the single-head 256-token x 256-channel blocks of
+ * the CIFAR-10 net (dxmi_attn_block_supported), inference path only.  x: NHWC bf16 [N,256,256]; stats: its GroupNorm block
+ * statistics fp32 [N][P][128][2] (dxmi_conv_desc.gn_stats / dxmi_gn_block_stats layout); gamma / beta: the block's norm.  The
+ * normalised input, q, k, v and the attention output never exist in memory: with G = scale Wk^T Wq and W' = Wproj Wv folded once
+ * per weight version (dxmi_attn_block_pack: fp32 [256][256] OI weights and [256] biases -> dxmi_attn_block_packed_bytes() bytes)
+ * the raw x tile in LDS is K, V and the residual at once (terms constant along the key axis drop out of the softmax; rows of the
+ * softmax sum to one).  out: [N,256,256] bf16; out_stats (optional): block statistics of out, fp32 [N][8][128][2].
+ * Tolerance against the reference block in fp32: the same as the three-launch form it replaces (dxmi_groupnorm_apply +
+ * dxmi_conv2d_fwd + dxmi_attention_proj_fwd), see tests/test_hip_round5_kernels.py. */
+int dxmi_attn_block_supported(int32_t T, int32_t C, int32_t heads, int32_t groups);
+int64_t dxmi_attn_block_packed_bytes(void);
+int dxmi_attn_block_pack(const float* wq, const float* bq, const float* wk, const float* wv, const float* bv,
+                         const float* wproj, const float* bproj, float scale, void* dst, void* stream);
+int dxmi_attn_block_fwd(const void* x, const float* stats, int32_t P, const float* gamma, const float* beta, float eps,
+                        const void* packed, void* out, float* out_stats, int32_t N, int32_t T, int32_t C, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Timestep-embedding path.
  * dxmi_timestep_embedding: out[N,dim] fp32 sinusoid of t; freq_i = exp(-ln(max_period)*i/denom)

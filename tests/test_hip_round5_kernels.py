@@ -1,0 +1,138 @@
+"""Round-5 kernels through the C-ABI: the 16x16 AttnBlock as one launch (dxmi_attn_block_fwd: GroupNorm on load, folded
+Wk^T Wq / Wproj Wv, the raw input tile as K, V and residual) against the reference block in torch fp32
+(/root/reference models/DxMI/unet_small.py:167-191) and against the three launches it replaces."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dxmi_hip import ops as o
+    o.device_check()
+    return o
+
+
+def _torch_block_stats(y):
+    """y [N,H,W,C] bf16 -> fp64 [N, C/2, 2]: (sum, sum of squares) per channel pair over the image."""
+    v = y.double().reshape(y.shape[0], -1, y.shape[-1] // 2, 2)
+    return torch.stack([v.sum((1, 3)), (v * v).sum((1, 3))], -1)
+
+
+def _attn_block_params(g, C=256, wscale=0.06):
+    p = {}
+    for name in ("q", "k", "v", "proj"):
+        p[name + "_w"] = (torch.randn(C, C, 1, 1, generator=g) * wscale).to(DEV)
+        p[name + "_b"] = (torch.randn(C, generator=g) * 0.3).to(DEV)
+    p["gamma"] = (1.0 + 0.3 * torch.randn(C, generator=g)).to(DEV)
+    p["beta"] = (0.2 * torch.randn(C, generator=g)).to(DEV)
+    return p
+
+
+def _reference_block(x, p, eps=1e-6):
+    """AttnBlock.forward in fp32 on the bf16 input (token-major [N,T,C])."""
+    N, T, C = x.shape
+    xf = x.float()
+    hn = F.group_norm(xf.transpose(1, 2).reshape(N, C, 16, 16), 32, p["gamma"], p["beta"], eps).reshape(N, C, T).transpose(1, 2)
+    q, k, v = (hn @ p[n + "_w"].view(C, C).t() + p[n + "_b"] for n in ("q", "k", "v"))
+    att = torch.softmax(torch.bmm(q, k.transpose(1, 2)) * float(C) ** -0.5, dim=2)
+    return xf + torch.bmm(att, v) @ p["proj_w"].view(C, C).t() + p["proj_b"]
+
+
+def _three_launches(ops, x4, st, p):
+    N, H, W, C = x4.shape
+    hn = ops.groupnorm_silu(x4, p["gamma"], p["beta"], eps=1e-6, silu=False, stats=(st, None))
+    qkv_w = ops.pack_conv_weight(torch.cat([p["q_w"], p["k_w"], p["v_w"]], 0))
+    qkv = ops.conv2d(hn, qkv_w, bias=torch.cat([p["q_b"], p["k_b"], p["v_b"]], 0).contiguous())
+    return ops.attention_proj(qkv.view(N, H * W, 3 * C), ops.pack_attn_proj_weight(p["proj_w"]), p["proj_b"], x4.view(N, H * W, C),
+                              heads=1, scale=float(C) ** -0.5).view(N, H, W, C)
+
+
+@pytest.mark.parametrize("N,wscale", [(1, 0.06), (5, 0.06), (3, 0.15)])
+def test_attn_block_one_launch(ops, N, wscale):
+    g = torch.Generator().manual_seed(500 + N)
+    T = C = 256
+    assert ops.attn_block_supported(T, C, 1) and not ops.attn_block_supported(64, C, 1) and not ops.attn_block_supported(T, 512, 1)
+    # per-channel offsets and scales so that the GroupNorm has something to do
+    x = (torch.randn(N, T, C, generator=g) * (0.5 + torch.rand(C, generator=g)) + 0.7 * torch.randn(C, generator=g)).to(torch.bfloat16).to(DEV)
+    x4 = x.view(N, 16, 16, C)
+    p = _attn_block_params(g, C, wscale)
+    st = ops.block_stats(x4)
+    packed = ops.attn_block_pack(p["q_w"], p["q_b"], p["k_w"], p["v_w"], p["v_b"], p["proj_w"], p["proj_b"], float(C) ** -0.5)
+    y, yst = ops.attn_block(x4, st, p["gamma"], p["beta"], packed, want_stats=True)
+    torch.cuda.synchronize()
+    assert y.shape == x4.shape and torch.isfinite(y.float()).all()
+    ref = _reference_block(x, p).view(N, 16, 16, C)
+    sep = _three_launches(ops, x4, st, p)
+    branch = (ref - x4.float()).norm().item()          # the attention branch alone (the residual x dominates the output)
+    err_one = (y.float() - ref).norm().item() / branch
+    err_sep = (sep.float() - ref).norm().item() / branch
+    print(f"attn_block N={N} wscale={wscale}: one launch {err_one:.3e}, three launches {err_sep:.3e} of the branch norm")
+    # the output is rounded to bf16 once: ~2^-9 of |x + branch| per element is the floor of both forms
+    floor = (2.0 ** -9) * ref.norm().item() / branch
+    assert err_one < 1.5 * floor + 1e-2, (err_one, floor)
+    assert err_one < 1.25 * err_sep + 2e-3, (err_one, err_sep)
+    # block statistics of the stored output from the same launch
+    assert yst.P == 8 and tuple(yst.buf.shape) == (N, 8, C // 2, 2)
+    want = _torch_block_stats(y).to(DEV)
+    assert ((yst.buf.double().sum(1) - want).abs() <= 1e-4 * (1 + want.abs())).all()
+    want8 = torch.stack([_torch_block_stats(y.view(N, T, C)[:, 32 * k:32 * k + 32].reshape(N, 2, 16, C)) for k in range(8)], 1).to(DEV)
+    assert ((yst.buf.double() - want8).abs() <= 1e-4 * (1 + want8.abs())).all()
+    # the output does not change when no statistics are asked for; bitwise reproducible; independent of the batch it rides in
+    assert torch.equal(y, ops.attn_block(x4, st, p["gamma"], p["beta"], packed))
+    i = N - 1
+    st1 = ops.block_stats(x4[i:i + 1].contiguous())
+    one = ops.attn_block(x4[i:i + 1].contiguous(), st1, p["gamma"], p["beta"], packed)
+    assert torch.equal(one[0], y[i])
+
+
+def test_attn_block_key_bias_is_irrelevant_and_partials_fold(ops):
+    """The k bias drops out of the softmax (constant along the key axis): the packed block ignores it by construction; check the
+    reference agrees.  Statistics with more than 8 partials per image take the serial tail of the prologue."""
+    g = torch.Generator().manual_seed(77)
+    N, T, C = 2, 256, 256
+    x = torch.randn(N, T, C, generator=g).to(torch.bfloat16).to(DEV)
+    p = _attn_block_params(g, C)
+    r0 = _reference_block(x, p)
+    p2 = dict(p)
+    p2["k_b"] = p["k_b"] + 5.0
+    assert ((r0 - _reference_block(x, p2)).abs().max() < 1e-3)
+    x4 = x.view(N, 16, 16, C)
+    st = ops.block_stats(x4)
+    packed = ops.attn_block_pack(p["q_w"], p["q_b"], p["k_w"], p["v_w"], p["v_b"], p["proj_w"], p["proj_b"], float(C) ** -0.5)
+    y = ops.attn_block(x4, st, p["gamma"], p["beta"], packed)
+    # 16 partials per image (one per row of the map) carrying the same totals
+    v = x4.float().reshape(N, 16, 16, C // 2, 2)
+    buf = torch.stack([v.sum((2, 4)), (v * v).sum((2, 4))], -1).contiguous()
+    y16 = ops.attn_block(x4, ops.BlockStats(buf, 16), p["gamma"], p["beta"], packed)
+    assert ((y.float() - y16.float()).abs().max() <= 2 ** -6 * y.float().abs().max())
+    assert ((y.float() - r0.view(N, 16, 16, C)).norm() / (r0 - x.float()).norm()).item() < 5e-2
+
+
+def test_unet_forward_with_and_without_the_one_launch_attn_block():
+    """The DDPM U-Net forward with the five 16x16 AttnBlocks as one launch each against the three-launch path (same weights, same
+    input): both are bf16 pipelines of the same network, so they agree to the bf16 noise floor of a forward."""
+    from models.DxMI.unet_small import Model
+    from oracle.weights import formula_tensor
+    torch.manual_seed(0)
+    net = Model(ch=128, out_ch=3, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=[16], dropout=0.1, in_channels=3, resolution=32)
+    sd = {k: formula_tensor(k, v.shape) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    net = net.to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(6, 3, 32, 32, generator=g).to(DEV)
+    t = torch.tensor([616.7, 1.5e-4, 300.0, 12.0, 900.0, 55.5], device=DEV)
+    with torch.no_grad():
+        net.FUSE_ATTN_BLOCK = True
+        tr1 = []
+        y1 = net.forward_inference(x, t, trace=tr1)
+        net.FUSE_ATTN_BLOCK = False
+        tr0 = []
+        y0 = net.forward_inference(x, t, trace=tr0)
+    worst = max(((a.float() - b.float()).norm() / b.float().norm()).item() for (_, a), (_, b) in zip(tr1, tr0) if a.dtype == torch.bfloat16)
+    rel = ((y1 - y0).norm() / y0.norm()).item()
+    print(f"unet forward one-launch vs three-launch attn blocks: rel-L2 {rel:.3e}, worst block {worst:.3e}")
+    assert torch.isfinite(y1).all() and rel < 1.2e-2 and worst < 2e-2
