@@ -33,9 +33,28 @@
 #include "conv_common.h"
 #include <stdlib.h>
 
+#ifdef DXMI_AB_STAMPS
+// timing-only build (tools/build_variant.sh ... -DDXMI_AB_STAMPS): s_memtime of every wave of the first 16 workgroups at the phase
+// boundaries, kept in LDS until the kernel's end (stamps that address global memory cost the kernel its registers)
+__device__ unsigned g_ab_stamps[16][8][12];
+extern "C" int dxmi_debug_read_ab_stamps(void* dst, int bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ab_stamps), bytes, 0, hipMemcpyDeviceToHost);
+}
+#define AB_STAMP(k) do { reinterpret_cast<unsigned*>(tabs + 1024)[wave * 12 + (k)] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)   /* every lane, same value: no branch */
+#define AB_STAMP_WORDS 96
+#define AB_RSTAMP(k) do { reinterpret_cast<unsigned*>(tabs + 1024)[wave * 12 + (k)] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define AB_STAMP_DUMP() do { if (lane < 12 && blockIdx.x < 16) g_ab_stamps[blockIdx.x][wave][lane] = reinterpret_cast<unsigned*>(tabs + 1024)[wave * 12 + lane]; } while (0)
+#else
+#define AB_STAMP_WORDS 0
+#define AB_STAMP(k) do {} while (0)
+#define AB_RSTAMP(k) do {} while (0)
+#define AB_STAMP_DUMP() do {} while (0)
+#endif
+
 namespace {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define AB_LDS_S16X4(p) ((__attribute__((address_space(3))) s16x4*)(p))
 #define AB_GPTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define AB_LPTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -43,10 +62,24 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ab_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ int ab_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
+// one ring step behind its barrier: MFMA, ring write + queue refill, then MFMA / ring read pairs
+#define AB_INTERLEAVE_STEP()                                    \
+    do {                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      \
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      \
+        _Pragma("unroll") for (int i_ = 0; i_ < 7; ++i_) {      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  \
+        }                                                       \
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      \
+    } while (0)
+
 constexpr int AB_X = 256 * 512;            // the image: 256 tokens x 512 B
 constexpr int AB_SLOT = 8192;              // ring slot: 8 weight fragments
 constexpr int AB_RING = 3 * AB_SLOT;
-constexpr int AB_LDS = AB_X + AB_RING + 8192;      // + tables: A | B | A g | b' (4 KB) + pair sums (1 KB)
+constexpr int AB_Q = 5;                    // register-staged slots in front of the ring
+constexpr int AB_LDS = AB_X + AB_RING;             // dynamic part; + 4 KB static: tables A | B | A g | b'
 constexpr float AB_LOG2E = 1.4426950408889634f;
 
 struct AttnBlockArgs {
@@ -108,12 +141,14 @@ __global__ __launch_bounds__(256) void attn_block_fold_kernel(const float* __res
 
 __global__ __launch_bounds__(512, 1) void attn_block256_kernel(AttnBlockArgs p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
+    // the tables are a separate (static) LDS object: hipcc orders every LDS access that MAY alias an LDS-DMA in flight behind
+    // s_waitcnt vmcnt(0); stores into the dynamic block would wait for the whole image before the table could be formed
+    __shared__ __attribute__((aligned(16))) float tabs[1024 + AB_STAMP_WORDS];
     char* const ring = smem + AB_X;
-    float* const tabA = reinterpret_cast<float*>(smem + AB_X + AB_RING);
+    float* const tabA = tabs;
     float* const tabB = tabA + 256;
     float* const tabG = tabA + 512;
     float* const tabP = tabA + 768;
-    float2* const pairs = reinterpret_cast<float2*>(tabA + 1024);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,68 +157,96 @@ __global__ __launch_bounds__(512, 1) void attn_block256_kernel(AttnBlockArgs p) 
     const int drow = lane >> 5, dslot = lane & 31;
     const bf16* const xn = p.x + (size_t)n * 65536;
 
-    // ---- prologue: this wave's 32 rows of x (16 DMAs of two rows), then the first two ring slots of G
+    AB_STAMP(0);
+    AB_RSTAMP(10);
+    // ---- prologue.  The few small loads of the (A, B) table go first: vector-memory results return in order, so they are back
+    // long before the image, and the table is formed (two LDS hand-overs, barriers that do NOT drain the vector-memory queue)
+    // while the image is still landing.
+    // (inline-asm loads with one counted wait: hipcc's own wait for a load that is older than LDS-DMAs in flight is vmcnt(0), and
+    // so is its wait in front of any LDS access that may alias an LDS-DMA destination — the table is stored by inline asm too.)
+    // Thread t < 128 owns channel pair t: its statistics partials, gamma / beta / g / b' of its two channels.
+    // (64-bit scalars, not 2-vectors: hipcc miscompiles element 1 of a vector-typed inline-asm output — it reads element 0)
+    uint64_t t[8], gab[4];
+    {
+        const int pt = tid & 127;
+        const float2* const sb = reinterpret_cast<const float2*>(p.stats) + (size_t)n * p.P * 128 + pt;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(t[k]) : "v"(sb + (k < p.P ? k : 0) * 128) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(gab[0]) : "v"(p.gamma + 2 * pt) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(gab[1]) : "v"(p.beta + 2 * pt) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(gab[2]) : "v"(p.gvec + 2 * pt) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(gab[3]) : "v"(p.bprime + 2 * pt) : "memory");
+    }
+    // this wave's 32 rows of x (16 DMAs of two rows), then the first two ring slots of G
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         const int r = wave * 32 + 2 * i + drow;
         const bf16* g = xn + (size_t)r * 256 + ((dslot ^ ab_swz(r)) << 3);
         __builtin_amdgcn_global_load_lds(AB_GPTR(g), AB_LPTR(smem + (wave * 32 + 2 * i) * 512), 16, 0, 0);
     }
-    auto issue_w = [&](const bf16* w, int s) {          // fragment 8 s + wave of the stream -> ring slot s % 3
-        const char* g = reinterpret_cast<const char*>(w) + (size_t)(s * 8 + wave) * 1024 + lane * 16;
-        __builtin_amdgcn_global_load_lds(AB_GPTR(g), AB_LPTR(ring + (s % 3) * AB_SLOT + wave * 1024), 16, 0, 0);
+    // Weight streams (G in phase 1, W' in phase 4): 16 slots of 8 fragments through a ring of three 8 KiB LDS slots, wave w moves
+    // fragment w of every slot.  An LDS-DMA ring keeps 16 KB in flight against ~1 900 cycles of L2 -> LDS latency: 8.6 B / clk of the
+    // 16 B / clk the MFMAs consume (phases 1 and 4 ran at 54 % of the matrix pipe, at 16 as at 256 workgroups: latency, not L2
+    // bandwidth).  Register staging adds a queue of AB_Q slots per wave IN FRONT of the ring: slot s is requested (plain
+    // global_load_dwordx4, 4 VGPRs) AB_Q + 2 steps before it is read, written to the ring two steps before.
+    u32x4 gq[AB_Q];
+    auto load_w = [&](const bf16* w, int s) {           // fragment 8 s + wave of the stream -> queue entry s % AB_Q
+        gq[s % AB_Q] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(w) + (size_t)(s * 8 + wave) * 1024 + lane * 16);
     };
-    issue_w(p.wG, 0);
-    issue_w(p.wG, 1);
+    auto store_w = [&](int s) {                         // queue entry -> ring slot s % 3
+        *reinterpret_cast<u32x4*>(ring + (s % 3) * AB_SLOT + wave * 1024 + lane * 16) = gq[s % AB_Q];
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < AB_Q; ++s0) load_w(p.wG, s0);
     // (A, B) of the image from the block statistics, in gn_apply_kernel's order: a pair's partials in partial order, a group's
     // four pairs in channel order, mean / rstd, A = rstd gamma, B = beta - mean A
-    if (tid < 128) {
-        const float2* const sb = reinterpret_cast<const float2*>(p.stats) + (size_t)n * p.P * 128 + tid;
-        float2 t[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k < p.P) t[k] = sb[k * 128];
+    // the 12 small loads are older than the 16 DMAs and the AB_Q weight loads: complete when at most 16 + AB_Q operations are
+    // outstanding (the operands tie the values to the wait: an ALU use must not be scheduled in front of it)
+    static_assert(AB_Q == 5, "the counted waits below");
+    asm volatile("s_waitcnt vmcnt(21)"
+                 : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(gab[0]), "+v"(gab[1]),
+                   "+v"(gab[2]), "+v"(gab[3])
+                 :: "memory");
+    {
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             if (k < p.P) {
-                s += t[k].x;
-                q += t[k].y;
+                s += __builtin_bit_cast(float, (uint32_t)t[k]);
+                q += __builtin_bit_cast(float, (uint32_t)(t[k] >> 32));
             }
-        for (int k = 8; k < p.P; ++k) {
-            const float2 tk = sb[k * 128];
-            s += tk.x;
-            q += tk.y;
-        }
-        pairs[tid] = make_float2(s, q);
-    }
-    float ga = 0.f, be = 0.f, gv = 0.f, bpv = 0.f;
-    if (tid < 256) {
-        ga = p.gamma[tid];
-        be = p.beta[tid];
-        gv = p.gvec[tid];
-        bpv = p.bprime[tid];
-    }
-    __syncthreads();                    // (drains the DMAs above as well: everything this wave needs next has landed)
-    if (tid < 256) {
-        const int g4 = (tid >> 3) * 4;
-        float s = 0.f, q = 0.f;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            s += pairs[g4 + b].x;
-            q += pairs[g4 + b].y;
-        }
+        // a group = four consecutive pairs = the four lanes of a DPP quad: every lane adds the quad's four sums in lane order
+        // (bitwise the sequential sum gn_apply_kernel forms), no LDS round trip
+        auto quad = [&](float v) {
+            const int vi = __builtin_bit_cast(int, v);
+            const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(vi, 0x00, 0xf, 0xf, true));
+            const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(vi, 0x55, 0xf, 0xf, true));
+            const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(vi, 0xAA, 0xf, 0xf, true));
+            const float v3 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(vi, 0xFF, 0xf, 0xf, true));
+            return ((v0 + v1) + v2) + v3;
+        };
+        const float sg = quad(s), qg = quad(q);
         const float cnt = 256.f * 8.f;
-        const float m = s / cnt;
-        const float rstd = rsqrtf(fmaxf(q / cnt - m * m, 0.f) + p.eps);
-        const float a = rstd * ga;
-        const float b = be - m * a;
-        tabA[tid] = a;
-        tabB[tid] = b;
-        tabG[tid] = a * gv;
-        tabP[tid] = bpv;
+        const float m = sg / cnt;
+        const float rstd = rsqrtf(fmaxf(qg / cnt - m * m, 0.f) + p.eps);
+        float a[2], b[2], ag[2], bp[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            a[e] = rstd * __builtin_bit_cast(float, (uint32_t)(gab[0] >> (32 * e)));
+            b[e] = __builtin_bit_cast(float, (uint32_t)(gab[1] >> (32 * e))) - m * a[e];
+            ag[e] = a[e] * __builtin_bit_cast(float, (uint32_t)(gab[2] >> (32 * e)));
+            bp[e] = __builtin_bit_cast(float, (uint32_t)(gab[3] >> (32 * e)));
+        }
+        auto pack2 = [](float lo, float hi) { return (uint64_t)__builtin_bit_cast(uint32_t, lo) | ((uint64_t)__builtin_bit_cast(uint32_t, hi) << 32); };
+        if (tid < 128) {
+            const unsigned ta = (unsigned)reinterpret_cast<uintptr_t>(AB_LPTR(tabA + 2 * tid));
+            asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:1024\n\tds_write_b64 %0, %3 offset:2048\n\tds_write_b64 %0, %4 offset:3072"
+                         :: "v"(ta), "v"(pack2(a[0], a[1])), "v"(pack2(b[0], b[1])), "v"(pack2(ag[0], ag[1])), "v"(pack2(bp[0], bp[1])) : "memory");
+        }
     }
-    __syncthreads();
+    AB_STAMP(1);
+    ab_barrier();
+    AB_WAIT_VM(0);          // this wave's rows of x have landed (hipcc may order the AB_Q weight loads among the DMAs: no count is safe but 0)
 
     // ---- x^ of this wave's queries: B operand of phase 1 (lane = query, channels 16 ks + 8 h .. + 7), rounded to bf16 exactly
     // where the GroupNorm launch stored it
@@ -207,47 +270,62 @@ __global__ __launch_bounds__(512, 1) void attn_block256_kernel(AttnBlockArgs p) 
         }
     }
 
+    AB_STAMP(2);
     // ---- phase 1: Y^T = G x^^T, cout block by cout block (two ring slots each); Y~ = A (.) (Y + g) replaces x^ in qf as it completes
+    store_w(0);
+    store_w(1);
+    load_w(p.wG, AB_Q);
+    load_w(p.wG, AB_Q + 1);
     bf16x8 yq[16];
+    bf16x8 fr[2][8];        // the fragments of ring slot i are read into registers while the MFMAs of slot i - 1 run
+    auto read_slot = [&](int i, bf16x8 (&f)[8]) {
+        const char* const slot = ring + (i % 3) * AB_SLOT + lane * 16;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) f[jj] = *reinterpret_cast<const bf16x8*>(slot + jj * 1024);
+    };
     {
         f32x16 y;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (i < 15) AB_WAIT_VM(1);      // own fragment of slot i landed (slot i + 1's may still fly)
-            else AB_WAIT_VM(0);
-            ab_barrier();                   // everybody's fragments of slot i landed; everybody is done with slot i - 1
-            if (i + 2 < 16) issue_w(p.wG, i + 2);
-            if ((i & 1) == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) y[r] = 0.f;
+        for (int i = 0; i <= 16; ++i) {
+            // (hipcc treats the asm barrier as a fence for memory operations only and sank the MFMAs of every other step below the
+            // NEXT barrier: 1 MFMA between two barriers, 15 behind the second — the matrix pipe idled through every other barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < 16) {
+                ab_barrier();                   // slot i is in the ring (written one step ago at the latest); everybody has slot i - 1 in registers
+                if (i + 2 < 16) store_w(i + 2);
+                if (i + 2 + AB_Q < 16) load_w(p.wG, i + 2 + AB_Q);
+                read_slot(i, fr[i & 1]);
             }
-            const char* const slot = ring + (i % 3) * AB_SLOT + lane * 16;
+            if (i > 0) {
+                const int j = i - 1;
+                if ((j & 1) == 0) {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(slot + jj * 1024);
-                y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[(i & 1) * 8 + jj], y, 0, 0, 0);
-            }
-            if (i & 1) {
-                const int cb = i >> 1;
+                    for (int r = 0; r < 16; ++r) y[r] = 0.f;
+                }
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int c0 = 32 * cb + 16 * hf + 8 * h;
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(tabA + c0), a1 = *reinterpret_cast<const f32x4*>(tabA + c0 + 4);
-                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(tabG + c0), g1 = *reinterpret_cast<const f32x4*>(tabG + c0 + 4);
-                    bf16x8 v;
+                for (int jj = 0; jj < 8; ++jj) y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j & 1][jj], qf[(j & 1) * 8 + jj], y, 0, 0, 0);
+                AB_INTERLEAVE_STEP();           // the MFMAs (operands in registers since the last step) lead, this step's LDS / memory issue rides between them
+                if (j & 1) {
+                    const int cb = j >> 1;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = (bf16)(y[8 * hf + e] * a0[e] + g0[e]);
-                        v[4 + e] = (bf16)(y[8 * hf + 4 + e] * a1[e] + g1[e]);
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int c0 = 32 * cb + 16 * hf + 8 * h;
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(tabA + c0), a1 = *reinterpret_cast<const f32x4*>(tabA + c0 + 4);
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(tabG + c0), g1 = *reinterpret_cast<const f32x4*>(tabG + c0 + 4);
+                        bf16x8 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = (bf16)(y[8 * hf + e] * a0[e] + g0[e]);
+                            v[4 + e] = (bf16)(y[8 * hf + 4 + e] * a1[e] + g1[e]);
+                        }
+                        yq[2 * cb + hf] = v;
                     }
-                    yq[2 * cb + hf] = v;
                 }
             }
         }
     }
+    AB_STAMP(3);
     ab_barrier();           // every wave's rows of x have landed (each waited for its own before phase 1) and the ring is free
-    issue_w(p.wP, 0);
-    issue_w(p.wP, 1);
 
     // ---- phase 2: S^T[key][query] = x . Y~^T, 8 tiles of 32 keys; logits arrive in the log2 domain (scale log2 e folded into G)
     f32x16 s[8];
@@ -267,6 +345,7 @@ __global__ __launch_bounds__(512, 1) void attn_block256_kernel(AttnBlockArgs p) 
             s[t] = a16;
         }
     }
+    AB_STAMP(4);
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -285,6 +364,7 @@ __global__ __launch_bounds__(512, 1) void attn_block256_kernel(AttnBlockArgs p) 
         }
     l += __shfl_xor(l, 32, 64);
 
+    AB_STAMP(5);
     // ---- phase 3: O^T[c][query] = x^T . P^T (V = raw x: the affine is applied to the 256 sums instead of the 65536 values)
     f32x16 o[8];
 #pragma unroll
@@ -314,6 +394,9 @@ __global__ __launch_bounds__(512, 1) void attn_block256_kernel(AttnBlockArgs p) 
             }
         }
     }
+    AB_STAMP(6);
+#pragma unroll
+    for (int s0 = 0; s0 < AB_Q; ++s0) load_w(p.wP, s0);        // W' slots 0 .. AB_Q - 1 fly under the Z affine
     // Z = A (.) O / l + B -> B operand of phase 4: k-step j takes registers 8 (j & 1) .. + 7 of o[j >> 1] as they stand
     // (channels 16 j + 8 (i >> 2) + 4 h + (i & 3)); W' is packed in the same channel order
     bf16x8 of[16];
@@ -329,6 +412,11 @@ __global__ __launch_bounds__(512, 1) void attn_block256_kernel(AttnBlockArgs p) 
                 for (int e = 0; e < 4; ++e) of[j][4 * g + e] = (bf16)((o[j >> 1][8 * (j & 1) + 4 * g + e] * inv) * a4[e] + b4[e]);
             }
     }
+    AB_STAMP(7);
+    store_w(0);
+    store_w(1);
+    load_w(p.wP, AB_Q);
+    load_w(p.wP, AB_Q + 1);
     ab_barrier();           // every wave is done with x as K and V: a wave's own rows become its output tile
 
     // ---- phase 4: y^T[cout][query] = W' Z^T; out = y + b' + x in place in the wave's rows of the image
@@ -337,37 +425,47 @@ __global__ __launch_bounds__(512, 1) void attn_block256_kernel(AttnBlockArgs p) 
         char* const orow = smem + r * 512 + 8 * h;
         f32x16 y;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if (i < 15) AB_WAIT_VM(1);
-            else AB_WAIT_VM(0);
-            ab_barrier();
-            if (i + 2 < 16) issue_w(p.wP, i + 2);
-            if ((i & 1) == 0) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) y[q] = 0.f;
+        for (int i = 0; i <= 16; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (i < 16) {
+                ab_barrier();
+                if (i + 2 < 16) store_w(i + 2);
+                if (i + 2 + AB_Q < 16) load_w(p.wP, i + 2 + AB_Q);
+                read_slot(i, fr[i & 1]);
             }
-            const char* const slot = ring + (i % 3) * AB_SLOT + lane * 16;
+            if (i > 0) {
+                const int j = i - 1, cb = j >> 1;
+                if ((j & 1) == 0) {
 #pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(slot + jj * 1024);
-                y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, of[(i & 1) * 8 + jj], y, 0, 0, 0);
-            }
-            if (i & 1) {
-                const int cb = i >> 1;
+                    for (int q = 0; q < 16; ++q) y[q] = 0.f;
+                }
+                // the residual pieces and the bias of this cout block are requested in front of the MFMAs that finish it
+                bf16x4 rv[4];
+                f32x4 bv[4];
+                if (j & 1) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    char* const a = orow + (((cb * 4 + g) ^ sw) << 4);
-                    const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a);
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(tabP + cb * 32 + g * 8 + 4 * h);
-                    bf16x4 ov;
+                    for (int g = 0; g < 4; ++g) {
+                        rv[g] = *reinterpret_cast<const bf16x4*>(orow + (((cb * 4 + g) ^ sw) << 4));
+                        bv[g] = *reinterpret_cast<const f32x4*>(tabP + cb * 32 + g * 8 + 4 * h);
+                    }
+                }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = (bf16)(y[4 * g + e] + (bv[e] + (float)rv[e]));
-                    *reinterpret_cast<bf16x4*>(a) = ov;
+                for (int jj = 0; jj < 8; ++jj) y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[j & 1][jj], of[(j & 1) * 8 + jj], y, 0, 0, 0);
+                AB_INTERLEAVE_STEP();
+                if (j & 1) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        bf16x4 ov;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] = (bf16)(y[4 * g + e] + (bv[g][e] + (float)rv[g][e]));
+                        *reinterpret_cast<bf16x4*>(orow + (((cb * 4 + g) ^ sw) << 4)) = ov;
+                    }
                 }
             }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the rows a wave drains are the rows it wrote
+    AB_STAMP(8);
     // ---- whole-row stores of the wave's 32 rows (+ their block statistics)
     bf16* const obase = p.out + (size_t)n * 65536;
 #pragma unroll
@@ -413,6 +511,9 @@ __global__ __launch_bounds__(512, 1) void attn_block256_kernel(AttnBlockArgs p) 
             *reinterpret_cast<f32x4*>(sd + 4) = f32x4{tot[4], tot[5], tot[6], tot[7]};
         }
     }
+    AB_STAMP(9);
+    AB_RSTAMP(11);
+    AB_STAMP_DUMP();
 }
 
 }  // namespace
@@ -437,8 +538,9 @@ extern "C" int dxmi_attn_block_pack(const float* wq, const float* bq, const floa
 extern "C" int dxmi_attn_block_fwd(const void* x, const float* stats, int32_t P, const float* gamma, const float* beta, float eps,
                                    const void* packed, void* out, float* out_stats, int32_t N, int32_t T, int32_t C, void* stream) {
     DXMI_CHECK_ARG(x && stats && gamma && beta && packed && out, "dxmi_attn_block_fwd: null pointer");
-    DXMI_CHECK_ARG(N > 0 && P > 0 && dxmi_attn_block_supported(T, C, 1, 32),
-                   "dxmi_attn_block_fwd: only the single-head 256-token x 256-channel block (N=%d T=%d C=%d P=%d)", N, T, C, P);
+    DXMI_CHECK_ARG(N > 0 && P > 0 && P <= 8 && dxmi_attn_block_supported(T, C, 1, 32),
+                   "dxmi_attn_block_fwd: only the single-head 256-token x 256-channel block, at most 8 statistics partials per image "
+                   "(dxmi_gn_stats_fold folds more) (N=%d T=%d C=%d P=%d)", N, T, C, P);
     AttnBlockArgs a;
     const char* pk = reinterpret_cast<const char*>(packed);
     a.x = (const bf16*)x; a.stats = stats; a.gamma = gamma; a.beta = beta;
@@ -447,7 +549,7 @@ extern "C" int dxmi_attn_block_fwd(const void* x, const float* stats, int32_t P,
     a.out = (bf16*)out; a.out_stats = out_stats; a.N = N; a.P = P; a.eps = eps;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_block256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS);
         attr_set = true;
     }
     hipLaunchKernelGGL(attn_block256_kernel, dim3(N), dim3(512), (size_t)AB_LDS, (hipStream_t)stream, a);

@@ -49,9 +49,16 @@ class FlatGradSync:
     (train_cifar10.py:298-309 gets the same from DDP's 25 MB buckets).  Buckets are always launched in index order, so every
     rank issues the same sequence of collectives.  `sync()` (== `__call__`) after the backward: packs whatever the hooks did not
     see (a parameter without a local gradient contributes zeros to the buffer and keeps `.grad = None` unless another rank
-    produced one), launches the remaining buckets, waits, and scatters the means back
-    into the `.grad` tensors with one multi-tensor copy.  Two backward passes without a `sync()` in between fall back to
-    one blocking all-reduce of the accumulated gradients."""
+    produced one), launches the remaining buckets and waits.  With the fp32 wire format `sync()` then RE-BINDS every `.grad` to
+    its slice of the flat buffer instead of copying the means back (round 4: a 143 MB scatter per U-Net exchange); the slices
+    stay untouched until the next backward packs into them, by which time the trainers have dropped the gradients
+    (`zero_grad(set_to_none=True)` / `p.grad = None`).  During a backward `.grad` is never an alias of the buffer a collective may
+    be working on, so the two-backward fallback keeps its meaning.  With a narrower wire format the means are copied back by one
+    multi-tensor copy.  Which parameters received a gradient on ANY rank
+    travels as one flag per parameter in the TAIL of the last bucket: no collective of its own (round 4 issued a second small
+    all-reduce per sync: 12 extra collectives per CIFAR train step, ~30 us of launch latency each on a path — the T + 1
+    value-net exchanges — that has nothing to hide behind).  Collectives per sync = number of buckets, exactly.  Two backward
+    passes without a `sync()` in between fall back to one blocking all-reduce of the accumulated gradients."""
 
     def __init__(self, module, wire_dtype=torch.float32, force=False, bucket_mb=32, overlap=True):
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -75,9 +82,15 @@ class FlatGradSync:
             if pos - start >= limit:
                 self.buckets.append((start, pos, count))
                 start, count = pos, 0
-        if count:
+        if count or not self.buckets:
             self.buckets.append((start, pos, count))
         self.numel = pos
+        # one "some rank produced a gradient" flag per parameter behind the gradients, inside the LAST bucket: that bucket is
+        # launched after every other one (strict index order), i.e. when every hook that will fire has fired
+        self.nflags = len(self.params)
+        b0, b1, bc = self.buckets[-1]
+        self.buckets[-1] = (b0, b1 + self.nflags, bc)
+        self.alias_grads = wire_dtype == torch.float32
         self._reset()
         self.hooks = []
         self.overlap = overlap
@@ -99,9 +112,18 @@ class FlatGradSync:
 
     def _buffers(self, device):
         if self.flat is None or self.flat.device != device:
-            self.flat = torch.empty(self.numel, dtype=self.wire_dtype, device=device)
+            self.flat = torch.empty(self.numel + self.nflags, dtype=self.wire_dtype, device=device)
             self.views = [self.flat[self.offset[i]:self.offset[i] + p.numel()].view_as(p) for i, p in enumerate(self.params)]
+            self.flags = self.flat[self.numel:]
+            self.flags.fill_(1.0)       # refilled at the end of every sync(): in place before the next backward's last bucket
         return self.flat, self.views
+
+    def _pack(self, idx):
+        """Gradients of parameters `idx` -> their slices of the flat buffer (a gradient that already IS its slice — kept from the
+        last sync() and accumulated into in place — is not copied)."""
+        todo = [i for i in idx if self.params[i].grad.data_ptr() != self.views[i].data_ptr()]
+        if todo:
+            torch._foreach_copy_([self.views[i] for i in todo], [self.params[i].grad for i in todo])
 
     def _on_grad(self, p):
         if not self._active():
@@ -110,8 +132,8 @@ class FlatGradSync:
         if self.ready[i]:             # second backward before sync(): the launched buckets hold stale sums
             self.dirty = True
             return
-        _, views = self._buffers(p.grad.device)
-        views[i].copy_(p.grad)
+        self._buffers(p.grad.device)
+        self._pack([i])
         self._mark(i)
 
     def _mark(self, i):
@@ -141,8 +163,10 @@ class FlatGradSync:
         if missing:
             # fixed element count on every rank: a parameter without a local gradient contributes zeros to the FLAT buffer
             # only; its .grad stays None unless some other rank produced one (torch DDP / torch.optim semantics: an unused
-            # parameter is skipped by the optimiser, not stepped with a zero gradient)
+            # parameter is skipped by the optimiser, not stepped with a zero gradient).  Its flag goes out as zero: the last
+            # bucket (which carries the flags) cannot have been launched yet — its launch waits for every parameter.
             torch._foreach_zero_([views[i] for i in missing])
+            self.flags[torch.tensor(missing, device=dev)] = 0.0
         world = dist.get_world_size()
         if self.dirty:
             # every rank must have issued every bucket collective exactly once before the blocking one (a rank whose hooks
@@ -154,9 +178,12 @@ class FlatGradSync:
                 h.wait()
             have = [i for i in range(len(self.params)) if self.params[i].grad is not None]
             if have:                    # torch's foreach ops reject empty lists (a rank may hold no gradient at all)
-                torch._foreach_copy_([views[i] for i in have], [self.params[i].grad for i in have])
+                self._pack(have)
             if missing:                 # the discarded collectives wrote into these slices
                 torch._foreach_zero_([views[i] for i in missing])
+            self.flags.fill_(1.0)
+            if missing:
+                self.flags[torch.tensor(missing, device=dev)] = 0.0
             if dist.get_backend() == "nccl":
                 dist.all_reduce(flat, op=dist.ReduceOp.AVG)
             else:
@@ -167,27 +194,27 @@ class FlatGradSync:
             if late:                    # gradients the hooks did not see (no hooks, constructed after backward, unused parameters)
                 have = [i for i in late if self.params[i].grad is not None]
                 if have:
-                    torch._foreach_copy_([views[i] for i in have], [self.params[i].grad for i in have])
+                    self._pack(have)
                 for i in late:
                     self._mark(i)
             for h in self.handles:
                 h.wait()
             if dist.get_backend() != "nccl":
                 flat.div_(world)
-        # which parameters received a gradient on ANY rank: one small collective, issued by every rank on every sync (same
-        # sequence everywhere); only a rank with locally missing gradients reads it back (one host sync on that rare path)
-        used = torch.ones(len(self.params), dtype=torch.float32, device=dev)
         if missing:
-            used[missing] = 0.0
-        dist.all_reduce(used, op=dist.ReduceOp.SUM)
-        if missing:
-            flags = used[missing].tolist()
-            for i, f in zip(missing, flags):
+            # the flags came back with the last bucket: only a rank with locally missing gradients reads them (one host sync on
+            # that rare path)
+            got = self.flags[torch.tensor(missing, device=dev)].float().tolist()
+            for i, f in zip(missing, got):
                 if f > 0:
-                    self.params[i].grad = torch.empty_like(self.params[i])
+                    self.params[i].grad = views[i] if self.alias_grads else torch.empty_like(self.params[i])
         have = [i for i in range(len(self.params)) if self.params[i].grad is not None]
-        if have:
+        if self.alias_grads:
+            for i in have:              # the means stay where the collective left them
+                self.params[i].grad = views[i]
+        elif have:
             torch._foreach_copy_([self.params[i].grad for i in have], [views[i] for i in have])   # one multi-tensor scatter back
+        self.flags.fill_(1.0)           # for the next backward (the next sync zeroes what is missing then)
         self._reset()
 
     __call__ = sync

@@ -724,6 +724,8 @@ def attn_block(x, stats, gamma, beta, packed, eps=1e-6, out=None, want_stats=Fal
     T = x.numel() // (N * C)
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and tuple(stats.buf.shape) == (N, stats.P, C // 2, 2)
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == C and beta.numel() == C
+    if stats.P > MAX_APPLY_PARTIALS:
+        stats = fold_stats(stats)
     if out is None:
         out = torch.empty_like(x)
     st = BlockStats(torch.empty((N, 8, C // 2, 2), dtype=torch.float32, device=x.device), 8) if want_stats else None

@@ -284,7 +284,8 @@ int dxmi_attention_proj_fwd(const void* qkv, const void* wproj_packed, const flo
 /* The whole AttnBlock in ONE launch (round 5; reference models/DxMI/unet_small.py:167-191: h_ = norm(x); q, k, v = 1x1 convs of
  * h_; w_ = softmax(q^T k * C^-0.5); h_ = proj_out(v w_^T); return x + h_), for the single-head 256-token x 256-channel blocks of
  * the CIFAR-10 net (dxmi_attn_block_supported), inference path only.  x: NHWC bf16 [N,256,256]; stats: its GroupNorm block
- * statistics fp32 [N][P][128][2] (dxmi_conv_desc.gn_stats / dxmi_gn_block_stats layout); gamma / beta: the block's norm.  The
+ * statistics fp32 [N][P][128][2], P <= 8 (dxmi_conv_desc.gn_stats / dxmi_gn_block_stats layout; dxmi_gn_stats_fold folds more);
+ * gamma / beta: the block's norm.  The
  * normalised input, q, k, v and the attention output never exist in memory: with G = scale Wk^T Wq and W' = Wproj Wv folded once
  * per weight version (dxmi_attn_block_pack: fp32 [256][256] OI weights and [256] biases -> dxmi_attn_block_packed_bytes() bytes)
  * the raw x tile in LDS is K, V and the residual at once (terms constant along the key axis drop out of the softmax; rows of the

@@ -266,6 +266,8 @@ def _sequence_worker(rank, world, port, q):
         (value(x * (step + 1)).pow(2).mean()).backward()
         local["value"].append([p.grad.clone().numpy() for p in value.parameters()])
         sync_v()
+        # fp32 wire: the means are not copied back, .grad IS the parameter's slice of the flat buffer
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync_v.params, sync_v.views))
         synced["value"].append([p.grad.clone().numpy() for p in value.parameters()])
     # update_sampler: one backward through value net INTO the U-Net; rank 2 does not touch the attention branch (missing gradients)
     h = unet["mid"](torch.tanh(unet["down"](x)))
@@ -313,12 +315,17 @@ def test_train_step_collective_sequence_world4_gloo():
         assert [(n, op) for n, op, _ in logs[r]] == [(n, op) for n, op, _ in logs[0]], f"rank {r} issued a different collective sequence"
     nb = res[0][4]
     assert nb >= 3 and all(r[4] == nb for r in res)
-    # sequence: (T+1) x [value flat + used-flags]  +  nb U-Net buckets + flags  +  1 bucket + flags of the untouched module
+    # sequence (round 5: the "used on any rank" flags ride in the tail of a module's LAST bucket, no collective of their own):
+    #   (T+1) x [value net: one bucket = gradients + 4 flags]  +  nb U-Net buckets  +  1 bucket of the untouched module
+    # collectives per train step = (T + 1) + n_buckets, exactly (+ 1 here for the module nobody touched)
     T = 3
     nv = sum(p.numel() for p in torch.nn.Sequential(torch.nn.Linear(12, 24), torch.nn.LeakyReLU(0.2), torch.nn.Linear(24, 1)).parameters())
     sizes = [n for n, _, _ in logs[0]]
-    assert sizes[:2 * (T + 1)] == [nv, 4] * (T + 1)
-    assert len(sizes) == 2 * (T + 1) + nb + 1 + 2
+    assert sizes[:T + 1] == [nv + 4] * (T + 1)
+    assert len(sizes) == (T + 1) + nb + 1
+    nu = 12 * 32 + 32 + 2 * (32 * 32 + 32) + 32 * 12 + 12 + T
+    assert sum(sizes[T + 1:T + 1 + nb]) == nu + 9          # the U-Net's buckets: every gradient once + 9 flags in the last one
+    assert sizes[-1] == 4 * 4 + 4 + 2
     assert res[0][5] >= 1 and res[2][5] < nb           # buckets launched DURING backward; rank 2 holds one back until sync()
     for step in range(T + 1):
         for i in range(4):

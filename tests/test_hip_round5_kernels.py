@@ -91,7 +91,7 @@ def test_attn_block_one_launch(ops, N, wscale):
 
 def test_attn_block_key_bias_is_irrelevant_and_partials_fold(ops):
     """The k bias drops out of the softmax (constant along the key axis): the packed block ignores it by construction; check the
-    reference agrees.  Statistics with more than 8 partials per image take the serial tail of the prologue."""
+    reference agrees.  Statistics with more than 8 partials per image are folded first (the C-ABI takes at most 8)."""
     g = torch.Generator().manual_seed(77)
     N, T, C = 2, 256, 256
     x = torch.randn(N, T, C, generator=g).to(torch.bfloat16).to(DEV)
