@@ -34,6 +34,10 @@ _Loader.add_implicit_resolver(
 def _mapping_no_duplicates(loader, node, deep=False):
     seen = set()
     for key_node, _ in node.value:
+        # as OmegaConf's loader: only plain keys are compared (a merge key `<<: *anchor` has tag:yaml.org,2002:merge, for which
+        # SafeLoader has no constructor — construct_mapping below flattens it)
+        if key_node.tag == "tag:yaml.org,2002:merge" or not isinstance(key_node, yaml.ScalarNode):
+            continue
         key = loader.construct_object(key_node, deep=deep)
         if key in seen:
             raise yaml.constructor.ConstructorError(

@@ -30,17 +30,51 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _tree_fingerprint(module):
+    """Cheap identity of a module tree: changes when a submodule is added, removed or replaced anywhere below `module`."""
+    fp, stack = [], [module]
+    while stack:
+        m = stack.pop()
+        subs = m._modules
+        fp.append(id(subs))
+        fp.append(len(subs))
+        for c in subs.values():
+            if c is not None:
+                fp.append(id(c))
+                stack.append(c)
+    return tuple(fp)
+
+
 def fast_parameters(module):
     """module.parameters() without nn.Module's name-building / de-duplication machinery (a U-Net's `tuple(... for p in
-    net.parameters())` was ~1 ms of Python per forward): the submodules are listed once (the module tree is fixed
-    after construction), their `_parameters` dictionaries are read live, in the order `parameters()` yields.  No parameter of
-    these nets is shared between two modules."""
-    mods = module.__dict__.get("_dxmi_param_modules")
-    if mods is None:
+    net.parameters())` was ~1 ms of Python per forward): the submodules are listed once, their `_parameters` dictionaries are read
+    live, in the order `parameters()` yields.  The cached list is dropped when the module tree changes (a submodule added or
+    replaced: the fingerprint walk is ~30 us for the U-Net, checked every 64th call and whenever the cheap root-level check
+    fails), and on first use the result is checked against `module.parameters()` (a parameter shared between two modules would
+    be yielded twice here: de-duplicated by identity)."""
+    cache = module.__dict__.get("_dxmi_param_modules")
+    if cache is not None:
+        cache[2] += 1
+        if cache[2] & 63 == 0 and _tree_fingerprint(module) != cache[1]:
+            cache = None
+    if cache is None:
         # every submodule, also those without parameters today: the samplers register `log_betas` on a net after construction
         mods = list(module.modules())
-        module.__dict__["_dxmi_param_modules"] = mods
-    for m in mods:
+        cache = [mods, _tree_fingerprint(module), 0, False]
+        module.__dict__["_dxmi_param_modules"] = cache
+        seen = set()
+        flat = [prm for m in mods for prm in m._parameters.values() if prm is not None and not (id(prm) in seen or seen.add(id(prm)))]
+        cache[3] = len(flat) != sum(1 for m in mods for prm in m._parameters.values() if prm is not None)      # shared parameters
+        assert len(flat) == sum(1 for _ in module.parameters()), "fast_parameters: module tree walk disagrees with module.parameters()"
+    if cache[3]:
+        seen = set()
+        for m in cache[0]:
+            for prm in m._parameters.values():
+                if prm is not None and id(prm) not in seen:
+                    seen.add(id(prm))
+                    yield prm
+        return
+    for m in cache[0]:
         for prm in m._parameters.values():
             if prm is not None:
                 yield prm
@@ -69,12 +103,33 @@ def set_tuning(name, value):
     return old
 
 
+_TUNING_SAVED = []
+
+
 def tune_for_throughput(on=True):
     """Training entry points: route convs whose 256-pixel-tile grid leaves most CUs idle (small per-GPU batches) to kernels with
     smaller tiles.  Off (the library default), every layer shape runs one kernel whatever the batch size, which keeps an image's
-    result bitwise independent of the batch it rides in (generation scripts, parity tests)."""
-    set_tuning("conv_ws_min_tiles", 96 if on else 0)
-    set_tuning("conv_sm_mask", 13 if on else 9)
+    result bitwise independent of the batch it rides in (generation scripts, parity tests).  `tune_for_throughput(False)`
+    RESTORES the values that were in effect before the matching `tune_for_throughput(True)` (environment overrides such as
+    DXMI_CONV_SM / DXMI_CONV_WS_MIN_TILES survive a train leg); `with ops.throughput_tuning():` does both."""
+    if on:
+        _TUNING_SAVED.append((set_tuning("conv_ws_min_tiles", 96), set_tuning("conv_sm_mask", 13)))
+    elif _TUNING_SAVED:
+        ws, sm = _TUNING_SAVED.pop()
+        set_tuning("conv_ws_min_tiles", ws)
+        set_tuning("conv_sm_mask", sm)
+
+
+class throughput_tuning:
+    """`with ops.throughput_tuning():` — tune_for_throughput(True) inside, the previous knob values restored on exit."""
+
+    def __enter__(self):
+        tune_for_throughput(True)
+        return self
+
+    def __exit__(self, *exc):
+        tune_for_throughput(False)
+        return False
 
 
 def get_tuning(name):
@@ -745,12 +800,15 @@ def timestep_embedding(t, dim, order=0, max_period=10000.0, out=None):
     return out
 
 
-def linear(x, pw, bias=None, pre_act=ACT_NONE, post_act=ACT_NONE, out=None):
-    """x fp32 [P, K] -> fp32 [P, M]; pw = pack_conv_weight(W[M, K])."""
+def linear(x, pw, bias=None, pre_act=ACT_NONE, post_act=ACT_NONE, out=None, splitk=False):
+    """x fp32 [P, K] -> fp32 [P, M]; pw = pack_conv_weight(W[M, K]).
+    splitk: allow the split-K form for skinny products with a long K.  Its slice count depends on the number of rows, so the
+    fp32 summation order of a row would change with the batch it rides in: only the training backward (linear_bwd) asks for
+    it; forward calls keep one reduction order per shape (bitwise batch independence of the generation path)."""
     _need_cuda(x, bias, out)
     assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == pw.Cin
     P, K = x.shape
-    S = load().dxmi_linear_splitk_slices(P, K, pw.Cout) if post_act == ACT_NONE else 1
+    S = load().dxmi_linear_splitk_slices(P, K, pw.Cout) if (splitk and post_act == ACT_NONE) else 1
     if S > 1:      # skinny product with a long K: slices of K in parallel, summed in slice order (deterministic)
         part = torch.empty((S, P, pw.Cout), dtype=torch.float32, device=x.device)
         check(load().dxmi_linear_splitk(_ptr(x), _ptr(pw.buf), _ptr(part), P, K, pw.Cout, pre_act, _stream()), "dxmi_linear_splitk")
@@ -784,7 +842,7 @@ def linear_bwd(x, dy, pw_t, need_dx=True):
     M = dy.shape[1]
     assert dy.shape[0] == P and x.dtype == torch.float32 and dy.dtype == torch.float32
     dy = dy.contiguous()
-    dx = linear(dy, pw_t) if need_dx else None
+    dx = linear(dy, pw_t, splitk=True) if need_dx else None
     rows = 64
     while rows < P:
         rows *= 2

@@ -28,11 +28,32 @@ from .replay import TransitionRing, buffer_gather, buffer_rows
 
 def _set_mode(module, training):
     """module.train() / module.eval() when the mode actually changes: the recursive flag walk over the module tree ran 24 times per
-    train step (the reference toggles the value net around every TD target), ~2 ms of host time."""
+    train step (the reference toggles the value net around every TD target), ~2 ms of host time.  "Changes" is judged against the
+    mode THIS function applied last (kept on the module) and the root flag: whoever toggled a child alone, or the root behind the
+    trainer's back, gets the full recursive walk again — the reference re-applies the mode unconditionally
+    (models/DxMI/trainer.py:261-322)."""
     if getattr(module, "training", None) is None:          # OpenAIDiffusion: a plain object forwarding train() / eval() to its net
         (module.train if training else module.eval)()
-    elif module.training != training:
+        return
+    last = module.__dict__.get("_dxmi_mode_applied")
+    if last is None or last[0] != training or module.training != training or _children_disagree(module, training, last):
         module.train(training)
+        module.__dict__["_dxmi_mode_applied"] = (training, _mode_probe(module))
+
+
+def _mode_probe(module):
+    """The (few) direct children whose flags stand for the subtree: toggling any of them alone is noticed by _set_mode."""
+    return [m for m in module._modules.values() if m is not None]
+
+
+def _children_disagree(module, training, last):
+    probe = last[1]
+    if len(probe) != len(module._modules):
+        return True
+    for m in probe:
+        if m.training != training:
+            return True
+    return False
 
 
 def reset_buffer(device, ring=None):
