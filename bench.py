@@ -457,7 +457,7 @@ def main():
     # ---- roofline leg (rank 0, outside the timed region): HIP events bracket every kernel launch of two more steps.
     # An event pair costs ~2 us of stream time and a step has ~2500 launches, so bracketing inside the timed region
     # would take ~8 % off the number being measured; the bracketed launches are the same kernels on the same shapes.
-    gen_summ = None
+    gen_summ, gen_clock = None, None
     if rank == 0 and not args.no_events:
         prof = ops.OpProfiler()
         ops.PROFILER = prof
@@ -466,6 +466,7 @@ def main():
         torch.cuda.synchronize()
         ops.PROFILER = None
         gen_summ = {k: {kk: vv / 2 for kk, vv in v.items()} for k, v in prof.summary().items()}     # per step
+        gen_clock = ops.conv_ws_clock_ghz()        # shader clock during the last conv_ws_kernel launch of the generation step
 
     # ---- second leg: DxMI train step (sample + value/energy update + policy update), same batch/GPU
     train_sps, train_summ, t_train_step = None, None, None
@@ -541,6 +542,11 @@ def main():
             "algorithmic_gbps": s["bytes"] / (s["ms"] * 1e-3) / 1e9,
             "share_of_step_time": s["ms"] * 1e-3 / step_s,
             "events": "two extra steps after the timed region, every launch bracketed on its stream",
+            # in-kernel shader clock (d s_memtime / d s_memrealtime of workgroup 0 over one conv_ws_kernel launch): the dense MFMA peak
+            # is quoted at the 2.4 GHz boost clock (256 CUs x 4096 FLOP/clk), the chip holds less under this kernel's load, and the
+            # boxes of the pool differ; frac_at_clock = achieved / (256 x 4096 x clock)
+            "clock_ghz": None if gen_clock is None else round(gen_clock, 3),
+            "frac_at_clock": None if not gen_clock else tflops / (256 * 4096 * gen_clock * 1e9 / 1e12),
         }
         line["roofline_classes"] = class_rooflines(gen_summ, step_s)
         # per conv kernel: time, rate, algorithmic bytes per launch and the HBM-side bytes per launch of the committed PMC passes

@@ -574,10 +574,6 @@ extern "C" int dxmi_conv2d_gn_fuse_supported(const dxmi_conv_desc* d) {
     const int rc = conv2d_impl(&q, nullptr, &id);
     if (rc != DXMI_OK) return 0;
     if (id == 450432) return 1;                        // conv_sm_kernel<2, 8, 32>: eight whole 4x4 images x 32 couts per tile
-    if (id == 400016 && (d->gn_flags & 2) && d->OH == 16 && d->OW == 16 && d->Cout % 128 == 0 && d->act == DXMI_ACT_NONE && !d->mask_src) {
-        static const int gn16 = getenv("DXMI_CONV_WS_GN16") ? atoi(getenv("DXMI_CONV_WS_GN16")) : 1;      // 0: separate GroupNorm launch (A/B timing)
-        return gn16 ? 1 : 0;                           // conv_ws_gn_kernel: a whole 16x16 image per tile, instead of the raw output
-    }
     return id == 400008 && (d->gn_flags & 2) ? 1 : 0;  // conv_ws8_kernel: a whole 8x8 image per wave, instead of the raw output
 }
 

@@ -798,8 +798,6 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
             if (rc <= 0) return rc;
             rc = conv_ws8_try_launch(a, st, kernel_id);
             if (rc <= 0) return rc;
-            rc = conv_ws_try_launch(a, st, kernel_id);       // conv_ws_gn_kernel (16x16 maps)
-            if (rc <= 0) return rc;
             DXMI_CHECK_ARG(false, "dxmi_conv2d_fwd: the kernel for this shape cannot fuse the GroupNorm of its output "
                                   "(dxmi_conv2d_gn_fuse_supported returns 0 for it)");
         }

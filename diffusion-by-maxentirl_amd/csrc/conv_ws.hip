@@ -71,6 +71,16 @@ extern "C" int dxmi_debug_read_ws_stamps(void* dst, int bytes) {
 #define WS_DBG(bit) 0
 #endif
 
+// Shader clock of the last launch (round 5): workgroup 0 leaves (s_memtime, s_memrealtime) of its first and last instruction
+// here; d s_memtime / d s_memrealtime x 100 MHz is the clock the chip held DURING the kernel (it lowers the clock under this
+// kernel's load: 1.86-2.13 GHz).  bench.py reports it beside the roofline fraction, so that a slow box (or a throttling one) can be
+// told from a slow kernel.  Two scalar reads and one 32-byte store per launch.
+__device__ unsigned long long g_ws_clock[4];
+extern "C" int dxmi_conv_ws_last_clock(unsigned long long* host_out4) {
+    return hipMemcpyFromSymbol(host_out4, HIP_SYMBOL(g_ws_clock), 4 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost) == hipSuccess ? DXMI_OK
+                                                                                                                                          : DXMI_ELAUNCH;
+}
+
 namespace {
 
 constexpr int WS_A_SLOT = 8192;              // one (chunk, tap): 2 k-steps x 4 cout blocks x 1 KiB fragments
@@ -78,7 +88,6 @@ constexpr int WS_RING = 6;                   // ring slots (steps): five steps o
 constexpr int WS_A_RING = WS_RING * WS_A_SLOT;
 constexpr int WS_RO = 256 * 256;             // output / residual tile: 256 px x 128 co bf16
 constexpr int WS_TB = 1024;                  // bias[128] | temb[128] fp32
-constexpr int WS_GN = 1024 + 256;            // conv_ws_gn_kernel: gamma[128] | beta[128] fp32 + the statistics exchange
 constexpr int WS_HALO_BLOCKS = 22;           // 1-KiB blocks of a halo image (34x10 or 18x18 pixels x 64 B)
 constexpr int WS_HALO = WS_HALO_BLOCKS * 1024;
 
@@ -140,19 +149,16 @@ struct WsTile {
 // The weight ring keeps the 32x32x16 fragment packing of pack_conv_weight (shared with conv_pipe): the 16x16x32 A fragment
 // (16 couts x 32 channels) of cout block cb16 is lanes (cb16 & 1) * 16 .. + 15 of both lane halves of the two k-step
 // fragments of cout block cb16 >> 1 — a per-lane base plus a compile-time offset as well, bank-conflict free as it lies.
-// GN (TW = 16, 16x16 maps only: a tile is a whole image x 128 couts = 16 whole groups of 8 channels): GroupNorm(+SiLU) of the output
-// written INSTEAD of the raw output (dxmi_conv_desc.gn_out, gn_flags bit 1) — conv_ws_gn_kernel below.
-template <int TW, bool GN>
+// (Round 4 carried a second instantiation that wrote GroupNorm(+SiLU) of a 16x16 map's output from this epilogue: parity-green, 4 %
+// slower end to end — two more passes over 128 accumulators on the MFMA waves' critical path — and removed in round 5: DESIGN 5.4 / 5.5.)
+template <int TW>
 __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
-    static_assert(!GN || TW == 16, "the fused GroupNorm needs whole images per tile");
     constexpr int TH = 256 / TW, HP = TW == 32 ? 34 : 18, HH = TH + 2, TWl = TW == 32 ? 5 : 4;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     char* const halo0 = smem;
     char* const aring = smem + 2 * WS_HALO;
     char* const ro = aring + WS_A_RING;
     float* const tb = reinterpret_cast<float*>(ro + WS_RO);
-    float* const gb = tb + WS_TB / 4;            // GN: gamma[128] | beta[128] of the tile's couts
-    float* const sx = gb + 256;                  // GN: (sum, sum of squares) of every (cout half, pixel half, group) — 32 x 2 floats
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -174,6 +180,10 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
     int q = blockIdx.x;
     if (q >= ntiles) return;
     const int qstride = gridDim.x;
+    if (blockIdx.x == 0 && tid == 0) {
+        g_ws_clock[0] = __builtin_amdgcn_s_memtime();
+        g_ws_clock[1] = __builtin_amdgcn_s_memrealtime();
+    }
     WS_CLOCKSTAMP(172, wave == 0);
 
     if (wave < 4) {
@@ -331,84 +341,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
                 using T_ = std::true_type;
                 using F_ = std::false_type;
                 const bool is_mask = has_res && p.res_is_mask;
-                if constexpr (GN) {
-                    // GroupNorm(+SiLU) of the tile from the epilogue (16x16 map: the tile is the whole image, a 16-cout block of a
-                    // wave is two whole groups of 8 channels, lanes kg = 2j, 2j + 1).  Pass 1: the values as a separate launch would
-                    // read them (rounded to bf16) stay in the accumulators; (sum, sum of squares) of this wave's 128 pixels per group
-                    // -> LDS.  E1b.  Pass 2: own + partner pixel half (half 0 first: a fixed order), one (scale, offset) per cout,
-                    // normalised tile -> LDS for the drain.  One-pass variance as the streaming kernel (gn_apply_kernel) forms it.
-                    auto pass1 = [&](auto RES) {
-                        constexpr bool kRes = decltype(RES)::value;
-#pragma unroll
-                        for (int cb = 0; cb < 4; ++cb) {
-                            const int co = ch * 64 + cb * 16 + 4 * kg;
-                            const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb + co), t0 = *reinterpret_cast<const f32x4*>(tb + 128 + co);
-                            f32x4 bv;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) bv[e] = b0[e] + t0[e];
-                            char* const a0 = rowb + (((ch * 8 + cb * 2 + (kg >> 1)) ^ px) << 4);
-                            bf16x4 r[8];
-                            if constexpr (kRes) {
-#pragma unroll
-                                for (int nb = 0; nb < 8; ++nb) r[nb] = *reinterpret_cast<const bf16x4*>(a0 + nb * 4096);
-                            }
-                            float sg = 0.f, qg = 0.f;
-#pragma unroll
-                            for (int nb = 0; nb < 8; ++nb) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    float v = acc[cb][nb][e] + bv[e];
-                                    if constexpr (kRes) v += (float)r[nb][e];
-                                    const float o = (float)(bf16)v;
-                                    acc[cb][nb][e] = o;
-                                    sg += o;
-                                    qg += o * o;
-                                }
-                            }
-                            sg = dxmi_row16_sum(sg);
-                            qg = dxmi_row16_sum(qg);
-                            sg += __shfl_xor(sg, 16, 64);
-                            qg += __shfl_xor(qg, 16, 64);
-                            if (px == 0 && (kg & 1) == 0) {
-                                float* d = sx + ((((ch * 2 + ph) * 4 + cb) * 2 + (kg >> 1)) << 1);
-                                d[0] = sg;
-                                d[1] = qg;
-                            }
-                        }
-                    };
-                    if (has_res) pass1(T_{}); else pass1(F_{});
-                    ws_barrier();                       // E1b
-                    const bool do_silu = (p.gn_flags & 1) != 0;
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb) {
-                        const int co = ch * 64 + cb * 16 + 4 * kg;
-                        const float* s0 = sx + ((((ch * 2 + 0) * 4 + cb) * 2 + (kg >> 1)) << 1);
-                        const float* s1 = sx + ((((ch * 2 + 1) * 4 + cb) * 2 + (kg >> 1)) << 1);
-                        const float S = s0[0] + s1[0], Q = s0[1] + s1[1];
-                        const float mean = S * (1.f / 2048.f);
-                        const float rstd = rsqrtf(fmaxf(Q * (1.f / 2048.f) - mean * mean, 0.f) + p.gn_eps);
-                        const f32x4 gm = *reinterpret_cast<const f32x4*>(gb + co), bt = *reinterpret_cast<const f32x4*>(gb + 128 + co);
-                        float ga[4], be[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            ga[e] = gm[e] * rstd;
-                            be[e] = bt[e] - mean * ga[e];
-                        }
-                        char* const a0 = rowb + (((ch * 8 + cb * 2 + (kg >> 1)) ^ px) << 4);
-#pragma unroll
-                        for (int nb = 0; nb < 8; ++nb) {
-                            bf16x4 y;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float t = acc[cb][nb][e] * ga[e] + be[e];
-                                if (do_silu) t = dxmi_silu_fast(t);
-                                y[e] = (bf16)t;
-                                acc[cb][nb][e] = 0.f;
-                            }
-                            *reinterpret_cast<bf16x4*>(a0 + nb * 4096) = y;
-                        }
-                    }
-                } else
                 if (plain && !is_mask) {                 // the U-Net's convs
                     if (has_res) { if (want_stats) epi(T_{}, F_{}, F_{}, T_{}); else epi(T_{}, F_{}, F_{}, F_{}); }
                     else { if (want_stats) epi(F_{}, F_{}, F_{}, T_{}); else epi(F_{}, F_{}, F_{}, F_{}); }
@@ -521,12 +453,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
                     __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_a), WS_LPTR(tb + 128), 4, 0, 0);
                     __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_b), WS_LPTR(tb + 192), 4, 0, 0);
                 }
-                if constexpr (GN) {
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.gn_gamma + co_a), WS_LPTR(gb), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.gn_gamma + co_b), WS_LPTR(gb + 64), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.gn_beta + co_a), WS_LPTR(gb + 128), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds(WS_GPTR(p.gn_beta + co_b), WS_LPTR(gb + 192), 4, 0, 0);
-                }
             }
             // The residual tile of THIS tile (tile switch): the bulk movers drain piece k of the previous tile's output in the
             // group step their schedule gives it; its residual replacement is fetched here one group step later (the group barrier
@@ -581,7 +507,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
                 load_group(3, nxt.cot, nxt.cot, fq[1]);
             }
             ws_barrier();                                        // E1
-            if constexpr (GN) ws_barrier();                      // E1b: the MFMA waves exchanged their group statistics
             ws_barrier();                                        // E2
             WS_TSTAMP(150, wave == 4 && q == (int)blockIdx.x);
             if (!more) break;
@@ -654,12 +579,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
                 __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_a), WS_LPTR(tb + 128), 4, 0, 0);
                 __builtin_amdgcn_global_load_lds(WS_GPTR(av + co_b), WS_LPTR(tb + 192), 4, 0, 0);
             }
-            if constexpr (GN) {
-                __builtin_amdgcn_global_load_lds(WS_GPTR(p.gn_gamma + co_a), WS_LPTR(gb), 4, 0, 0);
-                __builtin_amdgcn_global_load_lds(WS_GPTR(p.gn_gamma + co_b), WS_LPTR(gb + 64), 4, 0, 0);
-                __builtin_amdgcn_global_load_lds(WS_GPTR(p.gn_beta + co_a), WS_LPTR(gb + 128), 4, 0, 0);
-                __builtin_amdgcn_global_load_lds(WS_GPTR(p.gn_beta + co_b), WS_LPTR(gb + 192), 4, 0, 0);
-            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ws_barrier();                                           // P0
@@ -683,7 +602,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
                 }
             }
             ws_barrier();                                        // E1
-            if constexpr (GN) ws_barrier();                      // E1b: the MFMA waves exchanged their group statistics
             ws_barrier();                                        // E2
             if (!more) break;
             q += qstride;
@@ -761,7 +679,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
             }
             if (!have_prev) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first tile: the residual tile of the prologue landed
             ws_barrier();                                        // E1
-            if constexpr (GN) ws_barrier();                      // E1b: the MFMA waves exchanged their group statistics
             ws_barrier();                                        // E2
             out_prev = reinterpret_cast<bf16*>(p.out) + tile_base(cur);
             prev = cur;
@@ -797,15 +714,15 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
         }
         WS_CLOCKSTAMP(174, wave == 0);
     }
+    if (blockIdx.x == 0 && tid == 0) {
+        g_ws_clock[2] = __builtin_amdgcn_s_memtime();
+        g_ws_clock[3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 template <int TW>
 __global__ __launch_bounds__(512, 1) void conv_ws_kernel(ConvArgs p) {
-    conv_ws_body<TW, false>(p);
-}
-// 16x16 maps, GroupNorm(+SiLU) of the output from the epilogue (round 4; replaces one gn_apply_kernel launch per layer)
-__global__ __launch_bounds__(512, 1) void conv_ws_gn_kernel(ConvArgs p) {
-    conv_ws_body<16, true>(p);
+    conv_ws_body<TW>(p);
 }
 
 }  // namespace
@@ -818,9 +735,7 @@ int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     // an activation mask (data gradient of the value net's convs: out *= mask_src > 0 ? 1 : slope) rides the residual tile's path
     // when there is no residual; both at once stay on conv_pipe_kernel
     if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.ups == 2 || (a.mask_src && a.residual) || a.act == DXMI_ACT_SILU) return 1;
-    // fused GroupNorm of the output (conv_ws_gn_kernel): a 16x16 map (tile = whole image), whole 128-cout tiles of 8-channel groups,
-    // instead of the raw output, plain epilogue
-    if (a.gn_out && !(a.OW == 16 && a.OH == 16 && a.Cout % 128 == 0 && (a.gn_flags & 2) && a.act == DXMI_ACT_NONE && !a.mask_src && !a.gn_stats)) return 1;
+    if (a.gn_out) return 1;          // a fused GroupNorm of the output: conv_sm_kernel / conv_ws8_kernel only
     if (a.Cout % 64 != 0 || (a.C0 + a.C1) % 32 != 0 || a.C0 % 32 != 0) return 1;   // Cout % 128 == 64: the last cout tile is half empty
     const int TW = a.OW >= 32 ? 32 : a.OW;
     if (TW != 32 && TW != 16) return 1;
@@ -866,19 +781,16 @@ int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
 #else
     b.stagger = 0;
 #endif
-    const size_t lds = 2 * WS_HALO + WS_A_RING + WS_RO + WS_TB + (a.gn_out ? WS_GN : 0);
-    if (a.gn_out) b.out = a.gn_out;      // the movers drain the (normalised) tile to the fused output
+    const size_t lds = 2 * WS_HALO + WS_A_RING + WS_RO + WS_TB;
     int grid = b.PT * b.CT;
     if (grid > 256) grid = 256;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ws_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ws_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_ws_gn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (a.gn_out) hipLaunchKernelGGL(conv_ws_gn_kernel, dim3(grid), dim3(512), lds, st, b);
-    else if (TW == 32) hipLaunchKernelGGL(conv_ws_kernel<32>, dim3(grid), dim3(512), lds, st, b);
+    if (TW == 32) hipLaunchKernelGGL(conv_ws_kernel<32>, dim3(grid), dim3(512), lds, st, b);
     else hipLaunchKernelGGL(conv_ws_kernel<16>, dim3(grid), dim3(512), lds, st, b);
     DXMI_CHECK_LAUNCH("dxmi_conv2d_fwd(ws)");
     return DXMI_OK;

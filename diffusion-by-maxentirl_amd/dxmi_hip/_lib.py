@@ -45,6 +45,7 @@ SIGNATURES = {
     "dxmi_conv2d_kernel_id": (c_int, [ctypes.POINTER(ConvDesc)]),
     "dxmi_conv2d_gn_stats_partials": (c_int, [ctypes.POINTER(ConvDesc)]),
     "dxmi_conv2d_gn_fuse_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "dxmi_conv_ws_last_clock": (c_int, [ctypes.POINTER(ctypes.c_uint64)]),
     "dxmi_gn_block_stats_partials": (c_int, [c_int]),
     "dxmi_gn_block_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dxmi_gn_stats_fold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -138,6 +138,15 @@ def get_tuning(name):
     return v.value
 
 
+def conv_ws_clock_ghz():
+    """Shader clock (GHz) the chip held during the most recent conv_ws_kernel launch (dxmi_conv_ws_last_clock), or None when the
+    kernel has not run / the counters did not advance.  Synchronises."""
+    buf = (ctypes.c_uint64 * 4)()
+    check(load().dxmi_conv_ws_last_clock(buf), "dxmi_conv_ws_last_clock")
+    dc, dr = int(buf[2]) - int(buf[0]), int(buf[3]) - int(buf[1])
+    return (dc / dr) * 0.1 if dc > 0 and dr > 0 else None
+
+
 class PackedConvWeight:
     """bf16 MFMA-fragment-ordered copy of an OIHW fp32 weight."""
 

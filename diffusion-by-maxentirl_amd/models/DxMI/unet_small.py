@@ -232,7 +232,6 @@ class Model(nn.Module):
     FUSE_ATTN_PROJ = True             # proj_out + residual of the 16x16 AttnBlocks behind the attention kernel
     FUSE_ATTN_BLOCK = True            # the 16x16 AttnBlocks as ONE launch (norm, q|k|v, attention, proj_out, residual: ops.attn_block)
     FUSE_GN_SMALL = True              # norm2 of the 4x4 ResnetBlocks from conv1's epilogue (instance override: A-B timing)
-    FUSE_GN_16 = False                # ... and of the 16x16 ResnetBlocks (conv_ws_gn_kernel): parity-green but 4 % SLOWER end to end
     STREAM_GN_MIN_HW = 256            # instance attribute override (tests / A-B timing): 1 << 30 = one-pass GroupNorm everywhere
 
     def _conv_s(self, x, pw, **kw):
@@ -256,9 +255,9 @@ class Model(nn.Module):
         off = pk[id(b), "toff"]
         stream = x0.shape[1] * x0.shape[2] >= self.STREAM_GN_MIN_HW
         a = None
-        if (not stream and self.FUSE_GN_SMALL) or (x0.shape[1] == 16 and x0.shape[2] == 16 and self.FUSE_GN_16):
-            # 4x4 maps, and 16x16 maps (round 4: conv_ws_gn_kernel — a tile is a whole image): conv1's epilogue normalises its own
-            # output (whole images and groups per tile); h has no other reader.  Where the kernel for the shape cannot, a is None
+        if not stream and self.FUSE_GN_SMALL:
+            # 4x4 maps: conv1's epilogue normalises its own output (whole images and groups per tile); h has no other reader.
+            # Where the kernel for the shape cannot, a is None
             h, a = ops.conv2d(a0, pk[id(b), "conv1"], bias=b.conv1.bias, addvec=tp[:, off:off + b.out_channels],
                               fuse_gn=(b.norm2.weight, b.norm2.bias, 32, 1e-6, True, False))
             sh = None

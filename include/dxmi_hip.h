@@ -121,6 +121,10 @@ typedef struct dxmi_conv_desc {
 int dxmi_conv2d_fwd(const dxmi_conv_desc* d, void* stream);
 /* 1 when the kernel dxmi_conv2d_fwd would launch for `d` can fuse the GroupNorm of its output (gn_out ...), else 0. */
 int dxmi_conv2d_gn_fuse_supported(const dxmi_conv_desc* d);
+/* Measurement aid (round 5): (s_memtime, s_memrealtime) at the first and the last instruction of workgroup 0 of the most recent
+ * wave-specialised 3x3 conv launch (conv_ws_kernel), copied to host memory: host_out4 = {cycles0, ref0, cycles1, ref1}; the shader
+ * clock the chip held during that launch is (cycles1 - cycles0) / (ref1 - ref0) x 100 MHz.  Synchronises (a device-to-host copy). */
+int dxmi_conv_ws_last_clock(unsigned long long* host_out4);
 /* Partials per image (P above) the kernel dxmi_conv2d_fwd would launch for `d` writes into d->gn_stats; 0 = that kernel
  * does not produce block statistics (use dxmi_gn_block_stats on its output, or the one-pass dxmi_groupnorm_silu_fwd). */
 int dxmi_conv2d_gn_stats_partials(const dxmi_conv_desc* d);

@@ -78,7 +78,10 @@ def main():
         print(json.dumps({"world": world, "rank_identical_parameters": same if world > 1 else None, "finite": fin, "backend": dist.get_backend(),
                           "mean_rel_err": mean_err, "mean_bitwise": mean_bitwise, "ranks_differ": ranks_differ,
                           "nccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()),
-                          "flat_bytes": [tr.sync_v.flat.numel() * 4, tr.sync_sampler.flat.numel() * 4]}))
+                          "flat_bytes": [(tr.sync_v.flat.numel() - tr.sync_v.nflags) * 4, (tr.sync_sampler.flat.numel() - tr.sync_sampler.nflags) * 4],
+                          "flags": [tr.sync_v.nflags, tr.sync_sampler.nflags],
+                          "grads_alias_flat": all(p.grad is None or p.grad.data_ptr() == v.data_ptr()
+                                                  for s_ in (tr.sync_v, tr.sync_sampler) for p, v in zip(s_.params, s_.views))}))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -412,44 +412,6 @@ def test_conv_ws8_fused_groupnorm(ops, N, C0, C1, res, silu):
         assert torch.equal(one[0], y[i]), i
 
 
-@pytest.mark.parametrize("N,C0,C1,res,silu", [(37, 256, 0, False, True), (5, 256, 256, True, False), (260, 128, 0, False, True)])
-def test_conv_ws16_fused_groupnorm(ops, N, C0, C1, res, silu):
-    """16x16 maps (round 4): conv_ws_gn_kernel writes GroupNorm(+SiLU) of its output instead of the raw output — a tile is a whole
-    image x 128 couts, the two pixel halves exchange their group sums through LDS.  Against the separate launch on the raw output
-    (one bf16 step apart where the two statistics paths round differently), against fp32 GroupNorm, reproducible, batch-independent."""
-    Cout = 256
-    g = torch.Generator().manual_seed(23 + N)
-    x0 = torch.randn(N, 16, 16, C0, generator=g).to(torch.bfloat16).to(DEV)
-    x1 = torch.randn(N, 16, 16, C1, generator=g).to(torch.bfloat16).to(DEV) if C1 else None
-    w = (torch.randn(Cout, C0 + C1, 3, 3, generator=g) * 0.03).to(DEV)
-    pw = ops.pack_conv_weight(w)
-    bv = torch.randn(Cout, generator=g).to(DEV)
-    tv = torch.randn(N, Cout, generator=g).to(DEV)
-    r = torch.randn(N, 16, 16, Cout, generator=g).to(torch.bfloat16).to(DEV) if res else None
-    gamma = (1 + 0.3 * torch.randn(Cout, generator=g)).to(DEV)
-    beta = (0.3 * torch.randn(Cout, generator=g)).to(DEV)
-    kw = dict(in1=x1, bias=bv, addvec=tv, residual=r)
-    raw = ops.conv2d(x0, pw, **kw)
-    none, y = ops.conv2d(x0, pw, fuse_gn=(gamma, beta, 32, 1e-6, silu, False), **kw)
-    assert none is None and y is not None
-    sep = ops.groupnorm_silu(raw, gamma, beta, groups=32, eps=1e-6, silu=silu)
-    d = (y.float() - sep.float()).abs()
-    assert d.max().item() <= 2 ** -6 * max(1.0, sep.float().abs().max().item()) and (d > 0).float().mean().item() < 0.02
-    ref = F.group_norm(raw.float().permute(0, 3, 1, 2), 32, gamma, beta, 1e-6)
-    if silu:
-        ref = F.silu(ref)
-    assert ((y.float() - ref.permute(0, 2, 3, 1)).norm() / ref.norm()).item() < 3e-3
-    assert torch.equal(y, ops.conv2d(x0, pw, fuse_gn=(gamma, beta, 32, 1e-6, silu, False), **kw)[1])
-    for i in {0, N // 2, N - 1}:
-        _, one = ops.conv2d(x0[i:i + 1].contiguous(), pw, in1=None if x1 is None else x1[i:i + 1].contiguous(), bias=bv,
-                            addvec=tv[i:i + 1].contiguous(), residual=None if r is None else r[i:i + 1].contiguous(),
-                            fuse_gn=(gamma, beta, 32, 1e-6, silu, False))
-        assert torch.equal(one[0], y[i]), i
-    # keeping the raw output as well is not offered on these maps (one output tile in LDS)
-    out, y2 = ops.conv2d(x0, pw, fuse_gn=(gamma, beta, 32, 1e-6, silu, True), **kw)
-    assert y2 is None and torch.equal(out, raw)
-
-
 def test_stem_and_stride2_conv_block_stats(ops):
     """conv_stem_kernel and the stride-2 conv_pipe_kernel (Downsample) emit the block statistics of what they store (one partial
     per tile), the output is bitwise that of a launch without statistics, and an image's rows do not depend on the batch."""
