@@ -193,7 +193,12 @@ def test_hip_edm_trainer_step_vs_reference(golden_dir):
     print("edm master gradients:", report)
     worst = [r for r in report if r[2] < 0.995 or abs(r[3] - 1) > 0.05]
     assert not worst, worst
-    print("edm update cosines:", [round(_cos((P[k].detach() - w0[k]).cpu().numpy(), g[f"delta_{i}"]), 4) for i, k in enumerate(pick)])
+    wg = min(report, key=lambda r: r[2])
+    print(f"edm master gradients WORST tensor: {wg[1]} ({wg[0]} optimiser step) cosine {wg[2]} norm ratio {wg[3]} (bounds 0.995 / 5 %)")
+    ucos = [(k, _cos((P[k].detach() - w0[k]).cpu().numpy(), g[f"delta_{i}"])) for i, k in enumerate(pick)]
+    print("edm update cosines:", [round(c, 4) for _, c in ucos])
+    wu = min(ucos, key=lambda t: t[1])
+    print(f"edm update WORST tensor: {wu[0]} cosine {wu[1]:.5f} (bound {UPDATE_COS})")
     for i, k in enumerate(pick):
         got, ref = (P[k].detach() - w0[k]).cpu().numpy(), g[f"delta_{i}"]
         assert _cos(got, ref) > UPDATE_COS, (k, _cos(got, ref))

@@ -300,6 +300,8 @@ def test_hip_trainer_step_vs_reference(golden_dir, fixture, fused):
     lb = net.log_betas.detach().cpu().numpy()
     assert np.allclose(lb, g["log_betas_after"], atol=3e-5), (lb, g["log_betas_after"])
     print(f"{fixture}:", ", ".join(f"{r[0]}={r[1]:.4f}" for r in report))
+    worst = min(report, key=lambda r: r[1])
+    print(f"{fixture} WORST tensor: {worst[0]} cosine {worst[1]:.5f} (bounds: gradients 0.995, updates 0.97)")
 
 
 @pytest.mark.gpu
@@ -361,6 +363,8 @@ def test_hip_trainer_ev_step_vs_reference(golden_dir):
         report.append((f"f-update/{fnames[i]}", c))
         assert c > 0.97, (fnames[i], c)
     print("trainer_ev_step:", ", ".join(f"{r[0]}={r[1]:.4f}" for r in report))
+    worst = min(report, key=lambda r: r[1])
+    print(f"trainer_ev_step WORST tensor: {worst[0]} cosine {worst[1]:.5f} (bounds: gradients 0.995, updates 0.97)")
 
 
 def test_oracle_sample_guidance_matches_reference(golden_dir):

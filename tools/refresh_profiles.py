@@ -26,7 +26,7 @@ for d in (f"{tag}_pmc_sq1", f"{tag}_pmc_sq2"):
     keep = False
     for l in run("tools/pmc_summary.py", f"gpurun_out/{d}").split("\n"):
         if not l.startswith("    "):
-            keep = any(k in l for k in ("conv_ws_kernel", "conv_ws8_kernel", "conv_sm_kernel", "conv_head_kernel", "conv_pipe_kernel<4, ", "conv1x1_rw_kernel", "conv1x1_stream_kernel", "conv_pipe_kernel<2, 6, 3", "gn_silu_kernel", "gn_apply_kernel", "attention_kernel", "attention256_kernel"))
+            keep = any(k in l for k in ("conv_ws_kernel", "conv_ws8_kernel", "conv_sm_kernel", "conv_head_kernel", "conv_pipe_kernel<4, ", "conv1x1_rw_kernel", "conv1x1_stream_kernel", "conv_pipe_kernel<2, 6, 3", "gn_silu_kernel", "gn_apply_kernel", "attention_kernel", "attention256_kernel", "attn_block256_kernel"))
         if keep:
             out += l + "\n"
 open(f"profiles/{tag}_pmc_sq_counters.txt", "w").write(out)
