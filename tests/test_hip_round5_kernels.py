@@ -136,3 +136,4 @@ def test_unet_forward_with_and_without_the_one_launch_attn_block():
     rel = ((y1 - y0).norm() / y0.norm()).item()
     print(f"unet forward one-launch vs three-launch attn blocks: rel-L2 {rel:.3e}, worst block {worst:.3e}")
     assert torch.isfinite(y1).all() and rel < 1.2e-2 and worst < 2e-2
+
