@@ -101,6 +101,17 @@ int main(void) {
     expect_einval("attention_fwd(C % heads)", dxmi_attention_fwd(FAKE(1), FAKE(2), 4, 256, 250, 4, 0.0625f, NULL));
     expect_einval("attention_fwd(heads = 0)", dxmi_attention_fwd(FAKE(1), FAKE(2), 4, 256, 256, 0, 0.0625f, NULL));
     expect_einval("attention_proj_fwd(T = 64)", dxmi_attention_proj_fwd(FAKE(1), FAKE(2), (const float*)FAKE(3), FAKE(4), FAKE(5), NULL, 4, 64, 256, 1, 0.0625f, NULL));
+    /* round 5: the AttnBlock as one launch */
+    expect_einval("attn_block_fwd(x NULL)", dxmi_attn_block_fwd(NULL, (const float*)FAKE(2), 2, (const float*)FAKE(3), (const float*)FAKE(4), 1e-6f, FAKE(5), FAKE(6), NULL, 4, 256, 256, NULL));
+    expect_einval("attn_block_fwd(stats NULL)", dxmi_attn_block_fwd(FAKE(1), NULL, 2, (const float*)FAKE(3), (const float*)FAKE(4), 1e-6f, FAKE(5), FAKE(6), NULL, 4, 256, 256, NULL));
+    expect_einval("attn_block_fwd(T = 64)", dxmi_attn_block_fwd(FAKE(1), (const float*)FAKE(2), 2, (const float*)FAKE(3), (const float*)FAKE(4), 1e-6f, FAKE(5), FAKE(6), NULL, 4, 64, 256, NULL));
+    expect_einval("attn_block_fwd(C = 512)", dxmi_attn_block_fwd(FAKE(1), (const float*)FAKE(2), 2, (const float*)FAKE(3), (const float*)FAKE(4), 1e-6f, FAKE(5), FAKE(6), NULL, 4, 256, 512, NULL));
+    expect_einval("attn_block_fwd(P = 9)", dxmi_attn_block_fwd(FAKE(1), (const float*)FAKE(2), 9, (const float*)FAKE(3), (const float*)FAKE(4), 1e-6f, FAKE(5), FAKE(6), NULL, 4, 256, 256, NULL));
+    expect_einval("attn_block_fwd(P = 0)", dxmi_attn_block_fwd(FAKE(1), (const float*)FAKE(2), 0, (const float*)FAKE(3), (const float*)FAKE(4), 1e-6f, FAKE(5), FAKE(6), NULL, 4, 256, 256, NULL));
+    expect_einval("attn_block_fwd(N = 0)", dxmi_attn_block_fwd(FAKE(1), (const float*)FAKE(2), 2, (const float*)FAKE(3), (const float*)FAKE(4), 1e-6f, FAKE(5), FAKE(6), NULL, 0, 256, 256, NULL));
+    expect_einval("attn_block_pack(wq NULL)", dxmi_attn_block_pack(NULL, (const float*)FAKE(2), (const float*)FAKE(3), (const float*)FAKE(4), (const float*)FAKE(5), (const float*)FAKE(6), (const float*)FAKE(7), 0.0625f, FAKE(8), NULL));
+    expect_einval("attn_block_pack(dst NULL)", dxmi_attn_block_pack((const float*)FAKE(1), (const float*)FAKE(2), (const float*)FAKE(3), (const float*)FAKE(4), (const float*)FAKE(5), (const float*)FAKE(6), (const float*)FAKE(7), 0.0625f, NULL, NULL));
+    expect_negative("attn_block_fwd(valid, no device)", dxmi_attn_block_fwd(FAKE(1), (const float*)FAKE(2), 2, (const float*)FAKE(3), (const float*)FAKE(4), 1e-6f, FAKE(5), FAKE(6), NULL, 4, 256, 256, NULL));
     expect_einval("var_step_fwd(NULL x)", dxmi_var_step_fwd(NULL, (const float*)FAKE(1), (const float*)FAKE(2), (const float*)FAKE(3), (const float*)FAKE(4), (const float*)FAKE(5), (float*)FAKE(6), (float*)FAKE(7), (float*)FAKE(8), (float*)FAKE(9), 4, 3072, 0, NULL));
     expect_einval("var_step_fwd(N < 0)", dxmi_var_step_fwd((const float*)FAKE(1), (const float*)FAKE(1), (const float*)FAKE(2), (const float*)FAKE(3), (const float*)FAKE(4), (const float*)FAKE(5), (float*)FAKE(6), (float*)FAKE(7), (float*)FAKE(8), (float*)FAKE(9), -4, 3072, 0, NULL));
     expect_einval("var_gather_sched(NULL t)", dxmi_var_gather_sched(NULL, (const float*)FAKE(1), (const float*)FAKE(2), (const float*)FAKE(3), (const float*)FAKE(4), (float*)FAKE(5), (float*)FAKE(6), (float*)FAKE(7), (float*)FAKE(8), 4, 10, NULL));

@@ -29,4 +29,5 @@ hipError_t hipGetDevice(int* d) { *d = 0; return hipErrorNoDevice; }
 hipError_t hipGetDeviceCount(int* n) { *n = 0; return hipErrorNoDevice; }
 hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_tR0600* p, int) { memset(p, 0, sizeof *p); return hipErrorNoDevice; }
 hipError_t hipGetSymbolAddress(void** p, const void*) { *p = nullptr; return hipErrorNoDevice; }
+hipError_t hipMemcpyFromSymbol(void*, const void*, size_t, size_t, hipMemcpyKind) { return hipErrorNoDevice; }
 }
