@@ -46,8 +46,8 @@ def test_trainer_step_under_rccl():
     world = torch.cuda.device_count()
     assert line["backend"] == "nccl" and line["world"] == world and line["finite"]
     assert line["flat_bytes"][0] == 5_134_595 * 4 and line["flat_bytes"][1] == (35_746_307 + 4) * 4
-    # round 5: one "used on some rank" flag per parameter rides in the tail of the last bucket (33 value-net tensors, 330 + log_betas)
-    assert line["flags"] == [33, 331]
+    # round 5: one "used on some rank" flag per parameter rides in the tail of the last bucket (33 value-net tensors, the 329 trainable tensors of the sampler)
+    assert line["flags"] == [33, 329]
     assert line["mean_rel_err"] < 1e-6
     if world == 1:
         assert line["mean_bitwise"]            # AVG over a 1-rank communicator returns its input
