@@ -137,3 +137,17 @@ def test_unet_forward_with_and_without_the_one_launch_attn_block():
     print(f"unet forward one-launch vs three-launch attn blocks: rel-L2 {rel:.3e}, worst block {worst:.3e}")
     assert torch.isfinite(y1).all() and rel < 1.2e-2 and worst < 2e-2
 
+
+
+def test_conv_ws_in_kernel_clock(ops):
+    """dxmi_conv_ws_last_clock: the shader clock the chip held during the last conv_ws_kernel launch, from the kernel's own
+    s_memtime / s_memrealtime stamps (bench.py roofline.clock_ghz).  MI355X boosts to 2.4 GHz and throttles under MFMA load."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(64, 32, 32, 128, generator=g).to(torch.bfloat16).to(DEV)
+    pw = ops.pack_conv_weight((torch.randn(128, 128, 3, 3, generator=g) * 0.03).to(DEV))
+    for _ in range(3):
+        ops.conv2d(x, pw)
+    torch.cuda.synchronize()
+    c = ops.conv_ws_clock_ghz()
+    print(f"conv_ws_kernel in-kernel clock: {c:.3f} GHz")
+    assert c is not None and 0.8 < c < 2.6, c
