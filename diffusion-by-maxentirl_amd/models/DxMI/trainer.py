@@ -152,6 +152,8 @@ class DxMI_Trainer:
             extra = self.time_cost_sig * torch.sigmoid(-timestep + center) - self.time_cost_sig * torch.sigmoid(-timestep - 1 + center)
         return extra
 
+    PAIR_TD_FORWARD = True        # one value-net forward per TD step for target + prediction (A/B switch; results agree to bf16 noise)
+
     # ------------------------------------------------------------------ value / energy update
     def update_f_v(self, img, d_sample, state_dict):
         """reference :230-346."""
@@ -200,9 +202,19 @@ class DxMI_Trainer:
             running_cost = self.get_running_cost(state, next_state, pred_mean, pred_std, timestep)
             if need_entropy:
                 entropy = torch.log(pred_std.squeeze())
-            _set_mode(self.v, False)
-            with torch.no_grad():
-                target = self.v(next_state, timestep + 1).squeeze()
+            # TD target v(next_state) and TD prediction v(state): same parameters, so ONE forward over [next_state | state] where the
+            # value plugin offers it (models.value.TimeIndependentValue.forward_pair; the reference evaluates the target under eval()
+            # and the prediction under train(), :288-300 — no layer of the HIP value nets reads the flag); only the prediction's half
+            # is back-propagated.  Halves the launches of the value net's small maps (one tile per CU at 256 images).
+            pair = getattr(self.v, "forward_pair", None) if self.PAIR_TD_FORWARD else None
+            if pair is not None:
+                _set_mode(self.v, True)
+                target, v_xt = pair(next_state, timestep + 1, state, timestep)
+                target, v_xt = target.squeeze(), v_xt.squeeze()
+            else:
+                _set_mode(self.v, False)
+                with torch.no_grad():
+                    target = self.v(next_state, timestep + 1).squeeze()
             target = target + self._time_cost_terms(timestep)
             if self.time_cost is not None:
                 target = target + self.time_cost
@@ -211,8 +223,9 @@ class DxMI_Trainer:
             if self.entropy_in_value or self.entropy_in_value == 0:
                 assert isinstance(self.entropy_in_value, int), "self.entropy_in_value should be interger"
                 target = target - entropy * self.tau1 * (timestep < n_steps - self.entropy_in_value).float()
-            _set_mode(self.v, True)
-            v_xt = self.v(state, timestep).squeeze()
+            if pair is None:
+                _set_mode(self.v, True)
+                v_xt = self.v(state, timestep).squeeze()
             v_loss = F.mse_loss(v_xt, target.detach())
             v_loss.backward()
             self.sync_v()

@@ -127,6 +127,21 @@ class IGEBMEncoderV2(nn.Module):
             return forward_with_grad(self, input)
         return self.forward_inference(input)
 
+    def forward_pair(self, x_free, x_grad):
+        """(net(x_free) without a graph, net(x_grad) with one) from ONE forward over the concatenated batch: the TD steps of the
+        trainers evaluate the target v(next_state) and the prediction v(state) with the same parameters (reference
+        models/DxMI/trainer.py:288-300 switches eval() / train() in between, which no layer of this encoder reads), and the small
+        maps of this net leave a 256-image launch one tile per CU with every fixed cost exposed.  Each image's value is bitwise
+        what its own forward gives where the library's kernel choice does not depend on the batch (default knobs)."""
+        if not (torch.is_grad_enabled() and any(p.requires_grad for p in ops.fast_parameters(self))) or x_free.requires_grad or x_grad.requires_grad:
+            with torch.no_grad():
+                t = self.forward(x_free)
+            return t, self.forward(x_grad)
+        from .value_train import forward_with_grad
+        n0 = x_free.shape[0]
+        res = forward_with_grad(self, torch.cat((x_free.detach(), x_grad), 0), nfree=n0)
+        return res[:n0].detach(), res[n0:]
+
     @torch.no_grad()
     def forward_inference(self, input):
         pk = self.packed()

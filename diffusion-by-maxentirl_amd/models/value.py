@@ -12,5 +12,15 @@ class TimeIndependentValue(nn.Module):
     def forward(self, x, t, y=None):
         return self.net(x, y) if y is not None else self.net(x)
 
+    def forward_pair(self, x_free, t_free, x_grad, t_grad, y=None):
+        """(V(x_free, t_free) without a graph, V(x_grad, t_grad) with one) in one forward of the wrapped network (t is ignored):
+        the TD target and the TD prediction of one step (models.modules.IGEBMEncoderV2.forward_pair)."""
+        if y is not None or not hasattr(self.net, "forward_pair"):
+            import torch
+            with torch.no_grad():
+                tgt = self.forward(x_free, t_free, y=y)
+            return tgt, self.forward(x_grad, t_grad, y=y)
+        return self.net.forward_pair(x_free, x_grad)
+
     def load_pretrained(self, ckpt):
         self.net.load_pretrained(ckpt)

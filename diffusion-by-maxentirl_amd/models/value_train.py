@@ -19,8 +19,12 @@ SLOPE = 0.2
 
 
 class _ValueNetFn(torch.autograd.Function):
+    """nfree: the first `nfree` images of the batch take part in the forward only (round 5: the TD target v(next_state) and the
+    prediction v(state) of one TD step are ONE forward over [next_state | state] — same parameters, no mode-dependent layer in this
+    encoder — and only the second half is back-propagated; every image's value is what a forward on its own would give)."""
+
     @staticmethod
-    def forward(ctx, net, x, *params):
+    def forward(ctx, net, nfree, x, *params):
         pk = net.packed()
         x = x.contiguous().float()
         k27 = pk["conv1"].k27
@@ -36,12 +40,14 @@ class _ValueNetFn(torch.autograd.Function):
                 out = ops.pool_act(c2, True, ops.ACT_LEAKY02)
             else:
                 out = ops.conv2d(h1, pk[i, "conv2"], bias=b.conv2.bias, residual=skip, act=ops.ACT_LEAKY02)
-            saved.append((inp, h1, out))
+            saved.append((inp[nfree:], h1[nfree:], out[nfree:]) if nfree else (inp, h1, out))
             inp = out
         ow, ob = (net.out_scale.weight, net.out_scale.bias) if net.learn_out_scale else (None, None)
         res = ops.value_head(inp, net.linear.weight, net.linear.bias, ow, ob)
-        ctx.net, ctx.saved, ctx.a0, ctx.x, ctx.x_nhwc = net, saved, a0, x, x_nhwc
-        ctx.need_dx = x.requires_grad or ctx.needs_input_grad[1]
+        ctx.net, ctx.saved, ctx.a0, ctx.x, ctx.x_nhwc = net, saved, (a0[nfree:] if nfree else a0), (x[nfree:] if nfree else x), x_nhwc
+        ctx.nfree = nfree
+        ctx.need_dx = x.requires_grad or ctx.needs_input_grad[2]
+        assert not (nfree and ctx.need_dx), "a forward-only prefix and an input gradient do not go together"
         # parameter gradients are skipped when no parameter asks for one (the policy step only needs d/dx: its value
         # gradients are discarded by the next zero_grad, reference trainer.py:235, :387)
         ctx.need_dw = any(prm.requires_grad for prm in params)
@@ -54,7 +60,7 @@ class _ValueNetFn(torch.autograd.Function):
         grads = {}
         feat = saved[-1][2]
         N = feat.shape[0]
-        dy = dres.reshape(N).float().contiguous()
+        dy = dres.reshape(-1)[ctx.nfree:].float().contiguous()
         # ---- head: y = s @ w + b ; out = y * ow + ob
         w = net.linear.weight.reshape(-1)
         if net.learn_out_scale:
@@ -101,11 +107,11 @@ class _ValueNetFn(torch.autograd.Function):
         if ctx.need_dx:
             # data gradient of the stem: 128 -> 3 channel conv on flipped weights, fp32 NCHW out
             dx = ops.conv2d(d_a0, ops.pack_conv_weight(net.conv1.weight, transpose_flip=True), out_nchw_f32=True)
-        out = [None, dx]
+        out = [None, None, dx]
         for prm in net.parameters():
             out.append(grads.get(prm))
         return tuple(out)
 
 
-def forward_with_grad(net, x):
-    return _ValueNetFn.apply(net, x, *ops.fast_parameters(net))
+def forward_with_grad(net, x, nfree=0):
+    return _ValueNetFn.apply(net, nfree, x, *ops.fast_parameters(net))

@@ -151,3 +151,35 @@ def test_conv_ws_in_kernel_clock(ops):
     c = ops.conv_ws_clock_ghz()
     print(f"conv_ws_kernel in-kernel clock: {c:.3f} GHz")
     assert c is not None and 0.8 < c < 2.6, c
+
+
+def test_value_net_forward_pair_equals_two_forwards():
+    """IGEBMEncoderV2.forward_pair (round 5: TD target + TD prediction of a train step in ONE forward, trainer.py:288-300): the two
+    halves equal the no-grad forward and the autograd forward on their own, and the parameter gradients equal the gradients of
+    the prediction half alone."""
+    from models.modules import IGEBMEncoderV2
+    from models.value import TimeIndependentValue
+    torch.manual_seed(3)
+    v = TimeIndependentValue(IGEBMEncoderV2(in_chan=3, out_chan=1, keepdim=False, nh=128)).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(6, 3, 32, 32, generator=g).to(DEV)
+    x1 = torch.randn(6, 3, 32, 32, generator=g).to(DEV)
+    t = torch.zeros(6, dtype=torch.long, device=DEV)
+    tgt, pred = v.forward_pair(x0, t + 1, x1, t)
+    assert not tgt.requires_grad and pred.requires_grad and tgt.shape == pred.shape == (6, 1)
+    (pred.squeeze() - tgt.squeeze()).pow(2).mean().backward()
+    grads = [p.grad.clone() for p in v.parameters()]
+    for p in v.parameters():
+        p.grad = None
+    with torch.no_grad():
+        tgt2 = v(x0, t + 1)
+    pred2 = v(x1, t)
+    (pred2.squeeze() - tgt2.squeeze()).pow(2).mean().backward()
+    assert torch.equal(tgt, tgt2) and torch.equal(pred.detach(), pred2.detach())
+    for a, p in zip(grads, v.parameters()):
+        assert torch.equal(a, p.grad), (a - p.grad).abs().max()
+    # an input that asks for a gradient (the policy step) keeps the two-forward path
+    x1g = x1.clone().requires_grad_(True)
+    tgt3, pred3 = v.forward_pair(x0, t + 1, x1g, t)
+    pred3.sum().backward()
+    assert x1g.grad is not None and torch.equal(tgt3, tgt2)
