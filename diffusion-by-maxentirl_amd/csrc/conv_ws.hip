@@ -139,6 +139,53 @@ struct WsTile {
     int cot, n0, oy0, ox0;
 };
 
+#ifdef WS_VALU_PIECES
+// Measurement build (round 5, tools/build_variant.sh ... -DWS_VALU_PIECES=n): every mover wave runs n 16-byte pieces of the
+// GroupNorm(+SiLU) transform (bf16 -> fma -> SiLU -> bf16 on dummy registers: no LDS, no table loads) per group step — 2 per group
+// step and wave is the VALU work of transforming every halo chunk on load (22 KiB per chunk over four waves).  What the consuming
+// conv would pay AT LEAST for applying the normalisation itself; results are unchanged (the values go nowhere).
+typedef float ws_f32x2 __attribute__((ext_vector_type(2)));
+struct WsValuLoad {
+    u32x4 r[2];
+    ws_f32x2 A[4], B[4];
+    unsigned sink;
+    __device__ __forceinline__ void init(int lane) {
+        for (int k = 0; k < 2; ++k) r[k] = u32x4{0x3f803f00u + lane + k, 0xbf803e80u + k, 0x3e003f80u + lane, 0x40003f00u - k};
+        for (int i = 0; i < 4; ++i) {
+            A[i] = ws_f32x2{0.9f + 0.01f * lane, 1.1f - 0.01f * i};
+            B[i] = ws_f32x2{0.05f * i, -0.03f * lane};
+        }
+        sink = 0;
+    }
+    __device__ __forceinline__ void run() {
+#pragma unroll
+        for (int k = 0; k < WS_VALU_PIECES; ++k) {
+            u32x4& raw = r[k & 1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ws_f32x2 x = {__builtin_bit_cast(float, raw[i] << 16), __builtin_bit_cast(float, raw[i] & 0xffff0000u)};
+                ws_f32x2 y = x * A[i] + B[i];
+                const ws_f32x2 t = y * ws_f32x2{-1.4426950408889634f, -1.4426950408889634f};
+                ws_f32x2 e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                e = e + ws_f32x2{1.f, 1.f};
+                const ws_f32x2 rc = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+                y = y * rc;
+                bf16x2 o = {(bf16)y[0], (bf16)y[1]};
+                sink ^= __builtin_bit_cast(unsigned, o);
+            }
+            raw += u32x4{0x10001u, 0x20003u, 0x10002u, 0x30001u};
+        }
+    }
+};
+#define WS_VALU_DECL(lane_) WsValuLoad vl_; vl_.init(lane_)
+#define WS_VALU_RUN() vl_.run()
+#define WS_VALU_DONE() do { if (vl_.sink == 0x12345u) reinterpret_cast<volatile unsigned*>(p.out)[0] = vl_.sink; } while (0)
+#else
+#define WS_VALU_DECL(lane_) do {} while (0)
+#define WS_VALU_RUN() do {} while (0)
+#define WS_VALU_DONE() do {} while (0)
+#endif
+
 // Halo image: pixel (hy, hx) of the (TH+2) x (TW+2) halo at row pitch HP pixels, 64 B (32 channels) per pixel in four
 // 16-byte slots; channel piece j sits in slot j ^ (2 * ((hx >> 2) & 1)).  The MFMA shape is 16x16x32 (on random data the chip
 // holds a higher clock on it than on 32x32x16 at equal cycles per FLOP: MI355X_MICROARCH.md, DVFS give-back item 7): a B
@@ -366,6 +413,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
         }
     } else if (wave < 6) {
         // ================================================================ weight loaders (waves 4, 5)
+        WS_VALU_DECL(lane);
         const int lw = wave - 4;
         const char* const wb = reinterpret_cast<const char*>(p.w) + (size_t)lane * 16;
         WsTile cur;
@@ -493,6 +541,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
                     }
                     if (G > 0 || first_group0) load_group(G + 3, cur.cot, more ? nxt.cot : cur.cot, fq[(j + 1) & 1]);
                     WS_TSTAMP(151, wave == 4 && G == 0 && q == (int)blockIdx.x + qstride);
+                    WS_VALU_RUN();
                     if (!(WS_DBG(16))) ws_barrier();                        // end of group step G
                 }
             }
@@ -514,12 +563,14 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
             cur = nxt;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WS_VALU_DONE();
     } else if (wave == 6) {
         // ================================================================ halo mover (wave 6): loads only
         // Round 4: the two bulk movers no longer share every job.  vmcnt retires in order, so a wave that stores (the drain) and
         // loads (the halo image) waits, at the chunk end, for the acknowledgement of stores it issued long before the halo
         // blocks it actually needs (stamp build: 300-850 cycles late at every group barrier of a tile switch).  This wave issues
         // nothing but the next chunk's halo image (22 DMAs per chunk, three per step) and waits with vmcnt(0).
+        WS_VALU_DECL(lane);
         constexpr int HBA = WS_HALO_BLOCKS;
         const char* const zero_page = reinterpret_cast<const char*>(p.mask_src);
         int hrel0[HBA], hrel1[HBA];
@@ -598,7 +649,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
                 for (int t = 0; t < 9; ++t) {
                     if (t < 8 && do_halo) halo_issue(hc, hbuf, 3 * t, 3 * t + 3 < HBA ? 3 * t + 3 : HBA);
                     if (t == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the halo image landed
-                    if (t % 3 == 2) { if (!(WS_DBG(16))) ws_barrier(); }            // end of a group step
+                    if (t % 3 == 2) { WS_VALU_RUN(); if (!(WS_DBG(16))) ws_barrier(); }            // end of a group step
                 }
             }
             ws_barrier();                                        // E1
@@ -607,11 +658,13 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
             q += qstride;
             cur = nxt;
         }
+        WS_VALU_DONE();
     } else if (wave == 7) {
         // ================================================================ drain mover (wave 7): LDS -> global stores only
         // All 32 pieces (2 KiB each: both 64-lane halves) of the previous tile's output, on the schedule of piece_range(); the
         // loaders refill a piece with the residual one group step later.  No load, so no wait on a store's acknowledgement
         // anywhere but in front of E1 of the first tile (whose residual tile this wave fetched in the prologue).
+        WS_VALU_DECL(lane);
         const char* const zero_page = reinterpret_cast<const char*>(p.mask_src);
         const int prA = lane >> 4, prB = 4 + (lane >> 4), lc = lane & 15;
         const int lparA[2] = {prA * p.Cout + ((lc ^ prA) * 8), prA * p.Cout + ((lc ^ (prA | 8)) * 8)};
@@ -674,7 +727,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
                             }
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the piece is out of LDS before the group barrier
-                    if (t % 3 == 2) { if (!(WS_DBG(16))) ws_barrier(); }            // end of a group step
+                    if (t % 3 == 2) { WS_VALU_RUN(); if (!(WS_DBG(16))) ws_barrier(); }            // end of a group step
                 }
             }
             if (!have_prev) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // first tile: the residual tile of the prologue landed
@@ -687,6 +740,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
             q += qstride;
             cur = nxt;
         }
+        WS_VALU_DONE();
     }
 
     // ==================================================================== last tile out: all eight waves
