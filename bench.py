@@ -89,6 +89,8 @@ def kernel_name(kid):
     """dxmi_conv2d_kernel_id -> the template instantiation name rocprofv3 prints."""
     if kid >= 600000:
         return "conv_head_kernel"
+    if kid >= 550000:
+        return f"conv1x1_rw8_kernel<{(kid // 10) % 100}, {'true' if kid % 10 else 'false'}>"
     if kid >= 500000:
         return f"conv1x1_rw_kernel<{(kid // 1000) % 10}, {(kid // 10) % 100}, {'true' if kid % 10 else 'false'}>"
     if kid in (400008, 400009):      # 400009: OpProfiler's tag for a launch with the fused GroupNorm output (gn_out)

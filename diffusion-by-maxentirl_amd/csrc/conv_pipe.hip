@@ -763,6 +763,7 @@ int ilog2p(int v) {
 
 int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);       // conv_ws.hip
 int conv1x1_rw_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);   // conv1x1_rw.hip
+int conv1x1_rw8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);  // conv1x1_rw8.hip
 int conv_head_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);    // conv_head.hip
 int conv_ws8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);     // conv_ws8.hip
 int conv_sm_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id);      // conv_sm.hip
@@ -805,6 +806,8 @@ int conv_pipe_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
         if (rc <= 0) return rc;
         // besides conv_ws_kernel only the stem / conv_pipe kernels below emit GroupNorm block statistics, for one-image tiles
         // (dxmi_conv2d_gn_stats_partials says which shapes); the other small-map kernels are skipped for such a request
+        rc = conv1x1_rw8_try_launch(a, st, kernel_id);      // K = 576 (256-cout tiles, one 512-thread workgroup per CU)
+        if (rc <= 0) return rc;
         rc = conv1x1_rw_try_launch(a, st, kernel_id);
         if (rc <= 0) return rc;
         rc = conv_head_try_launch(a, st, kernel_id);

@@ -183,3 +183,49 @@ def test_value_net_forward_pair_equals_two_forwards():
     tgt3, pred3 = v.forward_pair(x0, t + 1, x1g, t)
     pred3.sum().backward()
     assert x1g.grad is not None and torch.equal(tgt3, tgt2)
+
+
+# -------------------------------------------------------------------------- 1x1 convs on conv1x1_rw8_kernel (K = 384 / 512 / 576)
+@pytest.mark.parametrize("N,H,C0,C1,Cout,res,rw8", [
+    (20, 16, 576, 0, 1728, False, True),     # q|k|v of the 576-channel AttentionBlocks: 6.75 cout tiles (the last one three quarters full)
+    (40, 16, 576, 0, 576, True, True),       # proj_out + residual: 2.25 cout tiles
+    (20, 32, 384, 192, 384, False, True),    # skip_connection over a virtual concat whose boundary (384) is a chunk boundary
+    (40, 16, 320, 256, 576, False, True),    # ... and one whose boundary is not
+    (8, 64, 192, 192, 192, False, True),     # K = 384 with a cout count conv1x1_rw_kernel does not take
+    (16, 32, 512, 0, 1536, False, True),     # K = 512, wide output (the LSUN net's q|k|v)
+    (100, 32, 384, 0, 1152, False, False),   # K = 384, Cout % 128 == 0: conv1x1_rw_kernel keeps it
+    (2, 16, 576, 0, 192, False, False),      # fewer pixel tiles than two per stream: the per-tile kernel
+])
+def test_conv1x1_rw8(ops, N, H, C0, C1, Cout, res, rw8):
+    import ctypes
+    from dxmi_hip import _lib
+    g = torch.Generator().manual_seed(N * 7 + Cout)
+    x0 = torch.randn(N, H, H, C0, generator=g).to(torch.bfloat16).to(DEV)
+    x1 = torch.randn(N, H, H, C1, generator=g).to(torch.bfloat16).to(DEV) if C1 else None
+    w = (torch.randn(Cout, C0 + C1, 1, 1, generator=g) * 0.05).to(DEV)
+    b = torch.randn(Cout, generator=g).to(DEV)
+    r = torch.randn(N, H, H, Cout, generator=g).to(torch.bfloat16).to(DEV) if res else None
+    pw = ops.pack_conv_weight(w)
+    y = ops.conv2d(x0, pw, in1=x1, bias=b, residual=r)
+    d = _lib.ConvDesc()
+    d.in0, d.in1, d.wpacked, d.bias, d.out = x0.data_ptr(), (x1.data_ptr() if C1 else None), pw.buf.data_ptr(), b.data_ptr(), y.data_ptr()
+    d.residual = r.data_ptr() if res else None
+    d.N, d.IH, d.IW, d.C0, d.C1, d.OH, d.OW, d.Cout = N, H, H, C0, C1, H, H, Cout
+    d.ksize, d.stride, d.pad = 1, 1, 0
+    kid = _lib.load().dxmi_conv2d_kernel_id(ctypes.byref(d))
+    assert (550000 <= kid < 600000) == rw8, kid
+    xin = torch.cat([x0, x1], 3) if C1 else x0
+    ref = xin.float().reshape(-1, C0 + C1) @ w.view(Cout, -1).to(torch.bfloat16).float().t() + b
+    if res:
+        ref = ref + r.float().reshape(-1, Cout)
+    err = ((y.float().reshape(-1, Cout) - ref).norm() / ref.norm()).item()
+    assert torch.isfinite(y.float()).all() and err < 4e-3, err
+    assert torch.equal(y, ops.conv2d(x0, pw, in1=x1, bias=b, residual=r))          # bitwise reproducible
+    if rw8:
+        # an image's result does not depend on the batch it rides in although a small batch takes the per-tile kernel: both kernels
+        # run the K extent through the same MFMA in the same order and round once
+        one = ops.conv2d(x0[:1].contiguous(), pw, in1=None if x1 is None else x1[:1].contiguous(), bias=b,
+                         residual=None if r is None else r[:1].contiguous())
+        d.N = 1
+        assert not (550000 <= _lib.load().dxmi_conv2d_kernel_id(ctypes.byref(d)) < 600000)
+        assert torch.equal(one[0], y[0])
