@@ -496,7 +496,11 @@ def groupnorm_silu_bwd(x, dy, gamma, beta, *, in1=None, add0=None, add1=None, gr
     C1 = in1.shape[3] if in1 is not None else 0
     C = C0 + C1
     assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and tuple(dy.shape) == (N, H, W, C)
-    if not load().dxmi_groupnorm_silu_bwd_supported(C0, C1, H * W, groups):
+    # 12 channels per group on the large maps (the 384-channel concat inputs of the CIFAR net's up path): the register-resident kernel
+    # slices them badly (414 us at 32x32, 101 us at 16x16, B = 256) and the generic three-launch path is ahead (285 / 79 us:
+    # tools/gn_bwd_time.py); every other shape of the net is faster on the resident kernel
+    slow_resident = (C // groups) % 4 == 0 and (C // groups) % 8 != 0 and (C // groups) > 4 and H * W >= 256
+    if slow_resident or not load().dxmi_groupnorm_silu_bwd_supported(C0, C1, H * W, groups):
         # shapes the register-resident backward cannot slice (the forward falls back the same way): generic three-launch path
         dx0, dx1, dg, db, _ = groupnorm_generic_bwd(x, dy, gamma, beta, in1=in1, add0=add0, add1=add1, groups=groups, eps=eps, silu=silu)
         return dx0, dx1, dg, db
