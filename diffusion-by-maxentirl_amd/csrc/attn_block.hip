@@ -16,12 +16,16 @@
 // and a block is 4 instead of 6 GEMMs per image and 67 MB of HBM traffic per launch at 256 images.
 //
 // One 512-thread workgroup per image, wave w owns queries 32w .. 32w+31 (as attention256_kernel):
-//   prologue  wave w brings ITS 32 rows of x by DMA (16 x 1 KiB, rows XOR-swizzled like attention256_kernel's blocks), the (A, B)
-//             table of the image is formed from the block statistics in gn_apply_kernel's order (pairs over the partials, groups
-//             over their pairs), x^ of the wave's rows is formed in registers (the only place it ever exists);
-//   phase 1   Y^T[c][query] = G x^^T: G's 128 one-KiB fragments stream L2 -> LDS through a ring of three 8 KiB slots (one DMA per
-//             wave and slot, one barrier per slot).  G's rows are packed in the order that makes the accumulators of a 32-channel
-//             block the B-operand fragments of phase 2 as they stand (lane half h: channels 16 j + 8 h .. + 7 of k-step j);
+//   prologue  wave w brings ITS 32 rows of x by DMA (16 x 1 KiB, rows XOR-swizzled like attention256_kernel's blocks); while they
+//             land the (A, B) table of the image is formed from the block statistics in gn_apply_kernel's order (pairs over the
+//             partials, groups over their pairs: DPP quad broadcasts, no LDS round trip; the table is a static LDS object stored by
+//             inline asm so that hipcc does not order it behind the DMAs); x^ of the wave's rows is formed in registers (the only
+//             place it ever exists);
+//   phase 1   Y^T[c][query] = G x^^T: G's 128 one-KiB fragments stream L2 -> registers (a queue of five slots per wave) -> a ring
+//             of three 8 KiB LDS slots, wave w moving fragment w of every slot, one barrier per slot; a slot's fragments are read
+//             into registers one step before their MFMAs, which lead each step with the ring traffic interleaved.  G's rows are
+//             packed in the order that makes the accumulators of a 32-channel block the B-operand fragments of phase 2 as they
+//             stand (lane half h: channels 16 j + 8 h .. + 7 of k-step j);
 //   phase 2   S^T[key][query] = x Y~^T against all 256 keys in LDS (no ring, no barrier), plain two-pass softmax in the log2 domain;
 //   phase 3   O^T[c][query] = x^T P^T through transposing LDS reads (attention256_kernel's scheme), Z = A (.) O / l + B;
 //   phase 4   y^T[cout][query] = W' Z^T, W' through the same ring; out = y + b' + x is formed IN PLACE in the wave's own rows of
