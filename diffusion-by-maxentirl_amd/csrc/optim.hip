@@ -86,10 +86,15 @@ __device__ __forceinline__ void radam_elem(float& p, float g, float& m, float& v
     p = p - upd;          // param.add_(update, alpha=-1.0)
 }
 
+// hyper != nullptr (the *_dev entry points: steps replayed from a hipGraph, where kernel arguments are frozen at capture):
+// the step-dependent scalars come from DEVICE memory — Adam: [bc2_sqrt, step_size[0..count)], RAdam: [1/bc1, bc2_sqrt, rect,
+// lr[0..count)], fp32, formed by the host exactly as for the by-value entry points and uploaded before the replay;
+// hyper_first = index of this launch's first tensor in the list.
 template <int RADAM>
 __global__ __launch_bounds__(MT_BLOCK) void mt_adam_kernel(MtTable t, AdamScalars sa, RAdamScalars sr,
                                                           const float* __restrict__ grad_scale,
-                                                          const float* __restrict__ found_inf, int write_back_grad) {
+                                                          const float* __restrict__ found_inf, int write_back_grad,
+                                                          const float* __restrict__ hyper, int hyper_first) {
     const int ti = mt_find(t, blockIdx.x);
     if (found_inf && *found_inf != 0.f) return;   // overflow step is skipped on the device (fp16_util.py:208-212)
     const int64_t n = t.numel[ti];
@@ -99,7 +104,11 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_adam_kernel(MtTable t, AdamScalar
     float* __restrict__ M = (float*)t.ptr[2][ti];
     float* __restrict__ V = (float*)t.ptr[3][ti];
     const float gs = grad_scale ? *grad_scale : 1.f;
-    const float lr = t.lr[ti];
+    float lr = t.lr[ti];
+    if (hyper) {
+        if (RADAM) { sr.inv_bc1 = hyper[0]; sr.bc2_sqrt = hyper[1]; sr.rect = hyper[2]; lr = hyper[3 + hyper_first + ti]; }
+        else       { sa.bc2_sqrt = hyper[0]; lr = hyper[1 + hyper_first + ti]; }
+    }
     const bool vec = ((((uintptr_t)P | (uintptr_t)G | (uintptr_t)M | (uintptr_t)V) & 15) == 0);
     if (vec && base + MT_CHUNK <= n) {
 #pragma unroll
@@ -204,7 +213,9 @@ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
 }
 
 __global__ __launch_bounds__(256) void dropout_bf16_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int64_t n8,
-                                                          uint32_t seed, uint32_t thresh, float scale) {
+                                                          uint32_t seed, const uint32_t* __restrict__ seed_dev, uint32_t thresh,
+                                                          float scale) {
+    if (seed_dev) seed = *seed_dev;      // dxmi_dropout_bf16_dev: the seed of a replayed (hipGraph) step lives in device memory
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
         const bf16x8 v = *(const bf16x8*)(x + i * 8);
         bf16x8 o;
@@ -281,10 +292,31 @@ extern "C" int64_t dxmi_mt_blocks(const int64_t* numel, int32_t count) {
     return nb;
 }
 
+static int adam_launch(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                       const int64_t* numel, const float* step_size, int32_t count, double beta1, double beta2,
+                       double eps, double bc2_sqrt, const float* grad_scale, int32_t write_back_grad, const float* hyper,
+                       void* stream);
+
 extern "C" int dxmi_adam_step(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
                               const int64_t* numel, const float* step_size, int32_t count, double beta1, double beta2,
                               double eps, double bc2_sqrt, const float* grad_scale, int32_t write_back_grad, void* stream) {
     DXMI_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && numel && step_size && count > 0, "dxmi_adam_step: null argument");
+    return adam_launch(params, grads, exp_avg, exp_avg_sq, numel, step_size, count, beta1, beta2, eps, bc2_sqrt, grad_scale,
+                       write_back_grad, nullptr, stream);
+}
+
+extern "C" int dxmi_adam_step_dev(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                                  const int64_t* numel, int32_t count, double beta1, double beta2, double eps,
+                                  const float* hyper, const float* grad_scale, int32_t write_back_grad, void* stream) {
+    DXMI_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && numel && hyper && count > 0, "dxmi_adam_step_dev: null argument");
+    return adam_launch(params, grads, exp_avg, exp_avg_sq, numel, nullptr, count, beta1, beta2, eps, 1.0, grad_scale,
+                       write_back_grad, hyper, stream);
+}
+
+static int adam_launch(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                       const int64_t* numel, const float* step_size, int32_t count, double beta1, double beta2,
+                       double eps, double bc2_sqrt, const float* grad_scale, int32_t write_back_grad, const float* hyper,
+                       void* stream) {
     AdamScalars sa;
     // python-double scalars rounded to fp32 once, exactly as ATen's Scalar -> opmath_t conversion does
     sa.one_minus_beta1 = (float)(1.0 - beta1);
@@ -298,20 +330,42 @@ extern "C" int dxmi_adam_step(void* const* params, void* const* grads, void* con
         const int c = count - off < DXMI_MT_MAX ? count - off : DXMI_MT_MAX;
         MtTable t;
         int nb = 0;
-        DXMI_CHECK_ARG(fill_table(t, c, params + off, grads + off, exp_avg + off, exp_avg_sq + off, numel + off, step_size + off, &nb),
+        DXMI_CHECK_ARG(fill_table(t, c, params + off, grads + off, exp_avg + off, exp_avg_sq + off, numel + off,
+                                  step_size ? step_size + off : nullptr, &nb),
                        "dxmi_adam_step: empty tensor in the list");
         hipLaunchKernelGGL(mt_adam_kernel<0>, dim3(nb), dim3(MT_BLOCK), 0, (hipStream_t)stream, t, sa, sr, grad_scale,
-                           (const float*)nullptr, write_back_grad);
+                           (const float*)nullptr, write_back_grad, hyper, off);
     }
     DXMI_CHECK_LAUNCH("dxmi_adam_step");
     return DXMI_OK;
 }
+
+static int radam_launch(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                        const int64_t* numel, const float* lr, int32_t count, double beta1, double beta2, double eps,
+                        double bc1, double bc2_sqrt, double rect, const float* grad_scale, const float* found_inf,
+                        const float* hyper, void* stream);
 
 extern "C" int dxmi_radam_step(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
                                const int64_t* numel, const float* lr, int32_t count, double beta1, double beta2, double eps,
                                double bc1, double bc2_sqrt, double rect, const float* grad_scale, const float* found_inf,
                                void* stream) {
     DXMI_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && numel && lr && count > 0, "dxmi_radam_step: null argument");
+    return radam_launch(params, grads, exp_avg, exp_avg_sq, numel, lr, count, beta1, beta2, eps, bc1, bc2_sqrt, rect, grad_scale,
+                        found_inf, nullptr, stream);
+}
+
+extern "C" int dxmi_radam_step_dev(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                                   const int64_t* numel, int32_t count, double beta1, double beta2, double eps,
+                                   const float* hyper, const float* grad_scale, const float* found_inf, void* stream) {
+    DXMI_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && numel && hyper && count > 0, "dxmi_radam_step_dev: null argument");
+    return radam_launch(params, grads, exp_avg, exp_avg_sq, numel, nullptr, count, beta1, beta2, eps, 1.0, 1.0, -1.0, grad_scale,
+                        found_inf, hyper, stream);
+}
+
+static int radam_launch(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                        const int64_t* numel, const float* lr, int32_t count, double beta1, double beta2, double eps,
+                        double bc1, double bc2_sqrt, double rect, const float* grad_scale, const float* found_inf,
+                        const float* hyper, void* stream) {
     RAdamScalars sr;
     sr.one_minus_beta1 = (float)(1.0 - beta1);
     sr.beta2 = (float)beta2;
@@ -325,9 +379,10 @@ extern "C" int dxmi_radam_step(void* const* params, void* const* grads, void* co
         const int c = count - off < DXMI_MT_MAX ? count - off : DXMI_MT_MAX;
         MtTable t;
         int nb = 0;
-        DXMI_CHECK_ARG(fill_table(t, c, params + off, grads + off, exp_avg + off, exp_avg_sq + off, numel + off, lr + off, &nb),
+        DXMI_CHECK_ARG(fill_table(t, c, params + off, grads + off, exp_avg + off, exp_avg_sq + off, numel + off, lr ? lr + off : nullptr, &nb),
                        "dxmi_radam_step: empty tensor in the list");
-        hipLaunchKernelGGL(mt_adam_kernel<1>, dim3(nb), dim3(MT_BLOCK), 0, (hipStream_t)stream, t, sa, sr, grad_scale, found_inf, 0);
+        hipLaunchKernelGGL(mt_adam_kernel<1>, dim3(nb), dim3(MT_BLOCK), 0, (hipStream_t)stream, t, sa, sr, grad_scale, found_inf, 0,
+                           hyper, off);
     }
     DXMI_CHECK_LAUNCH("dxmi_radam_step");
     return DXMI_OK;
@@ -360,7 +415,18 @@ extern "C" int dxmi_gradnorm_clip(void* const* grads, const int64_t* numel, int3
     return DXMI_OK;
 }
 
+static int dropout_launch(const void* x, void* y, int64_t n, float p, uint32_t seed, const uint32_t* seed_dev, void* stream);
+
 extern "C" int dxmi_dropout_bf16(const void* x, void* y, int64_t n, float p, uint32_t seed, void* stream) {
+    return dropout_launch(x, y, n, p, seed, nullptr, stream);
+}
+
+extern "C" int dxmi_dropout_bf16_dev(const void* x, void* y, int64_t n, float p, const uint32_t* seed, void* stream) {
+    DXMI_CHECK_ARG(seed, "dxmi_dropout_bf16_dev: null seed pointer");
+    return dropout_launch(x, y, n, p, 0u, seed, stream);
+}
+
+static int dropout_launch(const void* x, void* y, int64_t n, float p, uint32_t seed, const uint32_t* seed_dev, void* stream) {
     DXMI_CHECK_ARG(x && y && n > 0 && n % 8 == 0 && n < ((int64_t)1 << 32), "dxmi_dropout_bf16: n (%lld) must be a multiple of 8 below 2^32", (long long)n);
     DXMI_CHECK_ARG(p >= 0.f && p < 1.f, "dxmi_dropout_bf16: p (%f) outside [0,1)", p);
     const uint32_t thresh = (uint32_t)((double)p * 16777216.0);
@@ -369,7 +435,7 @@ extern "C" int dxmi_dropout_bf16(const void* x, void* y, int64_t n, float p, uin
     int64_t blocks = (n8 + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(dropout_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, n8,
-                       seed, thresh, scale);
+                       seed, seed_dev, thresh, scale);
     DXMI_CHECK_LAUNCH("dxmi_dropout_bf16");
     return DXMI_OK;
 }

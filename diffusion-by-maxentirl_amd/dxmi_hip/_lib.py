@@ -104,9 +104,12 @@ SIGNATURES = {
     "dxmi_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dxmi_mt_blocks": (c_int64, [c_void_p, c_int]),
     "dxmi_adam_step": (c_int, [c_void_p] * 6 + [c_int] + [ctypes.c_double] * 4 + [c_void_p, c_int, c_void_p]),
+    "dxmi_adam_step_dev": (c_int, [c_void_p] * 5 + [c_int] + [ctypes.c_double] * 3 + [c_void_p, c_void_p, c_int, c_void_p]),
+    "dxmi_radam_step_dev": (c_int, [c_void_p] * 5 + [c_int] + [ctypes.c_double] * 3 + [c_void_p, c_void_p, c_void_p, c_void_p]),
     "dxmi_radam_step": (c_int, [c_void_p] * 6 + [c_int] + [ctypes.c_double] * 6 + [c_void_p, c_void_p, c_void_p]),
     "dxmi_gradnorm_clip": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     "dxmi_dropout_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint32, c_void_p]),
+    "dxmi_dropout_bf16_dev": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     "dxmi_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
 }
 

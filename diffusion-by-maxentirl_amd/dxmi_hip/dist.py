@@ -18,6 +18,8 @@ reference keeps it per rank too.
 import torch
 import torch.distributed as dist
 
+from . import graph as _graph
+
 
 def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -126,7 +128,7 @@ class FlatGradSync:
             torch._foreach_copy_([self.views[i] for i in todo], [self.params[i].grad for i in todo])
 
     def _on_grad(self, p):
-        if not self._active():
+        if not self._active() or _graph.capturing():      # (captured step: sync() packs and exchanges everything, see there)
             return
         i = self.index[id(p)]
         if self.ready[i]:             # second backward before sync(): the launched buckets hold stale sums
@@ -154,9 +156,48 @@ class FlatGradSync:
             self.handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True))
 
     # ------------------------------------------------------------------ after the backward
+    def _sync_captured(self, cap):
+        """sync() of a step that is being captured into hipGraphs (dxmi_hip/graph.py).  A collective is never captured: the
+        gradients are packed into the flat buffer by the graph segment that ends here, the bucket all-reduces run EAGERLY between
+        two graph launches (`cap.cut`: same collectives, same order, same element counts on every rank as the eager step), and
+        the segment that follows reads the means where the collective left them.  The overlap of the exchange with the backward
+        is given up on this path (one backward is one graph segment): at the per-rank batches where replay matters the exchange
+        is ~1 ms of a step that the host would otherwise stretch by tens of ms."""
+        n = len(self.params)
+        if any(p.grad is None for p in self.params):
+            raise RuntimeError("FlatGradSync inside a StepGraph capture: every trainable parameter must receive a gradient "
+                               "(the set of exchanged tensors is frozen into the graph)")
+        dev = self.params[0].grad.device
+        if self.flat is None or self.flat.device != dev:
+            raise RuntimeError("FlatGradSync inside a StepGraph capture: run one eager step first (the flat buffer is allocated there)")
+        flat, views = self._buffers(dev)
+        self._pack(list(range(n)))
+
+        def exchange():
+            backend = dist.get_backend()
+            handles = []
+            for start, end, _ in self.buckets:            # strict index order, as the eager path launches them
+                handles.append(dist.all_reduce(flat[start:end], op=dist.ReduceOp.AVG if backend == "nccl" else dist.ReduceOp.SUM,
+                                               async_op=True))
+            for h in handles:
+                h.wait()
+            if backend != "nccl":
+                flat.div_(dist.get_world_size())
+                self.flags.fill_(1.0)
+        cap.cut(exchange)
+        if self.alias_grads:
+            for i in range(n):
+                self.params[i].grad = views[i]
+        else:
+            torch._foreach_copy_([p.grad for p in self.params], views)
+        self._reset()
+
     def sync(self):
         if not self._active():
             return
+        cap = _graph.current()
+        if cap is not None:
+            return self._sync_captured(cap)
         missing = [i for i, p in enumerate(self.params) if p.grad is None]
         dev = next((p.grad.device for p in self.params if p.grad is not None), self.params[0].device)
         flat, views = self._buffers(dev)

@@ -10,6 +10,7 @@ import os
 import torch
 
 from . import _lib
+from . import graph as _graph
 from ._lib import ConvDesc, check, load
 
 ACT_NONE, ACT_LEAKY02, ACT_RELU, ACT_SILU = 0, 1, 2, 3
@@ -157,23 +158,54 @@ class PackedConvWeight:
 
 
 _PACK_BATCH = None
+_PACK_REC = None            # the outermost active pack_batch: hands out (and records) the destination buffers of the block
+PACK_GENERATION = 0         # bumped whenever a recorded packed-weight buffer is freshly allocated (dxmi_hip/graph.py re-captures)
 
 
 class pack_batch:
     """`with ops.pack_batch():` — every pack_conv_weight() inside allocates its destination and is DEFERRED; on exit all of
     them run as a few multi-tensor launches (dxmi_pack_conv_weights).  The nets' `_pack` / `_pack_t` use it: after an
-    optimiser step ~60 (CIFAR U-Net) to ~330 (ImageNet-64 EDM net) weights are refreshed."""
+    optimiser step ~60 (CIFAR U-Net) to ~330 (ImageNet-64 EDM net) weights are refreshed.
+    Every destination the block asks for (packed fragments, and the derived tensors of `pack_tensor`) is recorded in call order
+    in `.buffers`; `pack_batch(reuse=previous.buffers)` hands the SAME buffers out again in the same order: a re-pack after an
+    optimiser step (parameters updated in place) then rewrites the fragments where they are — the addresses a captured hipGraph
+    holds stay valid (dxmi_hip/graph.py).  A block that allocates anything fresh bumps PACK_GENERATION."""
+
+    def __init__(self, reuse=None):
+        self.reuse = list(reuse) if reuse is not None else None
 
     def __enter__(self):
-        global _PACK_BATCH
+        global _PACK_BATCH, _PACK_REC
         self.plan = None
+        self.nested = _PACK_REC is not None
         self.outer = _PACK_BATCH is not None or os.environ.get("DXMI_PACK_BATCH", "1") == "0"     # (=0: one launch per weight, A/B timing)
         if not self.outer:
             _PACK_BATCH = []
+        if not self.nested:
+            _PACK_REC = self
+            self.buffers, self.cursor, self.fresh = [], 0, False
         return self
 
+    def alloc(self, shape, dtype, device):
+        """Next destination of the block: the matching buffer of `reuse`, or a new one."""
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        if self.reuse is not None and self.cursor < len(self.reuse):
+            t = self.reuse[self.cursor]
+            if tuple(t.shape) != shape or t.dtype != dtype or t.device != torch.device(device):
+                raise _lib.DxmiError("pack_batch(reuse=...): the block asks for different buffers than the pack it replays")
+        else:
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self.fresh = True
+        self.cursor += 1
+        self.buffers.append(t)
+        return t
+
     def __exit__(self, *exc):
-        global _PACK_BATCH
+        global _PACK_BATCH, _PACK_REC, PACK_GENERATION
+        if not self.nested:
+            _PACK_REC = None
+            if self.fresh:
+                PACK_GENERATION += 1
         if self.outer:
             return False
         items, _PACK_BATCH = _PACK_BATCH, None
@@ -185,6 +217,14 @@ class pack_batch:
             self.plan = PackPlan(arr, items)
             self.plan.replay()
         return False
+
+
+def pack_tensor(shape, dtype, device):
+    """Destination for a DERIVED tensor of a weight pack (concatenated biases, zero-padded sources): recorded / reused by the
+    enclosing pack_batch like the packed fragments; a plain allocation outside one."""
+    if _PACK_REC is not None:
+        return _PACK_REC.alloc(shape, dtype, device)
+    return torch.empty(shape, dtype=dtype, device=device)
 
 
 PACK_PLAN_REPLAY = os.environ.get("DXMI_PACK_PLAN", "1") != "0"      # 0: rebuild descriptors and buffers at every re-pack (A/B timing)
@@ -215,7 +255,7 @@ def pack_conv_weight(w, transpose_flip=False, k27=False, out=None):
     lib = load()
     nbytes = lib.dxmi_packed_conv_weight_bytes(Cout, Cin, k, int(k27))
     if out is None:
-        out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        out = pack_tensor(nbytes, torch.uint8, w.device)
     assert out.numel() == nbytes
     if _PACK_BATCH is not None:
         _PACK_BATCH.append((w, out, Cout, Cin, k, transpose_flip, k27))      # (w is kept alive until the launch)
@@ -390,6 +430,10 @@ def _workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream): split-K partials, column sums, generic-GroupNorm partials.  Keyed by
     the launch stream so that work overlapped on a second stream never shares it; a buffer captured into a hipGraph is
     never re-allocated (growth during capture raises: size it with one eager call first)."""
+    if _graph.capturing():
+        # inside a StepGraph capture: a scratch tensor of its own from the graph's private pool (stream-ordered reuse is the
+        # allocator's business there; the address is fixed for every replay)
+        return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
     stream = torch.cuda.current_stream(device)
     key = (str(device), stream.cuda_stream)
     buf = _WS.get(key)
@@ -743,7 +787,7 @@ def pack_attn_proj_weight(w):
     _need_cuda(w)
     w2 = w.detach().float().reshape(w.shape[0], -1).contiguous()
     assert tuple(w2.shape) == (256, 256)
-    dst = torch.empty(256 * 256, dtype=torch.bfloat16, device=w.device)
+    dst = pack_tensor(256 * 256, torch.bfloat16, w.device)
     check(load().dxmi_pack_attn_proj_weight(_ptr(w2), _ptr(dst), _stream()), "dxmi_pack_attn_proj_weight")
     return dst
 
@@ -777,7 +821,7 @@ def attn_block_pack(wq, bq, wk, wv, bv, wproj, bproj, scale):
     bs = [t.detach().float().contiguous() for t in (bq, bv, bproj)]
     _need_cuda(*ws, *bs)
     assert all(tuple(w.shape) == (256, 256) for w in ws) and all(b.numel() == 256 for b in bs)
-    dst = torch.empty(int(load().dxmi_attn_block_packed_bytes()), dtype=torch.uint8, device=ws[0].device)
+    dst = pack_tensor(int(load().dxmi_attn_block_packed_bytes()), torch.uint8, ws[0].device)
     check(load().dxmi_attn_block_pack(_ptr(ws[0]), _ptr(bs[0]), _ptr(ws[1]), _ptr(ws[2]), _ptr(bs[1]), _ptr(ws[3]), _ptr(bs[2]),
                                       float(scale), _ptr(dst), _stream()), "dxmi_attn_block_pack")
     return dst
@@ -1002,9 +1046,11 @@ def _need_f32_dense(*lists):
 
 
 def adam_step(params, grads, exp_avgs, exp_avg_sqs, step_sizes, beta1, beta2, eps, bc2_sqrt, grad_scale=None,
-              write_back_grad=False, cache=None):
+              write_back_grad=False, cache=None, hyper=None):
     """One torch.optim.Adam update of every tensor in the lists (see dxmi_adam_step).  step_sizes: python floats
-    -(lr_i / (1 - beta1^t)).  cache: dict reused across calls for the pointer arrays of params / moments (stable)."""
+    -(lr_i / (1 - beta1^t)).  cache: dict reused across calls for the pointer arrays of params / moments (stable).
+    hyper: DEVICE fp32 [1 + n] = (bc2_sqrt, step sizes) instead of the two host arguments (dxmi_adam_step_dev: a step that is
+    replayed from a hipGraph)."""
     _need_f32_dense(params, grads, exp_avgs, exp_avg_sqs)
     n = len(params)
     if cache is None or cache.get("n") != n:
@@ -1012,18 +1058,24 @@ def adam_step(params, grads, exp_avgs, exp_avg_sqs, step_sizes, beta1, beta2, ep
         if cache is not None:
             cache.update(c)
         cache = c
-    ss = (ctypes.c_float * n)(*step_sizes)
     if "elems" not in cache:
         cache["elems"] = sum(p.numel() for p in params)
     garr = _ptr_array(grads)
+    if hyper is not None:
+        assert hyper.is_cuda and hyper.dtype == torch.float32 and hyper.numel() == n + 1
+        check(load().dxmi_adam_step_dev(cache["p"], garr, cache["m"], cache["v"], cache["numel"], n, beta1, beta2, eps, _ptr(hyper),
+                                        _ptr(grad_scale), int(write_back_grad), _stream()), "dxmi_adam_step_dev")
+        return
+    ss = (ctypes.c_float * n)(*step_sizes)
     _prof("optimizer", "adam", 0.0, 28.0 * cache["elems"], lambda: check(
         load().dxmi_adam_step(cache["p"], garr, cache["m"], cache["v"], cache["numel"], ss, n, beta1, beta2, eps,
                               bc2_sqrt, _ptr(grad_scale), int(write_back_grad), _stream()), "dxmi_adam_step"))
 
 
 def radam_step(params, grads, exp_avgs, exp_avg_sqs, lrs, beta1, beta2, eps, bc1, bc2_sqrt, rect, grad_scale=None,
-               found_inf=None, cache=None):
-    """One torch.optim.RAdam update (see dxmi_radam_step); rect < 0 selects the un-rectified branch."""
+               found_inf=None, cache=None, hyper=None):
+    """One torch.optim.RAdam update (see dxmi_radam_step); rect < 0 selects the un-rectified branch.
+    hyper: DEVICE fp32 [3 + n] = (fp32(1 / bc1), bc2_sqrt, rect, lrs) instead of the host arguments (dxmi_radam_step_dev)."""
     _need_f32_dense(params, grads, exp_avgs, exp_avg_sqs)
     n = len(params)
     if cache is None or cache.get("n") != n:
@@ -1031,6 +1083,11 @@ def radam_step(params, grads, exp_avgs, exp_avg_sqs, lrs, beta1, beta2, eps, bc1
         if cache is not None:
             cache.update(c)
         cache = c
+    if hyper is not None:
+        assert hyper.is_cuda and hyper.dtype == torch.float32 and hyper.numel() == n + 3
+        check(load().dxmi_radam_step_dev(cache["p"], _ptr_array(grads), cache["m"], cache["v"], cache["numel"], n, beta1, beta2, eps,
+                                         _ptr(hyper), _ptr(grad_scale), _ptr(found_inf), _stream()), "dxmi_radam_step_dev")
+        return
     lr = (ctypes.c_float * n)(*lrs)
     check(load().dxmi_radam_step(cache["p"], _ptr_array(grads), cache["m"], cache["v"], cache["numel"], lr, n, beta1, beta2, eps,
                                  bc1, bc2_sqrt, rect, _ptr(grad_scale), _ptr(found_inf), _stream()), "dxmi_radam_step")
@@ -1061,11 +1118,16 @@ def clip_grad_norm_(parameters, max_norm):
 
 
 def dropout(x, p, seed, out=None):
-    """Counter-hash dropout of a bf16 tensor (see dxmi_dropout_bf16); call again with the same seed on the gradient."""
+    """Counter-hash dropout of a bf16 tensor (see dxmi_dropout_bf16); call again with the same seed on the gradient.
+    seed: python int, or a DEVICE int32 tensor holding the 32-bit seed (dxmi_dropout_bf16_dev: hipGraph-replayed steps)."""
     _need_cuda(x, out)
     assert x.dtype == torch.bfloat16 and x.is_contiguous()
     if out is None:
         out = torch.empty_like(x)
+    if torch.is_tensor(seed):
+        assert seed.is_cuda and seed.dtype == torch.int32 and seed.numel() == 1
+        check(load().dxmi_dropout_bf16_dev(_ptr(x), _ptr(out), x.numel(), float(p), _ptr(seed), _stream()), "dxmi_dropout_bf16_dev")
+        return out
     check(load().dxmi_dropout_bf16(_ptr(x), _ptr(out), x.numel(), float(p), int(seed) & 0xFFFFFFFF, _stream()), "dxmi_dropout_bf16")
     return out
 

@@ -11,6 +11,7 @@ import math
 
 import torch
 
+from . import graph as _graph
 from . import ops
 from ._lib import DxmiError
 
@@ -55,10 +56,10 @@ def _bump_versions(params):
 class _Batch:
     """Tensors of one fused launch series: equal betas / eps / step count (bias corrections are per launch)."""
 
-    __slots__ = ("params", "grads", "ms", "vs", "lrs")
+    __slots__ = ("params", "grads", "ms", "vs", "lrs", "groups")
 
     def __init__(self):
-        self.params, self.grads, self.ms, self.vs, self.lrs = [], [], [], [], []
+        self.params, self.grads, self.ms, self.vs, self.lrs, self.groups = [], [], [], [], [], []
 
 
 def _batches(opt, name):
@@ -81,7 +82,23 @@ def _batches(opt, name):
             b.ms.append(st["exp_avg"])
             b.vs.append(st["exp_avg_sq"])
             b.lrs.append(group["lr"])
+            b.groups.append(group)
     return out
+
+
+def _replay_counters(opt, b):
+    """Host side of a captured optimiser step at REPLAY time: the step counters of the batch's tensors advance as `_batches()`
+    advances them in an eager step (the capture pass itself has already been counted there); returns the new count."""
+    steps = [opt.state[p]["step"] for p in b.params]
+    first = [True]
+
+    def advance():
+        if first[0]:
+            first[0] = False
+        else:
+            torch._foreach_add_(steps, 1)
+        return float(steps[0])
+    return advance
 
 
 def _cache_for(opt, key, b):
@@ -100,11 +117,24 @@ class Adam(_FusedBase, torch.optim.Adam):
     def step(self, closure=None, grad_scale=None):
         """grad_scale: optional device scalar multiplied into every gradient (e.g. gradnorm_clip(...)[1:2])."""
         assert closure is None
+        cap = _graph.current()
         for key, b in _batches(self, "Adam").items():
             b1, b2, eps, t = key
-            steps = [-(lr / (1 - b1 ** t)) for lr in b.lrs]            # step_size, in double as torch forms it
-            ops.adam_step(b.params, b.grads, b.ms, b.vs, steps, b1, b2, eps, (1 - b2 ** t) ** 0.5, grad_scale=grad_scale,
-                          cache=_cache_for(self, key, b))
+            if cap is None:
+                steps = [-(lr / (1 - b1 ** t)) for lr in b.lrs]            # step_size, in double as torch forms it
+                ops.adam_step(b.params, b.grads, b.ms, b.vs, steps, b1, b2, eps, (1 - b2 ** t) ** 0.5, grad_scale=grad_scale,
+                              cache=_cache_for(self, key, b))
+            else:
+                # captured into a hipGraph (dxmi_hip/graph.py): the step-dependent scalars are a HOST INPUT of the graph — formed
+                # here, per replay, by the same double arithmetic (the learning rates are read live: schedulers keep working)
+                advance, groups = _replay_counters(self, b), list(b.groups)
+
+                def hyper_values(advance=advance, groups=groups, b1=b1, b2=b2):
+                    tt = advance()
+                    return [(1 - b2 ** tt) ** 0.5] + [-(g["lr"] / (1 - b1 ** tt)) for g in groups]
+                hyper = cap.host_input(torch.float32, len(b.params) + 1, hyper_values)
+                ops.adam_step(b.params, b.grads, b.ms, b.vs, None, b1, b2, eps, None, grad_scale=grad_scale,
+                              cache=_cache_for(self, key, b), hyper=hyper)
             _bump_versions(b.params)
         return None
 

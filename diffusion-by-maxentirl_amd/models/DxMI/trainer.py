@@ -21,6 +21,7 @@ Networks run through their HIP autograd functions (models/value_train.py, unet_s
 import torch
 import torch.nn.functional as F
 
+from dxmi_hip import graph as _graph
 from dxmi_hip import ops
 from ..diffusion import extract, make_beta_schedule
 from .replay import TransitionRing, buffer_gather, buffer_rows
@@ -54,6 +55,16 @@ def _children_disagree(module, training, last):
         if m.training != training:
             return True
     return False
+
+
+def _pack_modules(net):
+    """Sub-modules of `net` that keep packed bf16 weight sets (objects with refresh_packs / prepare_capture)."""
+    mods = net.modules() if hasattr(net, "modules") else [net]
+    out = [m for m in mods if hasattr(m, "refresh_packs") and hasattr(m, "prepare_capture")]
+    inner = getattr(net, "net", None)          # OpenAIDiffusion: a plain object holding the U-Net
+    if not out and inner is not None and hasattr(inner, "modules"):
+        out = [m for m in inner.modules() if hasattr(m, "refresh_packs") and hasattr(m, "prepare_capture")]
+    return out
 
 
 def reset_buffer(device, ring=None):
@@ -110,6 +121,46 @@ class DxMI_Trainer:
         self.value_grad_clip = value_grad_clip
         self.skip_sampler_tau = skip_sampler_tau
 
+    # ------------------------------------------------------------------ hipGraph replay of the two updates (dxmi_hip/graph.py)
+    use_graphs = False      # set True (train_cifar10.py does): update_f_v / update_sampler on a TransitionRing replay as hipGraphs
+
+    def _step_graph(self, name, state_dict, extra_key, fn, nets):
+        """The StepGraph of one update for one (ring, fill level, shapes) — or None when the call cannot be replayed: graphs off,
+        a reference-style dict buffer (row counts grow with every append), or a capture already running (a caller capturing a
+        larger step)."""
+        if not self.use_graphs or not isinstance(state_dict, TransitionRing) or _graph.capturing():
+            return None
+        graphs = self.__dict__.setdefault("_graphs", {})
+        key = (name, id(state_dict), state_dict.filled) + tuple(extra_key)
+        g = graphs.get(key)
+        if g is None:
+            device = state_dict.device
+            if torch.is_tensor(getattr(self, "betas_for_q", None)) and self.betas_for_q.device != device:
+                self.betas_for_q = self.betas_for_q.to(device)       # q-betas are indexed on the device inside the step
+            mods = [m for net in nets if net is not None for m in _pack_modules(net)]
+            g = graphs[key] = _graph.StepGraph(fn, device, modules=mods, name=f"{type(self).__name__}.{name}")
+        return g
+
+    @staticmethod
+    def _randperm(n, device):
+        """torch.randperm(n) from the CPU generator, as the reference draws it (:271, :352), on the device.  Inside a StepGraph
+        capture it is a host input of the graph: drawn per replay from the same generator, uploaded with the other host inputs."""
+        cap = _graph.current()
+        if cap is None:
+            return torch.randperm(n).to(device)
+        return cap.host_input(torch.int64, n, lambda: torch.randperm(n))
+
+    def _set_betas_for_q(self, new):
+        """In place where possible: a captured step reads and writes ONE persistent tensor (a re-bound attribute would leave the
+        graph updating a buffer nobody reads)."""
+        cur = self.betas_for_q
+        if torch.is_tensor(cur) and cur.device == new.device and cur.shape == new.shape and cur.dtype == new.dtype:
+            cur.copy_(new)
+        else:
+            if _graph.capturing():
+                raise RuntimeError("betas_for_q changes device / shape inside a StepGraph capture")
+            self.betas_for_q = new.detach()
+
     def set_models(self, f, v, sampler, optimizer, optimizer_fstar, optimizer_v):
         """reference :136-161."""
         self.f, self.v, self.sampler = f, v, sampler
@@ -143,7 +194,9 @@ class DxMI_Trainer:
         device = d_sample["sample"].device
         samples = torch.stack(d_sample["l_sample"])
         diff = ((samples[1:] - samples[:-1]) ** 2).view(samples.shape[0] - 1, -1).mean(dim=1).flip(0).to(device)
-        self.betas_for_q = (self.betas_for_q.to(device) * self.adavelreg + (1 - self.adavelreg) * diff).detach()
+        if self.betas_for_q.device != device:
+            self.betas_for_q = self.betas_for_q.to(device)
+        self._set_betas_for_q((self.betas_for_q * self.adavelreg + (1 - self.adavelreg) * diff).detach())
 
     def _time_cost_terms(self, timestep):
         extra = 0.
@@ -157,6 +210,17 @@ class DxMI_Trainer:
     # ------------------------------------------------------------------ value / energy update
     def update_f_v(self, img, d_sample, state_dict):
         """reference :230-346."""
+        g = None
+        if isinstance(state_dict, TransitionRing) and d_sample.get("_ring_slot") == (id(state_dict), state_dict.filled - 1) \
+                and len(img) == self.batchsize:
+            # the trajectory IS the ring slot: every tensor of the step but `img` has a fixed address -> replayable
+            nets = [self.v] + ([self.sampler] if self.value_resample else [])
+            g = self._step_graph("update_f_v", state_dict, tuple(img.shape),
+                                 lambda im, d=d_sample, sd=state_dict: self._update_f_v(im, d, sd), nets)
+        keys, vals = self._update_f_v(img, d_sample, state_dict) if g is None else g(img.detach())
+        return dict(zip(keys, vals.tolist()))          # the one device -> host synchronisation of the call
+
+    def _update_f_v(self, img, d_sample, state_dict):
         x_seq = d_sample["l_sample"]
         if self.adavelreg is not None:
             self.update_adaptive_vel_reg(d_sample)
@@ -181,8 +245,8 @@ class DxMI_Trainer:
         d_running_cost, d_value = {}, {}
 
         # TD value estimation over the last T*B buffered transitions
-        permutation = torch.randperm(batchsize * n_steps)                     # CPU generator, as the reference
-        indices = (permutation + (buffer_rows(state_dict) - batchsize * n_steps)).to(device)
+        permutation = self._randperm(batchsize * n_steps, device)            # CPU generator, as the reference
+        indices = permutation + (buffer_rows(state_dict) - batchsize * n_steps)
         rows_all, ts_all = self._td_rows(state_dict, indices, n_steps, batchsize)
         need_entropy = bool(self.entropy_in_value or self.entropy_in_value == 0)
         running_cost = v_loss = None
@@ -242,20 +306,26 @@ class DxMI_Trainer:
         if self.adavelreg is not None:
             for t, beta in enumerate(self.betas_for_q):
                 logs[f"adavelreg/beta{t}_"] = beta
-        return self._to_floats(logs)
+        return self._stack_logs(logs)
 
     # ------------------------------------------------------------------ policy update
     def update_sampler(self, state_dict, n_generator, d_sample=None):
         """reference :348-408."""
+        g = self._step_graph("update_sampler", state_dict, (n_generator,),
+                             lambda sd=state_dict: self._update_sampler(sd, n_generator), [self.sampler, self.v])
+        keys, vals = self._update_sampler(state_dict, n_generator) if g is None else g()
+        return dict(zip(keys, vals.tolist()))
+
+    def _update_sampler(self, state_dict, n_generator):
         _set_mode(self.v, False)
         _set_mode(self.sampler, True)
-        permutation = torch.randperm(buffer_rows(state_dict))
+        device = state_dict.device if isinstance(state_dict, TransitionRing) else state_dict["state"].device
+        permutation = self._randperm(buffer_rows(state_dict), device)
         batchsize = self.batchsize
         n_data = min(len(permutation), batchsize * n_generator)
-        device = state_dict.device if isinstance(state_dict, TransitionRing) else state_dict["state"].device
         for m in range(0, n_data, batchsize):
             self.optimizer.zero_grad()
-            indices = permutation[m:m + batchsize].to(device)
+            indices = permutation[m:m + batchsize]
             state = buffer_gather(state_dict, "state", indices)
             t = buffer_gather(state_dict, "timestep", indices)
             d_step = self.sampler.sample_step(state, t)
@@ -277,7 +347,7 @@ class DxMI_Trainer:
             sigma = torch.exp(net.log_betas.detach())
             for t in range(len(sigma)):
                 logs[f"sigma/sigma_{t}_"] = sigma[t]
-        return self._to_floats(logs)
+        return self._stack_logs(logs)
 
     # ------------------------------------------------------------------ value-guided sampling
     def sample_guidance(self, n_sample, device, x0=None, guidance_scale=None, t_select=None, noise=None):
@@ -359,12 +429,17 @@ class DxMI_Trainer:
         return rows, [state_dict["timestep"][r] for r in rows]
 
     @staticmethod
-    def _to_floats(logs):
-        """One device->host synchronisation for the whole dictionary."""
+    def _stack_logs(logs):
+        """(keys, fp32 device vector of the values): no synchronisation — the caller reads it back once."""
         keys = list(logs.keys())
         dev = next(v.device for v in logs.values() if torch.is_tensor(v))
-        vals = torch.stack([torch.as_tensor(logs[k], dtype=torch.float32, device=dev).reshape(()) for k in keys]).tolist()
-        return dict(zip(keys, vals))
+        return keys, torch.stack([torch.as_tensor(logs[k], dtype=torch.float32, device=dev).reshape(()) for k in keys])
+
+    @classmethod
+    def _to_floats(cls, logs):
+        """One device->host synchronisation for the whole dictionary."""
+        keys, vals = cls._stack_logs(logs)
+        return dict(zip(keys, vals.tolist()))
 
 
 class DxMI_Trainer_Cond(DxMI_Trainer):

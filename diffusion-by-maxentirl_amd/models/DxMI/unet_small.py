@@ -152,6 +152,7 @@ class Model(nn.Module):
         self.conv_out = _conv(block_in, out_ch, 3, 1, 1)
         self._packed = None
         self._packed_key = None
+        self._pack_bufs = None
         self.dropout_seed = None          # base seed of the dropout hash (None: torch.initial_seed() at first use)
         self.dropout_seeds_used = []      # seeds of the most recent training forward, in _resblocks() call order
         self._dropout_calls = 0
@@ -182,17 +183,20 @@ class Model(nn.Module):
         # torch bumps _version on every in-place update (optimizer.step, load_state_dict, .to())
         return tuple((p.data_ptr(), p._version) for p in ops.fast_parameters(self))
 
-    def _pack(self):
-        """(Re)build the bf16 MFMA weight fragments from the fp32 master parameters."""
-        with ops.pack_batch():            # every pack below runs in a few multi-tensor launches
+    def _pack(self, reuse=None):
+        """(Re)build the bf16 MFMA weight fragments from the fp32 master parameters.  reuse: the buffers of the previous pack
+        (parameters updated in place): the fragments are rewritten where they are (ops.pack_batch)."""
+        with ops.pack_batch(reuse=reuse) as pb:            # every pack below runs in a few multi-tensor launches
             pk = {}
             dev = self.conv_in.weight.device
+            f32 = torch.float32
             pk["dense0"] = ops.pack_conv_weight(self.temb.dense[0].weight)
             pk["dense1"] = ops.pack_conv_weight(self.temb.dense[1].weight)
             blocks = list(self._resblocks())
             # every temb_proj of the net in ONE [sum(Cout), temb_ch] operator (reference :123)
             pk["tproj"] = ops.pack_conv_weight(torch.cat([b.temb_proj.weight for b in blocks], 0))
-            pk["tproj_bias"] = torch.cat([b.temb_proj.bias for b in blocks], 0).detach().float().contiguous()
+            pk["tproj_bias"] = torch.cat([b.temb_proj.bias.detach() for b in blocks], 0,
+                                         out=ops.pack_tensor(sum(b.out_channels for b in blocks), f32, dev))
             off = 0
             for b in blocks:
                 pk[id(b), "toff"] = off
@@ -205,7 +209,8 @@ class Model(nn.Module):
             for m in self.modules():
                 if isinstance(m, AttnBlock):
                     pk[id(m), "qkv"] = ops.pack_conv_weight(torch.cat([m.q.weight, m.k.weight, m.v.weight], 0))
-                    pk[id(m), "qkv_bias"] = torch.cat([m.q.bias, m.k.bias, m.v.bias], 0).detach().float().contiguous()
+                    pk[id(m), "qkv_bias"] = torch.cat([m.q.bias.detach(), m.k.bias.detach(), m.v.bias.detach()], 0,
+                                                      out=ops.pack_tensor(3 * m.in_channels, f32, dev))
                     pk[id(m), "proj"] = ops.pack_conv_weight(m.proj_out.weight)
                     if m.in_channels == 256:      # the 16x16 blocks: proj_out fused behind the attention (ops.attention_proj)
                         pk[id(m), "proj_attn"] = ops.pack_attn_proj_weight(m.proj_out.weight)
@@ -217,13 +222,36 @@ class Model(nn.Module):
             pk["conv_in"] = ops.pack_conv_weight(self.conv_in.weight, k27=(self.in_channels == 3))
             pk["conv_out"] = ops.pack_conv_weight(self.conv_out.weight)
         assert dev.type == "cuda"
+        self._pack_bufs = pb.buffers
         return pk
+
+    @staticmethod
+    def _same_storage(key, old_key):
+        return old_key is not None and len(key) == len(old_key) and all(a[0] == b[0] for a, b in zip(key, old_key))
 
     def packed(self):
         key = self._param_key()
         if self._packed is None or key != self._packed_key:
-            self._packed, self._packed_key = self._pack(), key
+            # parameters updated in place (an optimiser step): the same buffers are rewritten, so every address a captured
+            # hipGraph holds stays valid (dxmi_hip/graph.py); moved parameters (.to(), a new tensor): fresh buffers
+            reuse = self._pack_bufs if (self._packed is not None and self._same_storage(key, self._packed_key)) else None
+            self._packed, self._packed_key = self._pack(reuse=reuse), key
         return self._packed
+
+    def refresh_packs(self):
+        """Bring every packed-weight set of the net that exists up to date with the parameters (no-op when they are)."""
+        self.packed()
+        if getattr(self, "_packed_t", None) is not None:
+            from .unet_small_train import _pack_t
+            _pack_t(self)
+
+    def prepare_capture(self):
+        """Before a StepGraph capture: on-demand entries of the transposed set (packed by a backward when first needed) are
+        dropped so that the captured step packs them itself, then everything else is refreshed eagerly."""
+        if getattr(self, "_packed_t", None) is not None:
+            for k in [k for k in self._packed_t if k not in self._packed_t_planned]:
+                del self._packed_t[k]
+        self.refresh_packs()
 
     # ------------------------------------------------------------------ fused blocks
     # Activations on maps of >= STREAM_GN_MIN_HW pixels travel as (tensor, BlockStats): the producing conv's epilogue writes the

@@ -18,6 +18,7 @@ Parameter gradients are returned in `net.parameters()` order as fp32 tensors.
 import torch
 import torch.nn.functional as F
 
+from dxmi_hip import graph as _graph
 from dxmi_hip import ops
 
 
@@ -28,7 +29,9 @@ def _pack_t(net):
         return net._packed_t
     from .unet_small import AttnBlock, Downsample, Upsample
     pk = {}
-    with ops.pack_batch():            # a few multi-tensor launches instead of one per layer
+    # parameters updated in place: the previous set's buffers are rewritten (addresses held by a captured hipGraph stay valid)
+    reuse = net._pack_t_bufs if (getattr(net, "_packed_t", None) is not None and net._same_storage(key, net._packed_t_key)) else None
+    with ops.pack_batch(reuse=reuse) as pb:            # a few multi-tensor launches instead of one per layer
         for b in net._resblocks():
             pk[id(b), "conv1"] = ops.pack_conv_weight(b.conv1.weight, transpose_flip=True)
             pk[id(b), "conv2"] = ops.pack_conv_weight(b.conv2.weight, transpose_flip=True)
@@ -45,6 +48,8 @@ def _pack_t(net):
         wpad = torch.zeros((64,) + tuple(w.shape[1:]), dtype=torch.float32, device=w.device)
         wpad[: w.shape[0]] = w.detach()
         pk["conv_out"] = ops.pack_conv_weight(wpad, transpose_flip=True)
+    net._pack_t_bufs = pb.buffers
+    net._packed_t_planned = set(pk.keys())       # everything else is packed on demand by a backward and dropped at the next re-pack
     net._packed_t, net._packed_t_key = pk, key
     return pk
 
@@ -70,7 +75,11 @@ class _UNetFn(torch.autograd.Function):
             mask = None
             if training and p_drop > 0:
                 # nn.Dropout (unet_small.py:129) as a counter-hash kernel: the backward regenerates the mask from the seed
-                mask = net._next_dropout_seed()
+                cap = _graph.current()
+                if cap is None:
+                    mask = net._next_dropout_seed()
+                else:       # captured step: the seed is a host input of the graph, drawn per replay from the same counter hash
+                    mask = cap.host_input(torch.int32, 1, lambda: [net._next_dropout_seed()])
                 a2 = ops.dropout(a2, p_drop, mask)
             if b.in_channels != b.out_channels:
                 sc_mod = b.conv_shortcut if b.use_conv_shortcut else b.nin_shortcut

@@ -20,6 +20,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from dxmi_hip import graph as _graph
 from dxmi_hip import ops
 from dxmi_hip._lib import DxmiError
 from ..modules import process_single_t
@@ -172,6 +173,8 @@ class VARSampler(nn.Module):
         if self.trainable_beta == "fix_last":
             self.net.register_buffer("std", std)
         self._tcache = {}
+        self.use_graph = False      # sample(): replay the T-step loop of a fixed (batch, device, destination) as one hipGraph
+        self._graphs = {}
 
     def init_schedule(self):
         """reference :326-355."""
@@ -263,6 +266,20 @@ class VARSampler(nn.Module):
             raise DxmiError("VARSampler.sample runs only on the HIP device path (device must be cuda:N)")
         if enable_grad:
             raise NotImplementedError("enable_grad=True (fresh_sample_grad) is not used by the DxMI configs")
+        if self.use_graph and noise is None and not _graph.capturing():
+            # hipGraph replay (dxmi_hip/graph.py): one graph per (batch, destination); the first call of a key runs eagerly, the
+            # second is captured.  Without `out=` the returned tensors are static: the next call with the same key overwrites them.
+            if device.index is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+            key = (n_sample, device.index, None if out is None else (id(out["ring"]), out["slot"]))
+            g = self._graphs.get(key)
+            if g is None:
+                g = self._graphs[key] = _graph.StepGraph(lambda: self._sample(n_sample, device, None, out), device,
+                                                         modules=[self._bare_net()], name=f"VARSampler.sample{key}")
+            return g()
+        return self._sample(n_sample, device, noise, out)
+
+    def _sample(self, n_sample, device, noise, out):
         shape = tuple(self.sample_shape)
         size = (n_sample,) + shape
         T = self.n_timesteps

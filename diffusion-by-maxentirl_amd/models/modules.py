@@ -76,35 +76,52 @@ class IGEBMEncoderV2(nn.Module):
         self.learn_out_scale = learn_out_scale
         if learn_out_scale:
             self.out_scale = nn.Linear(1, 1, bias=True)
-        self._packed, self._packed_key = None, None
-        self._packed_t, self._packed_t_key = None, None
+        self._packed, self._packed_key, self._pack_bufs = None, None, None
+        self._packed_t, self._packed_t_key, self._pack_t_bufs = None, None, None
 
     # ---- bf16 weight fragments, rebuilt when a parameter's version changes
     def packed(self):
         key = tuple((p.data_ptr(), p._version) for p in ops.fast_parameters(self))
         if self._packed is None or key != self._packed_key:
-            with ops.pack_batch():             # one multi-tensor launch for the net's weights
+            # parameters updated in place: the same buffers are rewritten (addresses held by a captured hipGraph stay valid)
+            reuse = self._pack_bufs if (self._packed is not None and self._same_storage(key, self._packed_key)) else None
+            with ops.pack_batch(reuse=reuse) as pb:             # one multi-tensor launch for the net's weights
                 pk = {"conv1": ops.pack_conv_weight(self.conv1.weight, k27=(self.in_chan == 3))}
                 for i, b in enumerate(self.blocks):
                     pk[i, "conv1"] = ops.pack_conv_weight(b.conv1.weight)
                     pk[i, "conv2"] = ops.pack_conv_weight(b.conv2.weight)
                     if b.skip is not None:
                         pk[i, "skip"] = ops.pack_conv_weight(b.skip[0].weight)
-            self._packed, self._packed_key = pk, key
+            self._packed, self._packed_key, self._pack_bufs = pk, key, pb.buffers
         return self._packed
+
+    @staticmethod
+    def _same_storage(key, old_key):
+        return old_key is not None and len(key) == len(old_key) and all(a[0] == b[0] for a, b in zip(key, old_key))
+
+    def refresh_packs(self):
+        """Bring the packed-weight sets that exist up to date with the parameters (no-op when they are)."""
+        self.packed()
+        if self._packed_t is not None:
+            self.packed_transposed()
+
+    def prepare_capture(self):
+        """Before a StepGraph capture (dxmi_hip/graph.py)."""
+        self.refresh_packs()
 
     def packed_transposed(self):
         """Transpose-flipped fragments: the data-gradient operators of the block convs."""
         key = tuple((p.data_ptr(), p._version) for p in ops.fast_parameters(self))
         if self._packed_t is None or key != self._packed_t_key:
             pk = {}
-            with ops.pack_batch():
+            reuse = self._pack_t_bufs if (self._packed_t is not None and self._same_storage(key, self._packed_t_key)) else None
+            with ops.pack_batch(reuse=reuse) as pb:
                 for i, b in enumerate(self.blocks):
                     pk[i, "conv1"] = ops.pack_conv_weight(b.conv1.weight, transpose_flip=True)
                     pk[i, "conv2"] = ops.pack_conv_weight(b.conv2.weight, transpose_flip=True)
                     if b.skip is not None:
                         pk[i, "skip"] = ops.pack_conv_weight(b.skip[0].weight, transpose_flip=True)
-            self._packed_t, self._packed_t_key = pk, key
+            self._packed_t, self._packed_t_key, self._pack_t_bufs = pk, key, pb.buffers
         return self._packed_t
 
     def train(self, mode=True):

@@ -441,6 +441,13 @@ int dxmi_adam_step(void* const* params, void* const* grads, void* const* exp_avg
                    const int64_t* numel, const float* step_size, int32_t count, double beta1, double beta2,
                    double eps, double bc2_sqrt, const float* grad_scale, int32_t write_back_grad, void* stream);
 
+/* The same update for a step that is REPLAYED from a hipGraph (dxmi_hip/graph.py: kernel arguments are frozen at capture, the
+ * step count is not): the step-dependent scalars are read from DEVICE memory, hyper = fp32 [bc2_sqrt, step_size[0..count)],
+ * formed by the host exactly as for dxmi_adam_step and uploaded before every replay.  Bit-identical results. */
+int dxmi_adam_step_dev(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                       const int64_t* numel, int32_t count, double beta1, double beta2, double eps, const float* hyper,
+                       const float* grad_scale, int32_t write_back_grad, void* stream);
+
 /* torch.optim.RAdam.step() (MixedPrecisionTrainer.optimize, models/cm/fp16_util.py:204-223; optimiser built at
  * train_image_large.py:153-160), arithmetic of torch/optim/radam.py _single_tensor_radam:
  *   p -= ((m/bc1) * lr_i) * (bc2_sqrt / (sqrt(v) + eps)) * rect      (rect < 0: p -= (m/bc1) * lr_i, rho_t <= 5)
@@ -450,6 +457,11 @@ int dxmi_radam_step(void* const* params, void* const* grads, void* const* exp_av
                     const int64_t* numel, const float* lr, int32_t count, double beta1, double beta2, double eps,
                     double bc1, double bc2_sqrt, double rect, const float* grad_scale, const float* found_inf,
                     void* stream);
+
+/* dxmi_radam_step for a hipGraph-replayed step: hyper = DEVICE fp32 [fp32(1/bc1), bc2_sqrt, rect, lr[0..count)]. */
+int dxmi_radam_step_dev(void* const* params, void* const* grads, void* const* exp_avg, void* const* exp_avg_sq,
+                        const int64_t* numel, int32_t count, double beta1, double beta2, double eps, const float* hyper,
+                        const float* grad_scale, const float* found_inf, void* stream);
 
 /* torch.nn.utils.clip_grad_norm_(params, max_norm) (trainer.py:388, :666-667; also MixedPrecisionTrainer._compute_norms
  * fp16_util.py:232-240 with max_norm <= 0 = "norm only"): out3[0] = global L2 norm, out3[1] = min(1, max_norm/(norm+1e-6)),
@@ -462,6 +474,9 @@ int dxmi_gradnorm_clip(void* const* grads, const int64_t* numel, int32_t count, 
  * keep(i) = (mix32(i ^ seed) >> 8) >= p*2^24, mix32 = the 32-bit finaliser x^=x>>16; x*=0x7feb352d; x^=x>>15;
  * x*=0x846ca68b; x^=x>>16.  The backward pass calls it again on the gradient with the same seed (no stored mask). */
 int dxmi_dropout_bf16(const void* x, void* y, int64_t n, float p, uint32_t seed, void* stream);
+/* ... with the seed read from DEVICE memory (a dropout site of a hipGraph-replayed step: the host uploads a fresh seed
+ * before every replay). */
+int dxmi_dropout_bf16_dev(const void* x, void* y, int64_t n, float p, const uint32_t* seed, void* stream);
 
 /* Replay-buffer row gather (INT path; trainer.py:278-289 `state_dict[key][indices][train_indices]`, :357-359):
  * dst[r] = src[idx[r]], rows of row_bytes (multiple of 4), idx int64 on the device, negative indices wrap; an index

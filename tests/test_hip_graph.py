@@ -1,0 +1,180 @@
+"""hipGraph replay of the DxMI steps (dxmi_hip/graph.py) against the eager HIP path on the same seeds: the captured step must
+walk the same sequence — device RNG, CPU randperm, dropout seeds, Adam step counts — and give the same numbers."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+UNET_KW = dict(ch=128, out_ch=3, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=[16], dropout=0.1,
+               in_channels=3, resolution=32)
+
+
+def _models(T, seed=0, device="cuda:0"):
+    from models.DxMI.unet_small import Model
+    from models.DxMI.var_sampler import VARSampler
+    from models.modules import IGEBMEncoderV2
+    from models.value import TimeIndependentValue
+    from oracle.weights import formula_tensor
+    torch.manual_seed(seed)
+    net = Model(**UNET_KW)
+    sampler = VARSampler(net, T, [3, 32, 32], trainable_beta="fix_last")
+    net.load_state_dict({k: (v if k in ("log_betas", "std") else formula_tensor(k, v.shape)) for k, v in net.state_dict().items()})
+    v = TimeIndependentValue(IGEBMEncoderV2(in_chan=3, out_chan=1, use_spectral_norm=False, keepdim=False,
+                                            out_activation="linear", avg_pool_dim=1, learn_out_scale=True, nh=128))
+    v.load_state_dict({k: formula_tensor(k, t.shape) for k, t in v.state_dict().items()})
+    return net, sampler.to(device), v.to(device)
+
+
+def test_sampler_graph_matches_eager():
+    """sample() replayed from a hipGraph draws the noise an eager call draws (torch's Philox offset advances per replay) and
+    returns the same trajectory, bit for bit; a replay does not repeat the previous call's images."""
+    T, B = 4, 8
+    outs = {}
+    for mode in ("eager", "graph"):
+        _, s, _ = _models(T)
+        s.eval()
+        s.use_graph = mode == "graph"
+        torch.cuda.manual_seed(77)
+        outs[mode] = [{k: (torch.stack(v).clone() if isinstance(v, list) else v.clone())
+                       for k, v in s.sample(B, device="cuda:0").items() if k in ("sample", "l_sample", "logp", "mean", "sigma")}
+                      for _ in range(4)]
+        if mode == "graph":
+            g = next(iter(s._graphs.values()))
+            assert g.replays == 2 and len(g.segments) == 1
+    for i in range(4):
+        for k in outs["eager"][i]:
+            assert torch.equal(outs["eager"][i][k], outs["graph"][i][k]), (i, k)
+    assert not torch.equal(outs["graph"][2]["sample"], outs["graph"][3]["sample"])
+
+
+def _train(mode, steps, T=4, B=8, resample=False, dist_force=False, device="cuda:0", data_seed=9):
+    from dxmi_hip.optim import Adam
+    from models.DxMI.replay import TransitionRing
+    from models.DxMI.trainer import DxMI_Trainer, append_buffer, reset_buffer
+    net, sampler, v = _models(T, device=device)
+    net.dropout_seed = 1234
+    opt = Adam([{"params": net.log_betas, "lr": 1e-3}, {"params": [p for n, p in net.named_parameters() if "log_betas" not in n], "lr": 1e-5}])
+    opt_v = Adam(v.parameters(), lr=1e-4)
+    tr = DxMI_Trainer(batchsize=B, tau1=0.1, tau2=0.01, gamma=1, use_sampler_beta=True, time_cost=0, adavelreg=0.99,
+                      time_cost_sig=True, n_timesteps=T, value_resample=resample)
+    tr.set_models(f=None, v=v, sampler=sampler, optimizer=opt, optimizer_fstar=None, optimizer_v=opt_v)
+    if dist_force:
+        from dxmi_hip.dist import FlatGradSync
+        tr.sync_v = FlatGradSync(v, force=True)
+        tr.sync_sampler = FlatGradSync(sampler, force=True)
+    tr.use_graphs = sampler.use_graph = mode == "graph"
+    ring = TransitionRing(1, T, B, (3, 32, 32), device)
+    torch.manual_seed(5)
+    torch.cuda.manual_seed(6)
+    g = torch.Generator(device=device).manual_seed(data_seed)
+    logs = []
+    for _ in range(steps):
+        img = torch.rand(B, 3, 32, 32, device=device, generator=g) * 2 - 1
+        sampler.eval()
+        d = sampler.sample(B, device=device, out=ring.next_slot())
+        buf = append_buffer(ring, d)
+        le = tr.update_f_v(img, d, buf)
+        ls = tr.update_sampler(buf, 1)
+        reset_buffer(device, ring=ring)
+        logs.append({**le, **ls})
+    torch.cuda.synchronize()
+    state = {"unet": {k: t.detach().clone() for k, t in net.state_dict().items()},
+             "v": {k: t.detach().clone() for k, t in v.state_dict().items()},
+             "betas_for_q": tr.betas_for_q.clone(), "opt_step": float(opt.state[net.conv_in.weight]["step"]),
+             "opt_v_step": float(opt_v.state[v.net.conv1.weight]["step"]), "dropout_calls": net._dropout_calls}
+    return logs, state, tr
+
+
+@pytest.mark.parametrize("resample", [False, True])
+def test_train_step_graph_matches_eager(resample):
+    """Four DxMI train steps (sample into the ring, update_f_v, update_sampler) replayed from hipGraphs against four eager steps:
+    every logged scalar, every parameter of both nets, the q-beta EMA, the optimiser step counters and the dropout call counter.
+    Steps 3 and 4 are pure replays (step 1 is the eager warm-up, step 2 the capture)."""
+    steps = 4
+    le, se, _ = _train("eager", steps, resample=resample)
+    lg, sg, tr = _train("graph", steps, resample=resample)
+    graphs = tr._graphs
+    assert len(graphs) == 2 and all(g.replays == steps - 2 and len(g.segments) == 1 for g in graphs.values())
+    for i in range(steps):
+        assert le[i].keys() == lg[i].keys()
+        for k in le[i]:
+            assert le[i][k] == lg[i][k] or abs(le[i][k] - lg[i][k]) <= 1e-6 * max(1.0, abs(le[i][k])), (i, k, le[i][k], lg[i][k])
+    assert se["opt_step"] == sg["opt_step"] == steps and se["opt_v_step"] == sg["opt_v_step"]
+    assert se["dropout_calls"] == sg["dropout_calls"]
+    assert torch.equal(se["betas_for_q"], sg["betas_for_q"])
+    for name in ("unet", "v"):
+        for k in se[name]:
+            assert torch.equal(se[name][k], sg[name][k]), (name, k, (se[name][k] - sg[name][k]).abs().max().item())
+
+
+def test_graph_survives_eager_update_in_between():
+    """An eager optimiser step between two replays leaves the packed weights stale on the host's books: the next replay
+    refreshes them first (StepGraph checks its modules' versions), so the replayed generation uses the updated weights."""
+    T, B = 4, 8
+    _, s, _ = _models(T)
+    s.eval()
+    s.use_graph = True
+    for _ in range(3):
+        s.sample(B, device="cuda:0")
+    net = s.net
+    with torch.no_grad():
+        net.conv_out.weight.mul_(0.5)          # version bump: the packs are stale now
+    torch.cuda.manual_seed(3)
+    a = s.sample(B, device="cuda:0")["sample"].clone()
+    s.use_graph = False
+    torch.cuda.manual_seed(3)
+    b = s.sample(B, device="cuda:0")["sample"].clone()
+    assert torch.equal(a, b)
+
+
+def cut_check():
+    """Body of the collective-at-a-cut test; runs inside a rank process (tests/_graph_cut_worker.py) with the nccl (= RCCL) group
+    up.  At world 1 the exchange is forced through the 1-rank communicator."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    T, steps = 4, 3
+    dev = f"cuda:{torch.cuda.current_device()}"
+    le, se, _ = _train("eager", steps, T=T, dist_force=True, device=dev, data_seed=9 + rank)
+    lg, sg, tr = _train("graph", steps, T=T, dist_force=True, device=dev, data_seed=9 + rank)
+    segs = {k[0]: [kind for kind, _ in g.segments] for k, g in tr._graphs.items()}
+    out = {"world": world, "f_v_eager_cuts": segs["update_f_v"].count("eager"), "f_v_graphs": segs["update_f_v"].count("graph"),
+           "sampler_eager_cuts": segs["update_sampler"].count("eager"), "sampler_graphs": segs["update_sampler"].count("graph"), "T": T}
+    out["logs_close"] = all(abs(le[i][k] - lg[i][k]) <= 1e-6 * max(1.0, abs(le[i][k])) for i in range(steps) for k in le[i])
+    out["params_equal"] = all(torch.equal(se[n][k], sg[n][k]) for n in ("unet", "v") for k in se[n])
+    chk = torch.tensor([sum(t.double().sum().item() for t in sg[n].values() if t.is_floating_point()) for n in ("unet", "v")],
+                       device=dev, dtype=torch.float64)
+    allc = [torch.zeros_like(chk) for _ in range(world)]
+    dist.all_gather(allc, chk)
+    out["ranks_identical"] = all(torch.equal(allc[0], c) for c in allc)
+    return out
+
+
+def test_graph_cut_runs_collective_between_segments():
+    """The multi-GPU form of the captured step, at world size = visible GPUs (1 on the driver's test box: the exchange is then
+    forced through a 1-rank RCCL communicator): FlatGradSync issues its all-reduces at a cut — eagerly, between two graph
+    launches — so update_f_v is T + 2 graph segments around T + 1 exchanges, update_sampler 2 around 1, and the results equal
+    the eager step's.  Rank processes are fresh interpreters (tests/_graph_cut_worker.py)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    world = torch.cuda.device_count()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(here, "_graph_cut_worker.py")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    line = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
+    T = line["T"]
+    assert line["f_v_eager_cuts"] == T + 1 and line["f_v_graphs"] == T + 2
+    assert line["sampler_eager_cuts"] == 1 and line["sampler_graphs"] == 2
+    assert line["logs_close"] and line["params_equal"] and line["ranks_identical"]
