@@ -59,6 +59,11 @@ def parse_args():
     ap.add_argument("--no-events", action="store_true", help="skip the per-launch HIP events (roofline legs)")
     ap.add_argument("--train-steps", type=int, default=8, help="timed DxMI train steps (0 = skip the train leg)")
     ap.add_argument("--no-edm", action="store_true", help="skip the EDM legs (BASELINE configs[3], configs[4] at their per-GPU sizes)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch images per GPU whatever N (generation shards by images: generate_cifar10.py:193-204); strong: the "
+                         "reference's TRAINING semantics, per-rank batch = --batch // N (train_cifar10.py:298-301: `batchsize // ngpus`)")
+    ap.add_argument("--no-graph", action="store_true", help="issue every launch from python (no hipGraph replay: dxmi_hip/graph.py); same as DXMI_GRAPH=0")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the 1-GPU legs at the per-rank batches of an 8-GPU / 4-GPU reference run (32 @ T=10, 128 @ T=4)")
     return ap.parse_args()
 
 
@@ -208,7 +213,7 @@ def eager_reference_gpu(device, T, batch):
     return out
 
 
-def build_trainer(sampler, device, B, T):
+def build_trainer(sampler, device, B, T, value_resample=False):
     """DxMI trainer on the HIP path with the reference's CIFAR-10 hyper-parameters
     (configs/cifar10/T10.yaml:33-59; optimizer split train_cifar10.py:283-296)."""
     from dxmi_hip.dist import broadcast_parameters
@@ -225,7 +230,7 @@ def build_trainer(sampler, device, B, T):
     opt = Adam([{"params": net.log_betas, "lr": 1e-5}, {"params": not_beta, "lr": 1e-7}])
     opt_v = Adam(v.parameters(), lr=1e-5)
     tr = DxMI_Trainer(batchsize=B, tau1=0.1, tau2=0.01, gamma=1, use_sampler_beta=True, time_cost=0, adavelreg=0.99,
-                      entropy_in_value=None, velocity_in_value=None, time_cost_sig=True, n_timesteps=T)
+                      entropy_in_value=None, velocity_in_value=None, time_cost_sig=True, n_timesteps=T, value_resample=value_resample)
     tr.set_models(f=None, v=v, sampler=sampler, optimizer=opt, optimizer_fstar=None, optimizer_v=opt_v)
     return tr
 
@@ -296,7 +301,7 @@ def edm_generation_leg(device, name, B, reps=2, events=True):
     return out
 
 
-def edm_train_leg(device, name="imagenet64_T10", B=16, steps=4):
+def edm_train_leg(device, name="imagenet64_T10", B=16, steps=4, graph=True):
     """One DxMI_Trainer_Cond step (models/DxMI/trainer.py:693-746 through MixedPrecisionTrainer, models/cm/fp16_util.py) on the
     ImageNet-64 EDM net at per-GPU batch `B` (synthetic images / labels): sample T + update_f_v + update_sampler_mixed_precision."""
     import torch
@@ -306,6 +311,7 @@ def edm_train_leg(device, name="imagenet64_T10", B=16, steps=4):
     from models.cm.fp16_util import MixedPrecisionTrainer
     from models.cm.script_util import create_model_and_diffusion
     from models.DxMI.openai_diffusion import OpenAIDiffusion
+    from models.DxMI.replay import TransitionRing
     from models.DxMI.trainer import append_buffer, reset_buffer
     cfg = configs_builtin.get(name)
     torch.manual_seed(0)
@@ -323,22 +329,27 @@ def edm_train_leg(device, name="imagenet64_T10", B=16, steps=4):
     opt_v = Adam(v.parameters(), lr=1e-5)
     trainer = dxmi_config.instantiate(cfg.trainer, batchsize=B)
     trainer.set_models(v=v, sampler=sampler, optimizer=opt, optimizer_v=opt_v)
+    trainer.use_graphs = sampler.use_graph = graph      # the three phases of the iteration replay as hipGraphs (dxmi_hip/graph.py)
     res = cfg.diffusion.image_size
     g = torch.Generator(device=device).manual_seed(1)
+    # the replay ring of train_image_large.py (one trajectory per iteration, generated in place by the sampler)
+    ring = TransitionRing(1, trainer.n_timesteps, B, sampler.sample_shape, device, with_y=True, sigma_dims=1)
 
     def step():
         data = torch.rand(B, 3, res, res, device=device, generator=g) * 2 - 1
         y = torch.randint(0, 1000, (B,), device=device, generator=g)
         sampler.eval()
-        d = sampler.sample(B, device=device, i_class=y)
-        buf = append_buffer(reset_buffer(device), d)
+        d = sampler.sample(B, device=device, i_class=y, out=ring.next_slot())
+        buf = append_buffer(ring, d)
         le = trainer.update_f_v(data, d, buf, y=y)
         ls = trainer.update_sampler_mixed_precision(buf, mp_trainer=mp)
+        reset_buffer(device, ring=ring)
         return le, ls
 
     from dxmi_hip import ops
     ops.tune_for_throughput(True)              # train_image_large.py's setting: under-filled conv grids on smaller tiles
-    step()
+    for _ in range(3 if graph else 1):         # (graph: eager first call, capture, first replay)
+        step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -348,9 +359,55 @@ def edm_train_leg(device, name="imagenet64_T10", B=16, steps=4):
     ops.tune_for_throughput(False)
     assert all(x == x for x in le.values())
     out = {"workload": f"{name}: DxMI_Trainer_Cond step, per-GPU batch {B}, T={sampler.n_timesteps}, fused RAdam / Adam, loss scale 2^20",
-           "train_steps_per_sec": round(1 / dt, 3), "ms_per_step": round(dt * 1e3, 1), "timed_steps": steps,
-           "lg_loss_scale_after": round(float(mp.lg_loss_scale), 3)}
+           "train_steps_per_sec": round(1 / dt, 3), "ms_per_step": round(dt * 1e3, 1), "timed_steps": steps, "hip_graph": graph,
+           "lg_loss_scale_after": round(float(mp.lg_loss_scale), 3), "radam_step_count": int(opt.step_count())}
     del trainer, mp, opt, opt_v, sampler, unet, v
+    torch.cuda.empty_cache()
+    return out
+
+
+def small_batch_leg(device, B, T, graph, value_resample=False, steps=6):
+    """The DxMI train step and the generation call at a per-rank batch of the reference's multi-GPU runs (`batchsize // ngpus`,
+    train_cifar10.py:298-301): B = 32 is configs[1] (global 256, T = 10) on 8 GPUs, B = 128 / T = 4 / value_resample is configs[2]
+    (global 512, T4_ddgan.yaml) on 4.  Fresh nets; 3 warm-up steps (the second one is the capture when `graph`), `steps` timed.
+    host_issue_ms = host time until the python calls of a step have returned (for the train step this includes its two log
+    read-backs); gpu_ms = HIP-event time of the same steps on the launch stream."""
+    import torch
+    from dxmi_hip import ops
+    from models.DxMI.replay import TransitionRing
+    sampler = build_sampler(device, T)
+    sampler.use_graph = graph
+    out = {"per_gpu_batch": B, "T": T, "hip_graph": graph, "timed_steps": steps}
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        issue = 0.0
+        for _ in range(steps):
+            ti = time.perf_counter()
+            fn()
+            issue += time.perf_counter() - ti
+        e1.record()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, issue / steps, e0.elapsed_time(e1) / steps
+
+    for _ in range(3):
+        sampler.sample(B, device=device)
+    wall, issue, gpu = timed(lambda: sampler.sample(B, device=device))
+    out["gen"] = {"images_per_sec": round(B / wall, 1), "ms_per_call": round(1e3 * wall, 2), "host_issue_ms": round(1e3 * issue, 2), "gpu_ms": round(gpu, 2)}
+    ops.tune_for_throughput(True)
+    tr = build_trainer(sampler, device, B, T, value_resample=value_resample)
+    tr.use_graphs = graph
+    ring = TransitionRing(1, T, B, (3, 32, 32), device)
+    imgs = torch.rand(B, 3, 32, 32, device=device) * 2 - 1
+    for _ in range(3):
+        train_step(tr, sampler, imgs, device, ring)
+    wall, issue, gpu = timed(lambda: train_step(tr, sampler, imgs, device, ring))
+    ops.tune_for_throughput(False)
+    out["train"] = {"steps_per_sec": round(1 / wall, 2), "ms_per_step": round(1e3 * wall, 2), "host_issue_ms": round(1e3 * issue, 2), "gpu_ms": round(gpu, 2)}
+    del tr, sampler, ring
     torch.cuda.empty_cache()
     return out
 
@@ -410,10 +467,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # RCCL
 
+    from dxmi_hip import graph as hip_graph
     from dxmi_hip import ops
     ops.device_check()
     sampler = build_sampler(device, args.T)
-    B, T = args.batch, args.T
+    use_graph = hip_graph.default_enabled() and not args.no_graph
+    sampler.use_graph = use_graph          # the T-step loop of a fixed (batch, destination) replays as one hipGraph after its first call
+    B, T = (args.batch // world if args.scaling == "strong" else args.batch), args.T
     torch.manual_seed(1234 + rank)      # seed + rank, as generate_cifar10.py:103-110
     torch.cuda.manual_seed(1234 + rank)
 
@@ -434,7 +494,7 @@ def main():
             return tt.item()
         return x
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup + (2 if use_graph else 0)):     # (+ the eager first call and the capture call of the hipGraph: never timed)
         step()
     # ---- timed region: exactly K steps between barrier + synchronize brackets; one event per step for the median
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -463,10 +523,12 @@ def main():
     if rank == 0 and not args.no_events:
         prof = ops.OpProfiler()
         ops.PROFILER = prof
+        sampler.use_graph = False             # per-launch events need the launches issued one by one
         for _ in range(2):
             step()
         torch.cuda.synchronize()
         ops.PROFILER = None
+        sampler.use_graph = use_graph
         gen_summ = {k: {kk: vv / 2 for kk, vv in v.items()} for k, v in prof.summary().items()}     # per step
         gen_clock = ops.conv_ws_clock_ghz()        # shader clock during the last conv_ws_kernel launch of the generation step
 
@@ -476,10 +538,11 @@ def main():
         from models.DxMI.replay import TransitionRing
         ops.tune_for_throughput(True)          # as train_cifar10.py / train_image_large.py do (the generation legs keep the defaults)
         tr = build_trainer(sampler, device, B, T)
+        tr.use_graphs = use_graph             # update_f_v / update_sampler replay as hipGraphs (gradient exchanges at graph cuts)
         ring = TransitionRing(1, T, B, (3, 32, 32), device)
         gimg = torch.Generator(device=device).manual_seed(112233 + rank)
         imgs = torch.rand(B, 3, 32, 32, device=device, generator=gimg) * 2 - 1
-        for _ in range(2):                                   # warm-up (weight packing, workspaces, optimiser state, allocator growth)
+        for _ in range(3):                                   # warm-up (weight packing, workspaces, optimiser state, allocator growth; the second step is the graph capture)
             train_step(tr, sampler, imgs, device, ring)
         sync_all()
         t1 = time.perf_counter()
@@ -493,9 +556,11 @@ def main():
         if rank == 0 and not args.no_events:
             prof = ops.OpProfiler()
             ops.PROFILER = prof
+            sampler.use_graph = tr.use_graphs = False
             train_step(tr, sampler, imgs, device, ring)
             torch.cuda.synchronize()
             ops.PROFILER = None
+            sampler.use_graph = tr.use_graphs = use_graph
             train_summ = prof.summary()
         ops.tune_for_throughput(False)
         sync_all()
@@ -507,11 +572,12 @@ def main():
         "metric": "images/sec (CIFAR-10 DDPM T=10 generation)", "value": images / elapsed, "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "median_ms_per_step": statistics.median(per_step_ms),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "train_steps_per_sec": train_sps, "hip_graph": use_graph,
         "config": {"workload": f"CIFAR-10 DDPM U-Net (35.7M params) VARSampler T={T} generation, "
                                f"{B} images/GPU/step, 3x32x32 (BASELINE configs[1]); noise drawn inside the step",
-                   "images_per_gpu_per_step": B, "T": T, "parallelism": f"dp{world} (independent trajectories, no collective)"},
-        "train_steps_per_sec": train_sps,
+                   "images_per_gpu_per_step": B, "global_batch": B * world, "T": T,
+                   "parallelism": f"dp{world} (independent trajectories, no collective)"},
         "train_config": {"per_gpu_batch": B, "global_batch": B * world, "timed_steps": args.train_steps,
                          "step": "sample T (in place in the replay ring) + update_f_v (1 energy + T TD steps) + update_sampler, "
                                  "fused Adam, device-side grad clip, dropout 0.1",
@@ -562,7 +628,15 @@ def main():
         # BASELINE configs[3] / [4] (EDM backbones) at their per-GPU sizes + the EDM train step: rank 0, outside the timed region
         line["edm"] = {"imagenet64_T10_b100": edm_generation_leg(device, "imagenet64_T10", 100, events=not args.no_events),
                        "lsun_bedroom_T4_b16": edm_generation_leg(device, "lsun_bedroom_T4", 16, events=not args.no_events),
-                       "imagenet64_T10_train_b16": edm_train_leg(device)}
+                       "imagenet64_T10_train_b16": edm_train_leg(device, graph=use_graph)}
+    if world == 1 and not args.no_small_batch:
+        # the per-rank batches of the reference's multi-GPU runs (global batch // N), on this one GPU: hipGraph replay vs python issue
+        line["small_batch"] = {
+            "cifar10_T10_b32": {"what": "configs[1] at 8 GPUs: 256 // 8 images per rank, T = 10",
+                                "graph": small_batch_leg(device, 32, 10, use_graph), "eager": small_batch_leg(device, 32, 10, False)},
+            "cifar10_T4_b128": {"what": "configs[2] at 4 GPUs: 512 // 4 images per rank, T = 4, value_resample (T4_ddgan.yaml)",
+                                "graph": small_batch_leg(device, 128, 4, use_graph, value_resample=True),
+                                "eager": small_batch_leg(device, 128, 4, False, value_resample=True)}}
     if world == 1 and not args.no_eager_reference:
         eg = eager_reference_gpu(device, T, B)
         line["reference_eager_gpu"] = {
@@ -588,7 +662,26 @@ def main():
                                 "sample": f"oracle (torch-CPU fp32 restatement), BASELINE configs[0] shape: {cb} images x T={T} at 8 threads "
                                           f"(whole sample) and at the {ncores} usable cores (1 of the {T} steps, rate scaled to T, null = "
                                           "not finished within 45 s); one repetition each; the better one is `value`"}
-    print(json.dumps(line))
+    # the scalars a reader of the driver's record needs, flat and EARLY in the line (its tail is cut)
+    flat = {"train_steps_per_sec": train_sps, "hip_graph": use_graph}
+    if "edm" in line:
+        flat.update({"c4_images_per_sec": line["edm"]["imagenet64_T10_b100"]["images_per_sec"],
+                     "c5_images_per_sec": line["edm"]["lsun_bedroom_T4_b16"]["images_per_sec"],
+                     "edm_train_steps_per_sec": line["edm"]["imagenet64_T10_train_b16"]["train_steps_per_sec"]})
+    if "small_batch" in line:
+        b32 = line["small_batch"]["cifar10_T10_b32"]
+        flat.update({"train_b32_steps_per_sec": b32["graph"]["train"]["steps_per_sec"], "train_b32_ms_per_step": b32["graph"]["train"]["ms_per_step"],
+                     "train_b32_host_issue_ms": b32["graph"]["train"]["host_issue_ms"], "train_b32_gpu_ms": b32["graph"]["train"]["gpu_ms"],
+                     "train_b32_eager_ms_per_step": b32["eager"]["train"]["ms_per_step"],
+                     "gen_b32_images_per_sec": b32["graph"]["gen"]["images_per_sec"], "gen_b32_host_issue_ms": b32["graph"]["gen"]["host_issue_ms"],
+                     "train_b128_T4_steps_per_sec": line["small_batch"]["cifar10_T4_b128"]["graph"]["train"]["steps_per_sec"]})
+    if "roofline" in line:
+        flat["roofline_frac"] = round(line["roofline"]["frac"], 4)
+    head = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"]
+    ordered = {k: line[k] for k in head}
+    ordered.update(flat)
+    ordered.update({k: v for k, v in line.items() if k not in ordered})
+    print(json.dumps(ordered))
 
 
 if __name__ == "__main__":

@@ -65,6 +65,7 @@ class StepGraph:
         self.segments = None
         self.generation = None
         self.replays = 0
+        self.captures = 0
 
     # ------------------------------------------------------------------ declared while capturing
     def host_input(self, dtype, n, producer):
@@ -137,6 +138,7 @@ class StepGraph:
         cur = torch.cuda.current_stream(dev)
         self.stream.wait_stream(cur)
         self.generation = ops.PACK_GENERATION
+        self.captures += 1
         _CURRENT = self
         ok = False
         try:

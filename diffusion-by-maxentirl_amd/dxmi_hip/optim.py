@@ -62,6 +62,13 @@ class _Batch:
         self.params, self.grads, self.ms, self.vs, self.lrs, self.groups = [], [], [], [], [], []
 
 
+class _BatchView:
+    __slots__ = ("params", "ms", "vs")
+
+    def __init__(self, params, ms, vs):
+        self.params, self.ms, self.vs = params, ms, vs
+
+
 def _batches(opt, name):
     """(betas, eps, step) -> _Batch.  Parameters that received their first gradient later than the others (or only
     intermittently) have a lagging step counter; torch.optim handles them per tensor, here they form their own launch."""
@@ -167,6 +174,62 @@ class RAdam(_FusedBase, torch.optim.RAdam):
         super().load_state_dict(state_dict)
         self.__dict__.pop("_dxmi_cache", None)
         self.__dict__.pop("_dxmi_slices", None)
+
+    @staticmethod
+    def radam_scalars(b1, b2, t):
+        """(fp32(1 / bc1), bc2_sqrt, rect | -1) of step count t, formed in double as torch/optim/radam.py forms them."""
+        bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+        rho_inf = 2 / (1 - b2) - 1
+        rho_t = rho_inf - 2 * t * (b2 ** t) / bc2
+        rect = -1.0
+        if rho_t > 5.0:
+            rect = ((rho_t - 4) * (rho_t - 2) * rho_inf / ((rho_inf - 4) * (rho_inf - 2) * rho_t)) ** 0.5
+        return 1.0 / bc1, math.sqrt(bc2), rect
+
+    @torch.no_grad()
+    def step_sliced_captured(self, cap, slices, hyper3, grad_scale, found_inf):
+        """step_sliced() of a step that is being captured into a hipGraph (MixedPrecisionTrainer under dxmi_hip/graph.py).  The
+        step count of a replayed iteration depends on how many earlier iterations of the same replay overflowed, which only the
+        device knows: the CALLER selects the row of step-dependent scalars on the device (hyper3 = fp32 [3]: 1/bc1, bc2_sqrt,
+        rect) and advances the host counters after the replay (`advance_steps`).  The learning rates are a host input of the
+        graph (read live per replay)."""
+        ps_all, ms, vs, groups = [], [], [], []
+        cache = self.__dict__.setdefault("_dxmi_slices", {})
+        betas = eps = None
+        for group in self.param_groups:
+            _check_group(group, "RAdam")
+            if betas is None:
+                betas, eps = tuple(group["betas"]), group["eps"]
+            if tuple(group["betas"]) != betas or group["eps"] != eps:
+                raise DxmiError("RAdam.step_sliced_captured: parameter groups with different betas / eps")
+            for P in group["params"]:
+                st = self.state[P]
+                if len(st) == 0:
+                    raise DxmiError("RAdam.step_sliced_captured: optimiser state missing (run one eager step first)")
+                views = cache.get(id(P))
+                if views is None:
+                    raise DxmiError("RAdam.step_sliced_captured: slice views missing (run one eager step first)")
+                ps = slices[P]
+                ps_all += ps
+                ms += views[1]
+                vs += views[2]
+                groups += [group] * len(ps)
+        n = len(ps_all)
+        lrs = cap.host_input(torch.float32, n, lambda: [g["lr"] for g in groups])
+        hyper = torch.cat([hyper3.reshape(3), lrs])
+        ops.radam_step(ps_all, [q.grad for q in ps_all], ms, vs, None, betas[0], betas[1], eps, None, None, None, grad_scale=grad_scale,
+                       found_inf=found_inf, cache=_cache_for(self, (betas[0], betas[1], eps, "captured"), _BatchView(ps_all, ms, vs)), hyper=hyper)
+        _bump_versions(ps_all)
+
+    def step_count(self):
+        """Common step count of the flat master parameters (they step together)."""
+        counts = {float(self.state[P]["step"]) for g in self.param_groups for P in g["params"] if len(self.state[P])}
+        if len(counts) != 1:
+            raise DxmiError(f"RAdam: parameters at different step counts {sorted(counts)}")
+        return counts.pop()
+
+    def advance_steps(self, n):
+        torch._foreach_add_([self.state[P]["step"] for g in self.param_groups for P in g["params"]], n)
 
     @torch.no_grad()
     def step_sliced(self, slices, grad_scale=None, found_inf=None):

@@ -48,6 +48,8 @@ def main():
                          "whose weights this image cannot download): callable(batch in [0,1]) -> [features [B, 2048, h, w]]")
     ap.add_argument("--fid_stats", type=str, default=None, help="statistics npz (`mu`, `sigma`) instead of the dataset's PNG folder")
     ap.add_argument("--synthetic", type=str, default=None, help="builtin config name, e.g. cifar10_T10 (random weights)")
+    ap.add_argument("--no_graph", action="store_true", help="issue every launch from python instead of replaying the T-step loop of a "
+                                                           "batch as one hipGraph (dxmi_hip/graph.py; DXMI_GRAPH=0 does the same)")
     args, unknown = ap.parse_known_args()
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -84,6 +86,8 @@ def main():
         sampler.net.load_state_dict(ckpt["state_dict"])
         print0(f"Loaded sampler from {sampler_path} (epoch {ckpt.get('epoch')}, FID {ckpt.get('fid')})")
     sampler.eval()
+    from dxmi_hip import graph as hip_graph
+    sampler.use_graph = hip_graph.default_enabled() and not args.no_graph     # second batch onwards: one hipGraphLaunch per batch
 
     trainer = None
     if args.guidance_scale is not None:   # reference :160-191: value net from value_best.pth, trainer only as the sampling driver

@@ -14,6 +14,7 @@ Extension: `noise=` injects the Gaussian draws (x_T and z_1..z_T) so CPU and GPU
 import torch
 import torch.nn as nn
 
+from dxmi_hip import graph as _graph
 from dxmi_hip import ops
 from dxmi_hip._lib import DxmiError
 from models.cm.karras_diffusion import get_sigmas_karras
@@ -36,6 +37,8 @@ class OpenAIDiffusion:
         else:
             self.net.register_buffer("log_betas", torch.log(self.sigma_up))
         self._dev_tabs = {}
+        self.use_graph = False      # sample(): replay the T-step loop of a fixed (batch, destination) as one hipGraph
+        self._graphs = {}
 
     def get_ancestral_step(self, sigmas):
         sigma_from, sigma_to = sigmas[:-1], sigmas[1:]
@@ -109,6 +112,23 @@ class OpenAIDiffusion:
         The trajectory is ONE block [T+1, B, C, H, W] (+ [T, B, ...] mean, [T, B] sigma) written by the fused transition
         kernel; out: a slot of a models.DxMI.replay.TransitionRing to generate in place in the replay buffer."""
         device = torch.device(device)
+        if self.use_graph and not enable_grad and x0 is None and noise is None and not isinstance(i_class, int) \
+                and device.type == "cuda" and not _graph.capturing():
+            # hipGraph replay (dxmi_hip/graph.py): one graph per (batch, destination, labels given or drawn); the first call of a key
+            # runs eagerly, the second is captured.  Without `out=` the returned tensors are static (overwritten by the next call).
+            if device.index is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+            key = (n_sample, device.index, None if out is None else (id(out["ring"]), out["slot"]), i_class is not None)
+            g = self._graphs.get(key)
+            if g is None:
+                from .trainer import _pack_modules
+                fn = (lambda y: self._sample(n_sample, device, y, False, None, None, out)) if i_class is not None else \
+                     (lambda: self._sample(n_sample, device, None, False, None, None, out))
+                g = self._graphs[key] = _graph.StepGraph(fn, device, modules=_pack_modules(self), name=f"OpenAIDiffusion.sample{key}")
+            return g(i_class) if i_class is not None else g()
+        return self._sample(n_sample, device, i_class, enable_grad, x0, noise, out)
+
+    def _sample(self, n_sample, device, i_class, enable_grad, x0, noise, out):
         if self.class_cond:
             if i_class is None:
                 i_class = torch.randint(0, self.num_classes, (n_sample,), device=device)

@@ -494,10 +494,28 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
         diff = ((samples[1:] - samples[:-1]) ** 2).view(samples.shape[0] - 1, -1).mean(dim=1)
         if self.beta_ordering == "reversed":
             diff = diff.flip(0)
-        self.betas_for_q = (self.betas_for_q.to(device) * self.adavelreg + (1 - self.adavelreg) * diff.to(device)).detach()
+        if self.betas_for_q.device != device:
+            self.betas_for_q = self.betas_for_q.to(device)
+        self._set_betas_for_q((self.betas_for_q * self.adavelreg + (1 - self.adavelreg) * diff.to(device)).detach())
 
     def update_f_v(self, img, d_sample, state_dict, y=None):
         """reference :553-691."""
+        g = None
+        if isinstance(state_dict, TransitionRing) and d_sample.get("_ring_slot") == (id(state_dict), state_dict.filled - 1) \
+                and len(img) == self.batchsize and self.value_update_order != "random":
+            nets = [self.v] + ([self.sampler] if self.value_resample else [])
+            if y is None:
+                fn = lambda im, d=d_sample, sd=state_dict: self._update_f_v(im, d, sd, None)
+            else:
+                fn = lambda im, yy, d=d_sample, sd=state_dict: self._update_f_v(im, d, sd, yy)
+            g = self._step_graph("update_f_v", state_dict, tuple(img.shape) + (y is not None,), fn, nets)
+        if g is None:
+            keys, vals = self._update_f_v(img, d_sample, state_dict, y)
+        else:
+            keys, vals = g(img.detach()) if y is None else g(img.detach(), y)
+        return dict(zip(keys, vals.tolist()))
+
+    def _update_f_v(self, img, d_sample, state_dict, y=None):
         if self.adavelreg is not None:
             self.update_adaptive_vel_reg(d_sample)
         x0 = d_sample["l_sample"][-1]
@@ -519,8 +537,8 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
         self.optimizer_v.step()
         self.optimizer_v.zero_grad()
 
-        permutation = torch.randperm(batchsize * n_steps)
-        indices = (permutation + (buffer_rows(state_dict) - batchsize * n_steps)).to(device)
+        permutation = self._randperm(batchsize * n_steps, device)
+        indices = permutation + (buffer_rows(state_dict) - batchsize * n_steps)
         rows_all, ts_all = self._td_rows(state_dict, indices, n_steps, batchsize)
         has_y = y is not None and (("y" in state_dict.has) if isinstance(state_dict, TransitionRing)
                                    else len(state_dict["y"]) == len(state_dict["state"]))
@@ -582,7 +600,7 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
         if self.adavelreg is not None:
             for t, beta in enumerate(self.betas_for_q):
                 logs[f"adavelreg/beta{t}_"] = beta
-        return self._to_floats(logs)
+        return self._stack_logs(logs)
 
     def _guidance_x0_scale(self, x0):          # reference :818-820: EDM trajectories start at sigma_max * N(0, I)
         return x0 * self.sampler.sigma_max
@@ -594,14 +612,32 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
 
     def update_sampler_mixed_precision(self, state_dict, mp_trainer, d_sample=None):
         """reference :693-746: one optimiser step per `batchsize` slice of ALL buffered transitions."""
+        g = None
+        if getattr(mp_trainer, "use_fp16", False) and getattr(mp_trainer, "_aliased", False) and hasattr(self.optimizer, "step_sliced_captured"):
+            g = self._step_graph("update_sampler_mp", state_dict, (id(mp_trainer),),
+                                 lambda sd=state_dict: self._update_sampler_mp(sd, mp_trainer) + (mp_trainer.captured_stats(),),
+                                 [self.sampler, self.v])
+        if g is None or g.calls < g.warmup:       # eager (also the warm-up call of a graph: optimize() does its own host bookkeeping)
+            if g is not None:
+                g.calls += 1
+            keys, vals = self._update_sampler_mp(state_dict, mp_trainer)
+            return dict(zip(keys, vals.tolist()))
+        keys, vals, stats = g()
+        back = torch.cat([vals, stats.reshape(-1)]).tolist()            # logs + the K x (grad norm, param norm, overflow flag): one read-back
+        mp_trainer.finish_replay(self.optimizer, [back[len(keys) + 3 * i:len(keys) + 3 * i + 3] for i in range(stats.shape[0])])
+        return dict(zip(keys, back[:len(keys)]))
+
+    def _update_sampler_mp(self, state_dict, mp_trainer):
         _set_mode(self.v, False)
         _set_mode(self.sampler, True)
-        permutation = torch.randperm(buffer_rows(state_dict))
-        batchsize = self.batchsize
         device = state_dict.device if isinstance(state_dict, TransitionRing) else state_dict["state"].device
+        permutation = self._randperm(buffer_rows(state_dict), device)
+        batchsize = self.batchsize
+        if _graph.capturing():
+            mp_trainer.begin_captured(self.optimizer)
         for m in range(0, len(permutation), batchsize):
             mp_trainer.zero_grad()
-            indices = permutation[m:m + batchsize].to(device)
+            indices = permutation[m:m + batchsize]
             state = buffer_gather(state_dict, "state", indices)
             t = buffer_gather(state_dict, "timestep", indices)
             y = buffer_gather(state_dict, "y", indices) if self.sampler.class_cond else None
@@ -622,7 +658,7 @@ class DxMI_Trainer_Cond(DxMI_Trainer):
             sigma = torch.exp(net.log_betas.detach())
             for t in range(len(sigma)):
                 logs[f"sigma/sigma_{t}_"] = sigma[t]
-        return self._to_floats(logs)
+        return self._stack_logs(logs)
 
 
 class DxMI_Trainer_EV(DxMI_Trainer):

@@ -12,6 +12,8 @@ same from its DDP wrapper during backward (train_image_large.py:173).
 import numpy as np
 import torch
 import torch.nn as nn
+
+from dxmi_hip import graph as _graph
 from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
 
 INITIAL_LOG_LOSS_SCALE = 20.0
@@ -121,14 +123,113 @@ class MixedPrecisionTrainer:
         zero_grad(self.model_params)
 
     def backward(self, loss):
+        cap = _graph.current()
+        if cap is not None:
+            return self._backward_captured(cap, loss)
         if self.use_fp16:
             (loss * 2 ** self.lg_loss_scale).backward()
         else:
             loss.backward()
 
     def optimize(self, opt):
-        self._sync()   # data-parallel mean of the gradients (no-op on one process)
+        self._sync()   # data-parallel mean of the gradients (no-op on one process; a graph cut inside a captured step)
+        if _graph.capturing():
+            return self._optimize_captured(opt)
         return self._optimize_fp16(opt) if self.use_fp16 else self._optimize_normal(opt)
+
+    # ------------------------------------------------------------------ captured into a hipGraph (dxmi_hip/graph.py)
+    # A replayed update runs K backward / optimize iterations without the host in between, so the loss-scale bookkeeping of
+    # optimize() — skip the step, roll the step counter back and halve the scale on overflow; grow the scale otherwise
+    # (reference fp16_util.py:204-231) — moves to the device: the number of overflows so far in this replay is a device counter
+    # `ovf`, and every iteration gets, as a host input, the table of (loss scale, 1 / scale, 1 / bc1, bc2_sqrt, rect) for EVERY
+    # possible value j = 0 .. i of that counter (step count t0 + i - j + 1, lg after i - j growths and j halvings, all formed on
+    # the host in double exactly as the eager path forms them); the device picks row `ovf`.  The RAdam kernel skips on the
+    # device flag as before.  After the replay `finish_replay` reads the K flags and norms back ONCE and repeats the eager
+    # bookkeeping on the host (lg_loss_scale, step counters, logged norms).
+    MAX_CAPTURED_ITERS = 64
+
+    def _capture_state(self, cap):
+        st = self.__dict__.get("_cap_state")
+        if st is None or st["cap"] is not cap or st["capture_id"] != cap.captures:
+            if not (self.use_fp16 and self._aliased):
+                raise NotImplementedError("MixedPrecisionTrainer inside a StepGraph capture: use_fp16 with device-aliased masters only")
+            dev = self.model_params[0].device
+            st = {"cap": cap, "capture_id": cap.captures, "i": 0, "ovf": torch.zeros(1, dtype=torch.int64, device=dev),
+                  "stats": torch.zeros((self.MAX_CAPTURED_ITERS, 3), dtype=torch.float32, device=dev), "row": None, "opt": None}
+            self.__dict__["_cap_state"] = st
+        return st
+
+    def _rows(self, i, opt):
+        """Host input of iteration i: rows j = 0 .. i (overflows so far in this replay)."""
+        from dxmi_hip.optim import RAdam
+        lg0, t0 = self.lg_loss_scale, opt.step_count()
+        b1, b2 = opt.param_groups[0]["betas"]
+        out = []
+        for j in range(i + 1):
+            lg = lg0
+            for _ in range(j):
+                lg -= 1
+            for _ in range(i - j):
+                lg += self.fp16_scale_growth
+            scale = 2.0 ** lg
+            inv_bc1, bc2_sqrt, rect = RAdam.radam_scalars(b1, b2, t0 + (i - j) + 1)
+            out.append([scale, 1.0 / scale, inv_bc1, bc2_sqrt, rect])
+        return np.asarray(out, dtype=np.float64).astype(np.float32).reshape(-1)
+
+    def _backward_captured(self, cap, loss):
+        st = self._capture_state(cap)
+        i = st["i"]
+        if i >= self.MAX_CAPTURED_ITERS:
+            raise RuntimeError("MixedPrecisionTrainer: more than MAX_CAPTURED_ITERS optimiser iterations in one captured step")
+        if st["opt"] is None:
+            raise RuntimeError("MixedPrecisionTrainer inside a StepGraph capture: call begin_captured(opt) first")
+        opt = st["opt"]
+        table = cap.host_input(torch.float32, (i + 1) * 5, lambda i=i, opt=opt: self._rows(i, opt)).view(i + 1, 5)
+        st["row"] = table.index_select(0, st["ovf"]).reshape(5)
+        (loss * st["row"][0]).backward()
+
+    def begin_captured(self, opt):
+        """Called by the trainer at the top of a captured update: binds the optimiser whose step count the host tables follow."""
+        st = self._capture_state(_graph.current())
+        st["opt"] = opt
+
+    def _optimize_captured(self, opt):
+        from dxmi_hip import ops
+        st = self._capture_state(_graph.current())
+        assert st["opt"] is opt and st["row"] is not None
+        for p in self.model_params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        row = st["row"]
+        gstat = ops.gradnorm_clip([p.grad for p in self.model_params], 0.0)
+        pstat = ops.gradnorm_clip([m.detach() for m in self.master_params], 0.0)
+        found = gstat[2:3]
+        opt.step_sliced_captured(st["cap"], self._slices, row[2:5], row[1:2], found)
+        st["stats"][st["i"]] = torch.stack([gstat[0], pstat[0], gstat[2]])
+        st["ovf"] += (found != 0).to(torch.int64)
+        zero_grad(self.model_params)
+        st["i"] += 1
+        st["row"] = None
+        return True
+
+    def captured_stats(self):
+        """Device [K, 3] (scaled gradient norm, parameter norm, overflow flag) of the K iterations of the captured update."""
+        st = self.__dict__["_cap_state"]
+        return st["stats"][:st["i"]]
+
+    def finish_replay(self, opt, stats):
+        """stats: captured_stats() read back ([K][3] python floats).  The eager bookkeeping of optimize(), iteration by iteration."""
+        ok = 0
+        for gn, pn, flag in stats:
+            self.log["lg_loss_scale"] = self.lg_loss_scale
+            scale = 2.0 ** self.lg_loss_scale
+            if flag != 0.0 or check_overflow(gn / scale):
+                self.lg_loss_scale -= 1
+            else:
+                self.log["grad_norm"], self.log["param_norm"] = gn / scale, pn
+                self.lg_loss_scale += self.fp16_scale_growth
+                ok += 1
+        opt.advance_steps(ok)
 
     def _optimize_fp16_sliced(self, opt):
         """`_optimize_fp16` without its five passes over the 1.2 GB of parameters (flatten the gradients, two norm passes with a

@@ -223,6 +223,22 @@ class UNetModel(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def refresh_packs(self):
+        """Bring every packed-weight set of the net that exists up to date with the parameters (no-op when they are)."""
+        self.packed()
+        if getattr(self, "_packed_t", None) is not None:
+            from .unet_train import _pack_t
+            _pack_t(self)
+
+    def prepare_capture(self):
+        """Before a StepGraph capture (dxmi_hip/graph.py): entries of the transposed set that a backward packs on demand are dropped
+        so that the captured step packs them itself; the planned sets are refreshed eagerly (in place: ops.PackPlan)."""
+        pkt = getattr(self, "_packed_t", None)
+        if pkt is not None:
+            for k in [k for k in pkt if k not in self._pack_t_planned]:
+                del pkt[k]
+        self.refresh_packs()
+
     # ------------------------------------------------------------------ fused blocks
     # Activations on maps of >= STREAM_GN_MIN_HW pixels travel as (tensor, BlockStats): the conv that produces a tensor writes
     # the GroupNorm statistics of what it stores (per channel pair: the group widths of these nets are 6 ... 32 channels), so

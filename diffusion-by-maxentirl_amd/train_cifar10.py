@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--batch_invariant", action="store_true",
                     help="keep one conv kernel per layer shape whatever the batch size (bitwise batch-independent results) instead of "
                          "routing under-filled grids to smaller tiles (dxmi_hip.ops.tune_for_throughput)")
+    ap.add_argument("--no_graph", action="store_true",
+                    help="issue every kernel launch from python instead of replaying the generation call and the two updates as hipGraphs "
+                         "(dxmi_hip/graph.py; DXMI_GRAPH=0 does the same)")
     args, unknown = ap.parse_known_args()
     d_cmd_cfg = cmd.parse_nested_args(cmd.parse_unknown_args(unknown))
     print0("Overriding", d_cmd_cfg)
@@ -136,6 +139,10 @@ def main():
     batchsize = cfg.training.batchsize // world     # the reference divides by the visible device count (:298-301)
     trainer = dxmi_config.instantiate(cfg.trainer, batchsize=batchsize)
     trainer.set_models(f=None, v=v, sampler=sampler, optimizer=optimizer, optimizer_fstar=None, optimizer_v=optimizer_v)
+    # per-rank batches of a multi-GPU run are small (batchsize // world): the step is replayed from hipGraphs so that the host does not
+    # bound it; gradient exchanges stay eager RCCL calls at graph cuts (dxmi_hip/dist.py)
+    from dxmi_hip import graph as hip_graph
+    trainer.use_graphs = sampler.use_graph = hip_graph.default_enabled() and not args.no_graph
 
     model_cfg_name = os.path.basename(args.config).split(".")[0].replace("builtin:", "")
     logdir = os.path.join(f"results/{cfg.data.name}/{model_cfg_name}", args.run)

@@ -178,3 +178,87 @@ def test_graph_cut_runs_collective_between_segments():
     assert line["f_v_eager_cuts"] == T + 1 and line["f_v_graphs"] == T + 2
     assert line["sampler_eager_cuts"] == 1 and line["sampler_graphs"] == 2
     assert line["logs_close"] and line["params_equal"] and line["ranks_identical"]
+
+
+EDM_KW = dict(image_size=32, class_cond=True, learn_sigma=False, num_channels=64, num_res_blocks=1, channel_mult="1,2",
+              num_heads=4, num_head_channels=64, num_heads_upsample=-1, attention_resolutions="16", dropout=0.0,
+              use_checkpoint=False, use_scale_shift_norm=True, resblock_updown=True, use_fp16=True,
+              use_new_attention_order=False, weight_schedule="uniform")
+EDM_SAMPLER_KW = dict(n_timesteps=4, sample_shape=(3, 32, 32), class_cond=True, num_classes=1000, trainable_beta="fix_last",
+                      stochastic_last=True, rho=4.0)
+EDM_TRAINER_KW = dict(tau1=0.1, tau2=0.01, gamma=1, n_timesteps=4, use_sampler_beta=True, adavelreg=0.99, entropy_in_value=None,
+                      velocity_in_value=None, value_grad_clip=True, time_cost=0, skip_sampler_tau=1, time_cost_sig=1)
+
+
+def _edm_train(mode, steps, lg0=20.0, B=4):
+    from dxmi_hip.optim import Adam, RAdam
+    from models.cm.fp16_util import MixedPrecisionTrainer
+    from models.cm.script_util import create_model_and_diffusion
+    from models.DxMI.openai_diffusion import OpenAIDiffusion
+    from models.DxMI.replay import TransitionRing
+    from models.DxMI.trainer import DxMI_Trainer_Cond, append_buffer, reset_buffer
+    from models.modules import IGEBMEncoderV2
+    from models.value import TimeIndependentValue
+    from oracle.weights import formula_tensor
+    dev = "cuda:0"
+    net, diffusion = create_model_and_diffusion(**EDM_KW)
+    net.load_state_dict({k: formula_tensor(k, v.shape) for k, v in net.state_dict().items()})
+    sampler = OpenAIDiffusion(net, diffusion, **EDM_SAMPLER_KW)
+    net.to(dev)
+    v = TimeIndependentValue(IGEBMEncoderV2(in_chan=3, out_chan=1, use_spectral_norm=False, keepdim=False, out_activation="linear",
+                                            avg_pool_dim=1, learn_out_scale=True, nh=128))
+    v.load_state_dict({k: formula_tensor(k, t.shape) for k, t in v.state_dict().items()})
+    v.to(dev)
+    mp = MixedPrecisionTrainer(model=net, use_fp16=True, initial_lg_loss_scale=lg0, special_key="log_betas")
+    opt = RAdam([{"params": mp.master_params[1:], "lr": 1e-6}, {"params": mp.master_params[0:1], "lr": 1e-4}])
+    opt_v = Adam(v.parameters(), lr=1e-5)
+    tr = DxMI_Trainer_Cond(batchsize=B, **EDM_TRAINER_KW)
+    tr.set_models(v=v, sampler=sampler, optimizer=opt, optimizer_v=opt_v)
+    tr.use_graphs = sampler.use_graph = mode == "graph"
+    T = EDM_SAMPLER_KW["n_timesteps"]
+    ring = TransitionRing(1, T, B, (3, 32, 32), dev, with_y=True, sigma_dims=1)
+    torch.manual_seed(5)
+    torch.cuda.manual_seed(6)
+    g = torch.Generator(device=dev).manual_seed(9)
+    logs = []
+    for _ in range(steps):
+        img = torch.rand(B, 3, 32, 32, device=dev, generator=g) * 2 - 1
+        y = torch.randint(0, 1000, (B,), device=dev, generator=g)
+        sampler.eval()
+        d = sampler.sample(B, device=dev, i_class=y, out=ring.next_slot())
+        buf = append_buffer(ring, d)
+        le = tr.update_f_v(img, d, buf, y=y)
+        ls = tr.update_sampler_mixed_precision(buf, mp_trainer=mp)
+        reset_buffer(dev, ring=ring)
+        logs.append({**le, **ls})
+    torch.cuda.synchronize()
+    state = {"unet": {k: t.detach().clone() for k, t in net.state_dict().items()}, "v": {k: t.detach().clone() for k, t in v.state_dict().items()},
+             "lg": mp.lg_loss_scale, "steps": opt.step_count(), "log": dict(mp.log), "betas_for_q": tr.betas_for_q.clone()}
+    return logs, state, tr
+
+
+@pytest.mark.parametrize("lg0", [20.0, 129.5])
+def test_edm_train_step_graph_matches_eager(lg0):
+    """DxMI_Trainer_Cond + MixedPrecisionTrainer + fused RAdam on a shrunken EDM net: the three phases of an iteration replayed
+    from hipGraphs against eager iterations.  lg0 = 129.5 makes the first loss scales overflow fp32 (2^129.5, 2^128.5 = inf):
+    those iterations are skipped ON THE DEVICE inside the replay — the device counter picks the rows of the host tables for
+    'j overflows so far' — and the host bookkeeping after the replay must land on the eager run's loss scale, step count and
+    parameters."""
+    steps = 4
+    le, se, _ = _edm_train("eager", steps, lg0=lg0)
+    lg, sg, tr = _edm_train("graph", steps, lg0=lg0)
+    assert {k[0] for k in tr._graphs} == {"update_f_v", "update_sampler_mp"}
+    assert all(g.replays == steps - 2 for g in tr._graphs.values())
+    assert se["lg"] == sg["lg"] and se["steps"] == sg["steps"], (se["lg"], sg["lg"], se["steps"], sg["steps"])
+    if lg0 > 100:
+        assert se["steps"] < steps * 4           # some iterations really overflowed
+    for i in range(steps):
+        for k in le[i]:
+            a, b = le[i][k], lg[i][k]
+            assert a == b or (a != a and b != b) or abs(a - b) <= 1e-6 * max(1.0, abs(a)), (i, k, a, b)
+    assert torch.equal(se["betas_for_q"], sg["betas_for_q"])
+    for name in ("unet", "v"):
+        for k in se[name]:
+            assert torch.equal(se[name][k], sg[name][k]), (name, k)
+    for k in ("grad_norm", "param_norm", "lg_loss_scale"):
+        assert se["log"].get(k) == sg["log"].get(k) or abs(se["log"][k] - sg["log"][k]) <= 1e-6 * abs(se["log"][k]), k
