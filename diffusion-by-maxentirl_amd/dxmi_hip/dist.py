@@ -54,8 +54,9 @@ class FlatGradSync:
     produced one), launches the remaining buckets and waits.  With the fp32 wire format `sync()` then RE-BINDS every `.grad` to
     its slice of the flat buffer instead of copying the means back (round 4: a 143 MB scatter per U-Net exchange); the slices
     stay untouched until the next backward packs into them, by which time the trainers have dropped the gradients
-    (`zero_grad(set_to_none=True)` / `p.grad = None`).  During a backward `.grad` is never an alias of the buffer a collective may
-    be working on, so the two-backward fallback keeps its meaning.  With a narrower wire format the means are copied back by one
+    (`zero_grad(set_to_none=True)` / `p.grad = None`: REQUIRED with the fp32 wire — a gradient that is kept and accumulated into
+    in place would be an alias of a buffer a collective may still be working on; `_on_grad` un-aliases such a gradient by
+    cloning it before the two-backward fallback runs).  With a narrower wire format the means are copied back by one
     multi-tensor copy.  Which parameters received a gradient on ANY rank
     travels as one flag per parameter in the TAIL of the last bucket: no collective of its own (round 4 issued a second small
     all-reduce per sync: 12 extra collectives per CIFAR train step, ~30 us of launch latency each on a path — the T + 1
@@ -76,10 +77,11 @@ class FlatGradSync:
         self.bucket_of = [0] * len(self.params)
         self.buckets = []             # (start, end, n_params)
         pos, start, count = 0, 0, 0
-        for i in self.order:
+        align = max(1, 16 // itemsize)      # every slice starts on a 16-byte boundary: the multi-tensor Adam / norm / clip kernels
+        for i in self.order:                # take their f32x4 path only on 16-byte aligned pointers, and .grad IS the slice after sync()
             self.offset[i] = pos
             self.bucket_of[i] = len(self.buckets)
-            pos += self.params[i].numel()
+            pos += (self.params[i].numel() + align - 1) // align * align      # (the pad elements are zeroed once and exchanged as zeros)
             count += 1
             if pos - start >= limit:
                 self.buckets.append((start, pos, count))
@@ -114,7 +116,7 @@ class FlatGradSync:
 
     def _buffers(self, device):
         if self.flat is None or self.flat.device != device:
-            self.flat = torch.empty(self.numel + self.nflags, dtype=self.wire_dtype, device=device)
+            self.flat = torch.zeros(self.numel + self.nflags, dtype=self.wire_dtype, device=device)
             self.views = [self.flat[self.offset[i]:self.offset[i] + p.numel()].view_as(p) for i, p in enumerate(self.params)]
             self.flags = self.flat[self.numel:]
             self.flags.fill_(1.0)       # refilled at the end of every sync(): in place before the next backward's last bucket
@@ -132,6 +134,9 @@ class FlatGradSync:
             return
         i = self.index[id(p)]
         if self.ready[i]:             # second backward before sync(): the launched buckets hold stale sums
+            if self.views is not None and p.grad.data_ptr() == self.views[i].data_ptr():
+                p.grad = p.grad.clone()   # accumulated in place into its flat slice (gradients kept across sync()): never leave
+                                          # .grad aliasing a buffer whose all-reduce may still be in flight
             self.dirty = True
             return
         self._buffers(p.grad.device)

@@ -49,19 +49,23 @@ def _tree_fingerprint(module):
 def fast_parameters(module):
     """module.parameters() without nn.Module's name-building / de-duplication machinery (a U-Net's `tuple(... for p in
     net.parameters())` was ~1 ms of Python per forward): the submodules are listed once, their `_parameters` dictionaries are read
-    live, in the order `parameters()` yields.  The cached list is dropped when the module tree changes (a submodule added or
-    replaced: the fingerprint walk is ~30 us for the U-Net, checked every 64th call and whenever the cheap root-level check
-    fails), and on first use the result is checked against `module.parameters()` (a parameter shared between two modules would
-    be yielded twice here: de-duplicated by identity)."""
+    live, in the order `parameters()` yields.  The cached list is dropped when the module tree changes: the root's direct children
+    are compared on EVERY call (count + identities, ~1 us), the whole tree's fingerprint (~30 us for the U-Net) on every 64th —
+    a submodule replaced deeper down is seen within 64 calls, one replaced at the root at once — and on first use the result is
+    checked against `module.parameters()` (a parameter shared between two modules would be yielded twice here: de-duplicated
+    by identity)."""
     cache = module.__dict__.get("_dxmi_param_modules")
     if cache is not None:
         cache[2] += 1
-        if cache[2] & 63 == 0 and _tree_fingerprint(module) != cache[1]:
+        subs = module._modules
+        if len(subs) != len(cache[4]) or any(a is not b for a, b in zip(subs.values(), cache[4])):
+            cache = None
+        elif cache[2] & 63 == 0 and _tree_fingerprint(module) != cache[1]:
             cache = None
     if cache is None:
         # every submodule, also those without parameters today: the samplers register `log_betas` on a net after construction
         mods = list(module.modules())
-        cache = [mods, _tree_fingerprint(module), 0, False]
+        cache = [mods, _tree_fingerprint(module), 0, False, tuple(module._modules.values())]
         module.__dict__["_dxmi_param_modules"] = cache
         seen = set()
         flat = [prm for m in mods for prm in m._parameters.values() if prm is not None and not (id(prm) in seen or seen.add(id(prm)))]
@@ -542,8 +546,9 @@ def groupnorm_silu_bwd(x, dy, gamma, beta, *, in1=None, add0=None, add1=None, gr
     assert dy.dtype == torch.bfloat16 and dy.is_contiguous() and tuple(dy.shape) == (N, H, W, C)
     # 12 channels per group on the large maps (the 384-channel concat inputs of the CIFAR net's up path): the register-resident kernel
     # slices them badly (414 us at 32x32, 101 us at 16x16, B = 256) and the generic three-launch path is ahead (285 / 79 us:
-    # tools/gn_bwd_time.py); every other shape of the net is faster on the resident kernel
-    slow_resident = (C // groups) % 4 == 0 and (C // groups) % 8 != 0 and (C // groups) > 4 and H * W >= 256
+    # tools/gn_bwd_time.py); every other shape of the net is faster on the resident kernel.  Only the MEASURED case is routed away
+    # (20 / 28 / 36 ... channels per group stay where they were)
+    slow_resident = (C // groups) == 12 and H * W >= 256
     if slow_resident or not load().dxmi_groupnorm_silu_bwd_supported(C0, C1, H * W, groups):
         # shapes the register-resident backward cannot slice (the forward falls back the same way): generic three-launch path
         dx0, dx1, dg, db, _ = groupnorm_generic_bwd(x, dy, gamma, beta, in1=in1, add0=add0, add1=add1, groups=groups, eps=eps, silu=silu)

@@ -17,8 +17,13 @@ class TimeIndependentValue(nn.Module):
         the TD target and the TD prediction of one step (models.modules.IGEBMEncoderV2.forward_pair)."""
         if y is not None or not hasattr(self.net, "forward_pair"):
             import torch
-            with torch.no_grad():
-                tgt = self.forward(x_free, t_free, y=y)
+            was_training = self.net.training
+            self.net.eval()                    # the reference evaluates the TD target under eval() (trainer.py:288-300)
+            try:
+                with torch.no_grad():
+                    tgt = self.forward(x_free, t_free, y=y)
+            finally:
+                self.net.train(was_training)
             return tgt, self.forward(x_grad, t_grad, y=y)
         return self.net.forward_pair(x_free, x_grad)
 

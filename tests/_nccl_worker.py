@@ -80,6 +80,9 @@ def main():
                           "nccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()),
                           "flat_bytes": [(tr.sync_v.flat.numel() - tr.sync_v.nflags) * 4, (tr.sync_sampler.flat.numel() - tr.sync_sampler.nflags) * 4],
                           "flags": [tr.sync_v.nflags, tr.sync_sampler.nflags],
+                          "raw_bytes": [sum(p.numel() for p in s_.params) * 4 for s_ in (tr.sync_v, tr.sync_sampler)],
+                          "padded_bytes": [sum((p.numel() + 3) // 4 * 4 for p in s_.params) * 4 for s_ in (tr.sync_v, tr.sync_sampler)],
+                          "slices_16B_aligned": all(v.data_ptr() % 16 == 0 for s_ in (tr.sync_v, tr.sync_sampler) for v in s_.views),
                           "grads_alias_flat": all(p.grad is None or p.grad.data_ptr() == v.data_ptr()
                                                   for s_ in (tr.sync_v, tr.sync_sampler) for p, v in zip(s_.params, s_.views))}))
     dist.barrier()

@@ -551,7 +551,46 @@ def gen_fid():
     save("fid_stats", **out)
 
 
-GENS = {"trainer_ev": gen_trainer_ev, "fid": gen_fid, "schedule": gen_schedule, "unet": gen_unet_forward, "var_sampling": gen_var_sampling,
+def gen_beta_variants():
+    """The learnable-sigma options that had no fixture (round-5 VERDICT): VARSampler(trainable_beta=True) — every step's sigma read
+    from net.log_betas, the last one included (var_sampler.py:383-394) — and OpenAIDiffusion(trainable_beta in {True, 'fix_last3'})
+    (openai_diffusion.py:76-84).  log_betas are moved off their initial values (stored with the fixture) so that a path that
+    reads the fixed table instead cannot pass."""
+    import contextlib, io
+    import models.DxMI.openai_diffusion as ref_oa
+    net, s = build_sampler(10, trainable_beta=True)
+    with torch.no_grad():
+        net.log_betas.add_(0.05 * torch.arange(10, dtype=torch.float32) - 0.2)
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(6, 3, 32, 32, generator=g)
+    t = torch.tensor([0, 9, 3, 9, 7, 1])
+    seed = 4343
+    torch.manual_seed(seed)
+    z = torch.randn_like(x)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        d = s.sample_step(x, t)
+    save("sample_step_T10_allbeta", seed=seed, x=x, t=t, z=z, log_betas=net.log_betas.detach(), **{k: v for k, v in d.items()})
+    for tag, tb in (("fixlast3", "fix_last3"), ("allbeta", True)):
+        net, diffusion = build_edm()
+        with contextlib.redirect_stdout(io.StringIO()):
+            se = ref_oa.OpenAIDiffusion(net, diffusion, n_timesteps=6, sample_shape=(3, 16, 16), class_cond=True, num_classes=1000,
+                                        trainable_beta=tb, stochastic_last=True, rho=4.0)
+        with torch.no_grad():
+            net.log_betas.add_(0.07 * torch.arange(net.log_betas.numel(), dtype=torch.float32) - 0.15)
+        g = torch.Generator().manual_seed(32)
+        xe = torch.randn(6, 3, 16, 16, generator=g) * 3
+        idx = torch.tensor([0, 5, 3, 2, 4, 1])
+        y = torch.tensor([3, 977, 1, 50, 400, 999])
+        torch.manual_seed(seed + 1)
+        ze = torch.randn_like(xe)
+        torch.manual_seed(seed + 1)
+        with torch.no_grad():
+            ds = se.sample_step(xe, idx, y=y)
+        save(f"edm_sample_step_T6_{tag}", seed=seed + 1, x=xe, idx=idx, y=y, z=ze, log_betas=net.log_betas.detach(), **ds)
+
+
+GENS = {"beta_variants": gen_beta_variants, "trainer_ev": gen_trainer_ev, "fid": gen_fid, "schedule": gen_schedule, "unet": gen_unet_forward, "var_sampling": gen_var_sampling,
         "sample_step": gen_sample_step, "value": gen_value, "trainer": gen_trainer_step, "trainer_T4": gen_trainer_step_T4_resample, "log_prob": gen_log_prob_step, "output": gen_output_stage, "guidance": gen_guidance, "edm": gen_edm, "edm_trainer": gen_edm_trainer}
 
 if __name__ == "__main__":

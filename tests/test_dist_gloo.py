@@ -319,11 +319,12 @@ def test_train_step_collective_sequence_world4_gloo():
     #   (T+1) x [value net: one bucket = gradients + 4 flags]  +  nb U-Net buckets  +  1 bucket of the untouched module
     # collectives per train step = (T + 1) + n_buckets, exactly (+ 1 here for the module nobody touched)
     T = 3
-    nv = sum(p.numel() for p in torch.nn.Sequential(torch.nn.Linear(12, 24), torch.nn.LeakyReLU(0.2), torch.nn.Linear(24, 1)).parameters())
+    pad4 = lambda n: (n + 3) // 4 * 4          # every parameter's slice of the flat buffer starts on a 16-byte boundary (fp32 wire)
+    nv = sum(pad4(p.numel()) for p in torch.nn.Sequential(torch.nn.Linear(12, 24), torch.nn.LeakyReLU(0.2), torch.nn.Linear(24, 1)).parameters())
     sizes = [n for n, _, _ in logs[0]]
     assert sizes[:T + 1] == [nv + 4] * (T + 1)
     assert len(sizes) == (T + 1) + nb + 1
-    nu = 12 * 32 + 32 + 2 * (32 * 32 + 32) + 32 * 12 + 12 + T
+    nu = 12 * 32 + 32 + 2 * (32 * 32 + 32) + 32 * 12 + 12 + pad4(T)
     assert sum(sizes[T + 1:T + 1 + nb]) == nu + 9          # the U-Net's buckets: every gradient once + 9 flags in the last one
     assert sizes[-1] == 4 * 4 + 4 + 2
     assert res[0][5] >= 1 and res[2][5] < nb           # buckets launched DURING backward; rank 2 holds one back until sync()
@@ -340,3 +341,79 @@ def test_train_step_collective_sequence_world4_gloo():
             assert np.allclose(res[r][3]["unet"][k], want, atol=1e-6), k
             assert np.array_equal(res[r][3]["unet"][k], like), k
     assert res[2][2]["unet"]["attn.weight"] is None    # the missing gradients really were missing on rank 2
+
+
+def _captured_sync_worker(rank, world, port, q):
+    """FlatGradSync's exchange of a step that is being captured into hipGraphs (dist.py `_sync_captured`), with the graph replaced
+    by a stand-in whose `cut(fn)` just runs `fn` (there are no graphs on the CPU): the pack / collectives-at-the-cut / re-bind
+    sequence must give what the eager, overlapped sync gives, with one collective per bucket in bucket order."""
+    sys.path.insert(0, os.path.join(ROOT, "diffusion-by-maxentirl_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dxmi_hip import graph as hip_graph
+    from dxmi_hip.dist import FlatGradSync
+    torch.manual_seed(3)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 300), torch.nn.ReLU(), torch.nn.Linear(300, 7), torch.nn.ReLU(), torch.nn.Linear(7, 1))
+    fs = FlatGradSync(m, bucket_mb=0.004)          # ~1 k elements per bucket: several buckets
+    x = torch.randn(5, 8, generator=torch.Generator().manual_seed(10 + rank))
+    m(x).sum().backward()
+    local = [p.grad.clone() for p in m.parameters()]
+    fs()                                            # eager, overlapped: allocates the flat buffer; reference result
+    eager = [p.grad.clone() for p in m.parameters()]
+    for p in m.parameters():
+        p.grad = None
+
+    class Cap:
+        cuts = 0
+
+        def cut(self, fn):
+            Cap.cuts += 1
+            prev, hip_graph._CURRENT = hip_graph._CURRENT, None      # the cut's function runs un-captured
+            try:
+                fn()
+            finally:
+                hip_graph._CURRENT = prev
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (calls.append(int(t.numel())), orig(t, *a, **k))[1]
+    cap = Cap()
+    hip_graph._CURRENT = cap
+    try:
+        m(x).sum().backward()                      # hooks must stay quiet while capturing
+        assert not calls
+        fs()
+    finally:
+        hip_graph._CURRENT = None
+        dist.all_reduce = orig
+    got = [p.grad.clone() for p in m.parameters()]
+    aliased = all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(fs.params, fs.views))
+    q.put((rank, [g.numpy() for g in local], [g.numpy() for g in eager], [g.numpy() for g in got], calls, Cap.cuts,
+           [b[1] - b[0] for b in fs.buckets], aliased))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_captured_sync_matches_eager_sync_gloo():
+    import socket
+    import numpy as np
+    world = 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_captured_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(world):
+        _, local, eager, got, calls, cuts, bucket_sizes, aliased = res[r]
+        assert cuts == 1 and calls == bucket_sizes and len(bucket_sizes) >= 2 and aliased
+        for i in range(len(got)):
+            want = sum(res[k][1][i] for k in range(world)) / world
+            assert np.allclose(got[i], want, atol=1e-6)
+            assert np.array_equal(got[i], eager[i]) and np.array_equal(got[i], res[0][3][i])

@@ -147,3 +147,25 @@ def test_product_refuses_cpu_tensors():
                     attention_resolutions=(2,), channel_mult=(1, 2), num_head_channels=64)
     with pytest.raises(DxmiError):
         net(torch.zeros(1, 3, 16, 16), torch.zeros(1))
+
+
+@pytest.mark.parametrize("tag,tb", [("fixlast3", "fix_last3"), ("allbeta", True)])
+def test_edm_sample_step_learnable_sigma_variants(golden_dir, tag, tb):
+    """OpenAIDiffusion(trainable_beta in {'fix_last3', True}) (openai_diffusion.py:76-84) at T = 6, log_betas off their initial
+    values: the last three steps keep the ancestral sigma_up under 'fix_last3', none does under True."""
+    cfg = VARIANTS[""]
+    g = load(golden_dir, f"edm_sample_step_T6_{tag}")
+    sd = formula_sd(cfg)
+    sch = edm.EDMSchedule(6, stochastic_last=True, rho=4.0, trainable_beta=tb)
+    lb = torch.from_numpy(g["log_betas"])
+    idx = torch.from_numpy(g["idx"])
+    with torch.no_grad():
+        ds = edm.sample_step(oracle_model(sd, cfg), sch, torch.from_numpy(g["x"]), idx, torch.from_numpy(g["z"]), log_betas=lb,
+                             y=torch.from_numpy(g["y"]))
+    for k in ("sample", "mean", "sigma"):
+        np.testing.assert_allclose(ds[k].numpy(), g[k], rtol=0, atol=1e-5, err_msg=k)
+    learned = torch.exp(lb)[idx].clamp(1e-4, None).numpy()
+    fixed = sch.sigma_up[idx].clamp(1e-4, None).numpy()
+    uses_learned = np.isclose(g["sigma"], learned, rtol=1e-6)
+    want = (idx.numpy() < 3) if tb == "fix_last3" else np.ones(len(idx), bool)
+    assert (uses_learned == want).all() and np.isclose(g["sigma"][~want], fixed[~want], rtol=1e-6).all()

@@ -45,7 +45,10 @@ def test_trainer_step_under_rccl():
     line = _run_ranks()
     world = torch.cuda.device_count()
     assert line["backend"] == "nccl" and line["world"] == world and line["finite"]
-    assert line["flat_bytes"][0] == 5_134_595 * 4 and line["flat_bytes"][1] == (35_746_307 + 4) * 4
+    assert line["raw_bytes"][0] == 5_134_595 * 4 and line["raw_bytes"][1] == (35_746_307 + 4) * 4
+    # every parameter's slice of the flat buffer starts on a 16-byte boundary (round-5 ADVICE: .grad IS the slice after sync(), and
+    # the multi-tensor Adam / norm / clip kernels take their f32x4 path only on aligned pointers)
+    assert line["flat_bytes"] == line["padded_bytes"] and line["slices_16B_aligned"]
     # round 5: one "used on some rank" flag per parameter rides in the tail of the last bucket (33 value-net tensors, the 329 trainable tensors of the sampler)
     assert line["flags"] == [33, 329]
     assert line["mean_rel_err"] < 1e-6

@@ -290,6 +290,24 @@ def test_sampling_T4_vs_reference(golden_dir, tag):
     np.testing.assert_allclose(ds["sigma"].cpu().numpy(), g["sigma"], rtol=1e-6)
 
 
+@pytest.mark.parametrize("tag,tb", [("fixlast3", "fix_last3"), ("allbeta", True)])
+def test_edm_sample_step_learnable_sigma_variants(golden_dir, tag, tb):
+    """OpenAIDiffusion(trainable_beta in {'fix_last3', True}) against the reference's step at T = 6 (openai_diffusion.py:76-84),
+    log_betas off their initial values."""
+    from models.DxMI.openai_diffusion import OpenAIDiffusion
+    net, diffusion, _ = build(TINY_KW)
+    s = OpenAIDiffusion(net, diffusion, n_timesteps=6, sample_shape=(3, 16, 16), class_cond=True, num_classes=1000, trainable_beta=tb,
+                        stochastic_last=True, rho=4.0)
+    net.to(DEV)
+    g = load(golden_dir, f"edm_sample_step_T6_{tag}")
+    with torch.no_grad():
+        net.log_betas.copy_(torch.from_numpy(g["log_betas"]))
+        ds = s.sample_step(torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["idx"]), noise=torch.from_numpy(g["z"]).to(DEV),
+                           y=torch.from_numpy(g["y"]).to(DEV))
+    assert rel_l2(ds["sample"].cpu(), g["sample"]) < 2e-2 and rel_l2(ds["mean"].cpu(), g["mean"]) < 2e-2
+    np.testing.assert_allclose(ds["sigma"].cpu().numpy(), g["sigma"], rtol=1e-6)
+
+
 def test_imagenet64_unet_full_size_vs_oracle():
     """configs/imagenet64 network (192 ch, 3 res blocks, (1,2,3,4), attention at 32/16/8, class-cond,
     scale-shift, resblock up/down; 295.9M parameters) at 64x64 against the fp32 oracle on the CPU."""

@@ -64,8 +64,8 @@ def test_unet_forward_vs_reference_and_oracle(golden_dir, sampler10):
     assert y.shape == (2, 3, 32, 32) and y.dtype == torch.float32
     r_ref, r_orc = rel_l2(y, g["y"]), rel_l2(y, yo)
     print(f"unet forward: rel-L2 vs reference fp32 {r_ref:.3e}, vs oracle bf16-model {r_orc:.3e}")
-    assert r_ref < 1.2e-2, r_ref
-    assert r_orc < 1.2e-2, r_orc
+    assert r_ref < 1e-2, r_ref             # the bound the docstring / SURVEY 7 state (measured 8.7e-3)
+    assert r_orc < 1e-2, r_orc
     th, to = dict(trace_h), dict(trace_o)
     nchw = lambda a: a.float().cpu().permute(0, 3, 1, 2)
     # temb MLP (fp32 rows): accumulation-order noise only
@@ -189,6 +189,28 @@ def test_sample_step_vs_reference(golden_dir, name, tb):
     with torch.no_grad():
         d2 = s.sample_step(x.to(DEV), 3, noise=z.to(DEV))
     assert torch.allclose(d2["sigma"].flatten(), d["sigma"].flatten()[2].expand(6))
+
+
+def test_sample_step_all_learnable_sigma_vs_reference(golden_dir):
+    """VARSampler(trainable_beta=True): every sigma from net.log_betas, the last step included (reference var_sampler.py:383-394),
+    with log_betas moved off their initial values — both the fused no-grad transition and the autograd one."""
+    s, _ = make_sampler(10, True)
+    g = load(golden_dir, "sample_step_T10_allbeta")
+    with torch.no_grad():
+        s.net.log_betas.copy_(torch.from_numpy(g["log_betas"]))
+    x, t, z = (torch.from_numpy(g[k]).to(DEV) for k in ("x", "t", "z"))
+    with torch.no_grad():
+        d = s.sample_step(x, t, noise=z)
+    dg = s.sample_step(x, t, noise=z)              # parameters ask for gradients: the differentiable transition
+    for dd in (d, dg):
+        for k in ("sample", "mean", "control"):
+            assert rel_l2(dd[k].detach().cpu(), g[k]) < 1e-2, k
+        for k in ("sigma", "entropy"):
+            assert dd[k].shape == g[k].shape and rel_l2(dd[k].detach().cpu(), g[k]) < 1e-6, k
+        assert rel_l2(dd["logp"].detach().cpu(), g["logp"]) < 1e-4
+    dg["entropy"].sum().backward()
+    want = torch.bincount(t.cpu(), minlength=10).float()          # d sum(log sigma_t) / d log_betas = visits per step, last one too
+    assert torch.allclose(s.net.log_betas.grad.cpu(), want)
 
 
 def test_host_schedule_tables_bit_exact(golden_dir, sampler10):

@@ -183,3 +183,23 @@ def test_log_prob_step_matches_reference(golden_dir):
         got = got if rows < 0 else got[:rows]
         ref = g[f"grad_{i}"]
         assert np.linalg.norm(got - ref) <= 3e-4 * np.linalg.norm(ref), k
+
+
+def test_sample_step_all_learnable_sigma_matches_reference(golden_dir):
+    """VARSampler(trainable_beta=True): every step's sigma from net.log_betas, the last one included (var_sampler.py:383-394);
+    the fixture's log_betas are off their initial values."""
+    g = load(golden_dir, "sample_step_T10_allbeta")
+    keys = load(golden_dir, "schedule")["T10_state_dict_keys"]
+    sd = unet_state_dict(keys, 10)
+    sched = _sched_t(10)
+    lb = torch.from_numpy(g["log_betas"])
+    assert not torch.allclose(lb, sched["log_betas"])
+    cfg = ounet.UNetSmallConfig()
+    with torch.no_grad():
+        d = ovs.sample_step(lambda xx, tt: ounet.forward(sd, cfg, xx, tt), sched, lb, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]),
+                            torch.from_numpy(g["z"]), trainable_beta=True)
+    for key in ("sample", "mean", "control", "sigma", "entropy", "logp"):
+        got, ref = d[key].numpy(), g[key]
+        assert got.shape == ref.shape, key
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 2e-5, key
+    np.testing.assert_allclose(d["sigma"].flatten().numpy(), np.exp(g["log_betas"])[g["t"]], rtol=1e-6)
