@@ -494,8 +494,18 @@ def main():
             return tt.item()
         return x
 
-    for _ in range(args.warmup + (2 if use_graph else 0)):     # (+ the eager first call and the capture call of the hipGraph: never timed)
-        step()
+    graph_errors = {}
+    try:
+        for _ in range(args.warmup + (2 if use_graph else 0)):     # (+ the eager first call and the capture call of the hipGraph: never timed)
+            step()
+    except Exception as e:          # a capture that fails on this box must not cost the measurement: issue the launches from python
+        if not use_graph:
+            raise
+        graph_errors["generation"] = repr(e)[:300]
+        use_graph = sampler.use_graph = False
+        torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            step()
     # ---- timed region: exactly K steps between barrier + synchronize brackets; one event per step for the median
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     sync_all()
@@ -542,8 +552,18 @@ def main():
         ring = TransitionRing(1, T, B, (3, 32, 32), device)
         gimg = torch.Generator(device=device).manual_seed(112233 + rank)
         imgs = torch.rand(B, 3, 32, 32, device=device, generator=gimg) * 2 - 1
-        for _ in range(3):                                   # warm-up (weight packing, workspaces, optimiser state, allocator growth; the second step is the graph capture)
-            train_step(tr, sampler, imgs, device, ring)
+        try:
+            for _ in range(3):                               # warm-up (weight packing, workspaces, optimiser state, allocator growth; the second step is the graph capture)
+                train_step(tr, sampler, imgs, device, ring)
+        except Exception as e:
+            if not use_graph:
+                raise
+            graph_errors["train"] = repr(e)[:300]
+            use_graph = sampler.use_graph = tr.use_graphs = False
+            torch.cuda.synchronize()
+            ring.reset()
+            for _ in range(2):
+                train_step(tr, sampler, imgs, device, ring)
         sync_all()
         t1 = time.perf_counter()
         for _ in range(args.train_steps):
@@ -624,19 +644,31 @@ def main():
                                                     "traffic": pmc_traffic(kernel_name(k[1]))[0]} for k, v in convs.items()}
     if train_summ:
         line["train_roofline_classes"] = class_rooflines(train_summ, t_train_step)
+    def guarded(fn, *a, **k):
+        """A leg with hipGraph replay; if the capture fails on this box the leg is measured without it (and says so)."""
+        try:
+            return fn(*a, **k)
+        except Exception as e:
+            if not k.get("graph"):
+                raise
+            graph_errors[fn.__name__] = repr(e)[:300]
+            torch.cuda.synchronize()
+            k["graph"] = False
+            return fn(*a, **k)
+
     if world == 1 and not args.no_edm:
         # BASELINE configs[3] / [4] (EDM backbones) at their per-GPU sizes + the EDM train step: rank 0, outside the timed region
         line["edm"] = {"imagenet64_T10_b100": edm_generation_leg(device, "imagenet64_T10", 100, events=not args.no_events),
                        "lsun_bedroom_T4_b16": edm_generation_leg(device, "lsun_bedroom_T4", 16, events=not args.no_events),
-                       "imagenet64_T10_train_b16": edm_train_leg(device, graph=use_graph)}
+                       "imagenet64_T10_train_b16": guarded(edm_train_leg, device, graph=use_graph)}
     if world == 1 and not args.no_small_batch:
         # the per-rank batches of the reference's multi-GPU runs (global batch // N), on this one GPU: hipGraph replay vs python issue
         line["small_batch"] = {
             "cifar10_T10_b32": {"what": "configs[1] at 8 GPUs: 256 // 8 images per rank, T = 10",
-                                "graph": small_batch_leg(device, 32, 10, use_graph), "eager": small_batch_leg(device, 32, 10, False)},
+                                "graph": guarded(small_batch_leg, device, 32, 10, graph=use_graph), "eager": small_batch_leg(device, 32, 10, graph=False)},
             "cifar10_T4_b128": {"what": "configs[2] at 4 GPUs: 512 // 4 images per rank, T = 4, value_resample (T4_ddgan.yaml)",
-                                "graph": small_batch_leg(device, 128, 4, use_graph, value_resample=True),
-                                "eager": small_batch_leg(device, 128, 4, False, value_resample=True)}}
+                                "graph": guarded(small_batch_leg, device, 128, 4, graph=use_graph, value_resample=True),
+                                "eager": small_batch_leg(device, 128, 4, graph=False, value_resample=True)}}
     if world == 1 and not args.no_eager_reference:
         eg = eager_reference_gpu(device, T, B)
         line["reference_eager_gpu"] = {
@@ -664,6 +696,8 @@ def main():
                                           "not finished within 45 s); one repetition each; the better one is `value`"}
     # the scalars a reader of the driver's record needs, flat and EARLY in the line (its tail is cut)
     flat = {"train_steps_per_sec": train_sps, "hip_graph": use_graph}
+    if graph_errors:
+        line["hip_graph_errors"] = graph_errors
     if "edm" in line:
         flat.update({"c4_images_per_sec": line["edm"]["imagenet64_T10_b100"]["images_per_sec"],
                      "c5_images_per_sec": line["edm"]["lsun_bedroom_T4_b16"]["images_per_sec"],

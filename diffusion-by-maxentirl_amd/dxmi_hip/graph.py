@@ -88,6 +88,29 @@ class StepGraph:
         self.producers.append(fill)
         return self.stage_dev[off:off + nbytes].view(dtype)
 
+    # ------------------------------------------------------------------ a second captured stream (fork / join inside the graph)
+    def fork_side(self, reads=()):
+        """-> a side stream that has been made to wait for everything captured so far on the current stream: work launched on it
+        becomes a parallel branch of the hipGraph (weight-gradient kernels next to the data-gradient chain of a backward: at the
+        per-rank batches of a multi-GPU run one kernel does not fill 256 CUs).  reads: tensors allocated on the main stream that the
+        branch reads — their blocks are held until the capture ends (record_stream), since the main stream is free to drop them
+        while the branch is still pending.  `join_side()` before anything on the main stream consumes the branch's results."""
+        if _CURRENT is not self:
+            raise DxmiError("StepGraph.fork_side outside this graph's capture")
+        if self.side is None:
+            self.side = torch.cuda.Stream(self.device)
+        self.side.wait_stream(torch.cuda.current_stream(self.device))
+        for t in reads:
+            if t is not None:
+                t.record_stream(self.side)
+        self.forked = True
+        return self.side
+
+    def join_side(self):
+        if self.forked:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self.forked = False
+
     def cut(self, eager_fn):
         """End the graph segment here, run `eager_fn()` un-captured (now and between the two launches of every replay), start the
         next segment."""
@@ -106,6 +129,7 @@ class StepGraph:
         self._g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
 
     def _end_segment(self):
+        self.join_side()                         # a capture cannot end with an un-joined branch
         self._g.capture_end()
         self.segments.append(("graph", self._g))
         self._upload()
@@ -128,6 +152,7 @@ class StepGraph:
         self.stage_dev = torch.zeros(self.stage_bytes, dtype=torch.uint8, device=dev)
         self.uploaded = torch.cuda.Event()
         self.used, self.producers, self.segments = 0, [], []
+        self.side, self.forked = None, False
         for m in self.modules:
             m.prepare_capture()
         self.static_in = [a.detach().clone() if torch.is_tensor(a) and not getattr(a, "_dxmi_static", False) else a for a in args]

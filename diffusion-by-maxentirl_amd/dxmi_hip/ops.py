@@ -449,7 +449,44 @@ def _workspace(nbytes, device):
     return buf
 
 
-def conv2d_wgrad(x, dy, ksize, *, in1=None, pad=None, stride=1, upsample=False, out=None, accumulate=False, with_bias=False):
+WGRAD_SIDE_STREAM = os.environ.get("DXMI_WGRAD_STREAM", "0") == "1"      # measured slower on gfx950 (B = 32: 35.9 -> 38.9 ms per train step, B = 256: 90.0 -> 92.5): off unless asked for
+
+
+class wgrad_branch:
+    """`with ops.wgrad_branch(reads):` — inside a StepGraph capture the block's launches go to the graph's SIDE stream (a parallel
+    branch behind everything captured so far: StepGraph.fork_side); outside a capture, or with DXMI_WGRAD_STREAM=0, a no-op.
+    Weight gradients have no consumer until the optimiser: the backward's data-gradient chain need not wait for them.
+    `ops.wgrad_join()` before their first consumer on the main stream (the end of every autograd backward here)."""
+
+    def __init__(self, reads=()):
+        self.reads, self.ctx = reads, None
+
+    def __enter__(self):
+        cap = _graph.current()
+        if cap is not None and WGRAD_SIDE_STREAM and PROFILER is None:
+            self.ctx = torch.cuda.stream(cap.fork_side(self.reads))
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def wgrad_join():
+    cap = _graph.current()
+    if cap is not None:
+        cap.join_side()
+
+
+def conv2d_wgrad(x, dy, ksize, **kw):
+    """Weight gradient of a conv (see _conv2d_wgrad); inside a captured step it runs as a parallel branch (wgrad_branch)."""
+    with wgrad_branch((x, dy, kw.get("in1"), kw.get("out"))):
+        return _conv2d_wgrad(x, dy, ksize, **kw)
+
+
+def _conv2d_wgrad(x, dy, ksize, *, in1=None, pad=None, stride=1, upsample=False, out=None, accumulate=False, with_bias=False):
     """Weight gradient of a conv: x [N,IH,IW,C0] (| in1), dy [N,OH,OW,Cout] NHWC bf16 ->
     fp32 OIHW [Cout, C0+C1, k, k] (written, or added when accumulate).  with_bias: also the bias gradient
     (column sums of dy) from the same launch -> (dw, db)."""
@@ -979,10 +1016,11 @@ def stem_conv_wgrad(x_nchw, dy):
     _need_cuda(x_nchw, dy)
     N, C, H, W = x_nchw.shape
     assert C == 3 and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
-    cols = torch.empty((N, H, W, 64), dtype=torch.bfloat16, device=x_nchw.device)
-    check(load().dxmi_im2col27(_ptr(x_nchw), _ptr(cols), N, H, W, _stream()), "dxmi_im2col27")
-    dw = conv2d_wgrad(cols, dy, 1)                      # [Cout, 64, 1, 1]
-    return dw[:, :27, 0, 0].reshape(dy.shape[3], 3, 3, 3).contiguous()
+    with wgrad_branch((x_nchw, dy)):                    # (im2col, the pixel-GEMM and the slice: one branch of a captured step)
+        cols = torch.empty((N, H, W, 64), dtype=torch.bfloat16, device=x_nchw.device)
+        check(load().dxmi_im2col27(_ptr(x_nchw), _ptr(cols), N, H, W, _stream()), "dxmi_im2col27")
+        dw = _conv2d_wgrad(cols, dy, 1)                 # [Cout, 64, 1, 1]
+        return dw[:, :27, 0, 0].reshape(dy.shape[3], 3, 3, 3).contiguous()
 
 
 def quantize_u8(x, mode=0, nhwc=True, out=None):

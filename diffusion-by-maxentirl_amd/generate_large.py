@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--fid_stats", type=str, default=None, help="npz with the dataset's `mu` / `sigma` (reference: datasets/VIRTUAL_*.npz)")
     ap.add_argument("--fid_dims", type=int, default=2048)
     ap.add_argument("--synthetic", type=str, default=None, help="builtin config name, e.g. imagenet64_T10 (random weights)")
+    ap.add_argument("--no_graph", action="store_true", help="issue every launch from python instead of replaying the T-step loop of a "
+                                                           "batch as one hipGraph (dxmi_hip/graph.py; DXMI_GRAPH=0 does the same)")
     args, unknown = ap.parse_known_args()
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -85,6 +87,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.distributed.init_process_group(backend="nccl", init_method="env://")  # RCCL
 
+    from dxmi_hip import graph as hip_graph
+    sampler.use_graph = hip_graph.default_enabled() and not args.no_graph        # second batch onwards: one hipGraphLaunch per batch
     n_batches = int(args.n_sample / args.batchsize / world)
     l_sample, i_img = [], 0
     from dxmi_hip import ops

@@ -154,8 +154,9 @@ class _UNetFn(torch.autograd.Function):
         H = d_eps.shape[2]
         d_pad = torch.zeros((N, H, H, 64), dtype=torch.bfloat16, device=dev)
         d_pad[..., : d_eps.shape[1]] = d_eps.permute(0, 2, 3, 1).to(torch.bfloat16)
-        wg = ops.conv2d_wgrad(ctx.a_out, d_pad, 3)
-        grads[net.conv_out.weight] = wg[: net.out_ch].contiguous()
+        with ops.wgrad_branch((ctx.a_out, d_pad)):       # (captured step: a parallel branch, joined at the end of this backward)
+            wg = ops._conv2d_wgrad(ctx.a_out, d_pad, 3)
+            grads[net.conv_out.weight] = wg[: net.out_ch].contiguous()
         grads[net.conv_out.bias] = d_eps.float().sum((0, 2, 3))
         d_a = ops.conv2d(d_pad, pkt["conv_out"])
         g, _, dg, db = ops.groupnorm_silu_bwd(ctx.h_last, d_a, net.norm_out.weight, net.norm_out.bias, silu=True)
@@ -206,10 +207,11 @@ class _UNetFn(torch.autograd.Function):
             d_a = ops.conv2d(g, pkt[id(m), "proj"])
             d_qkv = ops.attention_bwd(qkv.view(Nn, Hh * Ww, 3 * C), d_a.view(Nn, Hh * Ww, C), 1, float(int(C) ** (-0.5)))
             d_qkv = d_qkv.view(Nn, Hh, Ww, 3 * C)
-            wq, bq = ops.conv2d_wgrad(hn, d_qkv, 1, with_bias=True)       # the bias gradient from the dY tiles the kernel stages anyway
-            for j, conv in enumerate((m.q, m.k, m.v)):
-                grads[conv.weight] = wq[j * C:(j + 1) * C].contiguous()
-                grads[conv.bias] = bq[j * C:(j + 1) * C].contiguous()
+            with ops.wgrad_branch((hn, d_qkv)):
+                wq, bq = ops._conv2d_wgrad(hn, d_qkv, 1, with_bias=True)   # the bias gradient from the dY tiles the kernel stages anyway
+                for j, conv in enumerate((m.q, m.k, m.v)):
+                    grads[conv.weight] = wq[j * C:(j + 1) * C].contiguous()
+                    grads[conv.bias] = bq[j * C:(j + 1) * C].contiguous()
             d_hn = ops.conv2d(d_qkv, pkt[id(m), "qkv"])
             d_x, _, dgn, dbn = ops.groupnorm_silu_bwd(xa, d_hn, m.norm.weight, m.norm.bias, add0=g, silu=False)
             grads[m.norm.weight], grads[m.norm.bias] = dgn, dbn
@@ -283,6 +285,7 @@ class _UNetFn(torch.autograd.Function):
         de0 = ops.silu_bwd(e0, da0)
         _, grads[d0.weight], grads[d0.bias] = ops.linear_bwd(ctx.emb, de0, None, need_dx=False)
 
+        ops.wgrad_join()
         out = [None, dx, None]
         for prm in net.parameters():
             out.append(grads.get(prm))

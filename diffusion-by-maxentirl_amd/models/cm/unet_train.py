@@ -197,8 +197,9 @@ class _EDMUNetFn(torch.autograd.Function):
         H, W = d_out.shape[2], d_out.shape[3]
         d_pad = torch.zeros((N, H, W, 64), dtype=torch.bfloat16, device=dev)
         d_pad[..., : d_out.shape[1]] = d_out.permute(0, 2, 3, 1).to(torch.bfloat16)
-        wg = ops.conv2d_wgrad(ctx.a_out, d_pad, 3)
-        grads[net.out[2].weight] = wg[: net.out_channels].contiguous()
+        with ops.wgrad_branch((ctx.a_out, d_pad)):       # (captured step: a parallel branch, joined at the end of this backward)
+            wg = ops._conv2d_wgrad(ctx.a_out, d_pad, 3)
+            grads[net.out[2].weight] = wg[: net.out_channels].contiguous()
         grads[net.out[2].bias] = d_out.float().sum((0, 2, 3))
         d_a = ops.conv2d(d_pad, pkt["conv_out"])
         g, _, _ = gn_bwd(net.out[0], ctx.h_last, d_a, fwd_stats=ctx.s_out)
@@ -331,6 +332,7 @@ class _EDMUNetFn(torch.autograd.Function):
         de0 = ops.silu_bwd(e0, da0)
         _, grads[l0.weight], grads[l0.bias] = ops.linear_bwd(ctx.sinus, de0, None, need_dx=False)
 
+        ops.wgrad_join()
         out = [None, dx, None, None]
         for prm in net.parameters():
             out.append(grads.get(prm))

@@ -107,6 +107,7 @@ class _ValueNetFn(torch.autograd.Function):
         if ctx.need_dx:
             # data gradient of the stem: 128 -> 3 channel conv on flipped weights, fp32 NCHW out
             dx = ops.conv2d(d_a0, ops.pack_conv_weight(net.conv1.weight, transpose_flip=True), out_nchw_f32=True)
+        ops.wgrad_join()
         out = [None, None, dx]
         for prm in net.parameters():
             out.append(grads.get(prm))

@@ -84,6 +84,9 @@ def main():
                          "this image cannot download); with --fid_stats it enables the periodic fid() of training.fid_every")
     ap.add_argument("--fid_stats", type=str, default=None, help="dataset statistics npz (`mu`, `sigma`; reference: datasets/VIRTUAL_*.npz)")
     ap.add_argument("--fid_dims", type=int, default=2048)
+    ap.add_argument("--no_graph", action="store_true",
+                    help="issue every kernel launch from python instead of replaying the three phases of an iteration as hipGraphs "
+                         "(dxmi_hip/graph.py; DXMI_GRAPH=0 does the same)")
     args, unknown = ap.parse_known_args()
     d_cmd_cfg = cmd.parse_nested_args(cmd.parse_unknown_args(unknown))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -149,6 +152,10 @@ def main():
 
     trainer = dxmi_config.instantiate(cfg.trainer, batchsize=batchsize)
     trainer.set_models(v=v, sampler=sampler, optimizer=opt, optimizer_v=opt_v)
+    # an iteration is ~20 k launches at a per-rank batch of 16: replayed from hipGraphs (sampling, value update, the K policy
+    # iterations with the loss-scale bookkeeping on the device) the host no longer bounds it; gradient exchanges stay eager RCCL calls
+    from dxmi_hip import graph as hip_graph
+    trainer.use_graphs = sampler.use_graph = hip_graph.default_enabled() and not args.no_graph
 
     n_iter = cfg.training.n_iter if args.max_iters is None else min(cfg.training.n_iter, args.max_iters)
     # device-resident replay ring (one trajectory per iteration, generated in place by the sampler; sigma is 1-D here)

@@ -78,12 +78,13 @@ def test_bench_self_launch_over_visible_gpus():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     n = torch.cuda.device_count()
     r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "2", "--warmup", "1", "--train-steps", "1",
-                        "--no-cpu-baseline", "--no-eager-reference", "--no-edm", "--no-events"], cwd=root, capture_output=True, text=True,
+                        "--no-cpu-baseline", "--no-eager-reference", "--no-edm", "--no-events", "--no-small-batch"], cwd=root, capture_output=True, text=True,
                        timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     line = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert line["n_gpus"] == n and line["steps"] == 2 and line["value"] > 0 and line["train_steps_per_sec"] > 0
-    assert line["scaling"] == "weak" and line["config"]["images_per_gpu_per_step"] == 256
+    assert line["scaling"] == "weak" and line["config"]["images_per_gpu_per_step"] == 256 and line["hip_graph"] is True
+    assert "hip_graph_errors" not in line
     assert line["library"]["path"].endswith("libdxmi_hip.so") and line["library"]["dxmi_version"] >= 100
     if n > 1:
         assert line["rccl"]["world"] == n and len(line["per_rank_images_per_sec"]) == n
