@@ -194,6 +194,125 @@ __global__ __launch_bounds__(64) void value_head_bwd_kernel(const bf16* __restri
     }
 }
 
+// Parameter gradients of the value head from one launch (models/value_train.py: ~10 torch elementwise / reduce launches per backward,
+// twelve backwards per train step).  y = (s . w + b) * ow + ob with s = relu-sum features [N, C]; dy [N]:
+//   d_linear_w[c] = sum_n (dy[n] * ow) * s[n, c]     d_linear_b = sum_n dy[n] * ow
+//   d_ow = sum_n dy[n] * (s[n] . w + b)              d_ob = sum_n dy[n]
+// One workgroup, fixed summation order (n ascending per thread, then a fixed tree): bitwise reproducible.  out = [C + 3] fp32:
+// d_linear_w | d_linear_b | d_ow | d_ob.  ow == nullptr: no out_scale (the last two are written as zero).
+__global__ __launch_bounds__(256) void value_head_pgrad_kernel(const float* __restrict__ s, const float* __restrict__ w,
+                                                              const float* __restrict__ b, const float* __restrict__ dy,
+                                                              const float* __restrict__ ow, float* __restrict__ out, int N, int C) {
+    __shared__ float red[3][256];
+    const int tid = threadIdx.x;
+    const float scale = ow ? ow[0] : 1.f;
+    for (int c = tid; c < C; c += 256) {
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc += (dy[n] * scale) * s[(size_t)n * C + c];
+        out[c] = acc;
+    }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int n = tid; n < N; n += 256) {
+        float y = b[0];
+        for (int c = 0; c < C; ++c) y += s[(size_t)n * C + c] * w[c];
+        a0 += dy[n] * scale;
+        a1 += dy[n] * y;
+        a2 += dy[n];
+    }
+    red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            red[0][tid] += red[0][tid + o];
+            red[1][tid] += red[1][tid + o];
+            red[2][tid] += red[2][tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[C] = red[0][0];
+        out[C + 1] = ow ? red[1][0] : 0.f;
+        out[C + 2] = ow ? red[2][0] : 0.f;
+    }
+}
+
+// TD step of DxMI_Trainer.update_f_v on a replay ring (models/DxMI/trainer.py:278-300; reference trainer.py:271-300), data side in ONE
+// launch: the rows `state[r]` and (when next_rows) `next_state[r]` of the buffered transitions are gathered straight into the two
+// halves of the batch the value net evaluates ([next_state | state]: TD target and TD prediction share one forward), and the
+// running cost ||x' - x||^2 / (2 beta) averaged over CHW (trainer.py:163-169) is reduced on the way.  INT path: rows are int64
+// indices into the ring's [rows, CHW] fp32 trajectory block; an index outside [0, n_src_rows) poisons the row with NaN.
+// next_dense: the re-drawn next states of `value_resample` (already dense [B, CHW]) instead of a gather.  beta: DEVICE scalar.
+__global__ __launch_bounds__(256) void td_gather_cost_kernel(const float* __restrict__ traj, const int64_t* __restrict__ state_rows,
+                                                            const int64_t* __restrict__ next_rows, const float* __restrict__ next_dense,
+                                                            const float* __restrict__ beta, float* __restrict__ out_next,
+                                                            float* __restrict__ out_state, float* __restrict__ cost, int CHW,
+                                                            int64_t n_src_rows) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const int64_t rs = state_rows[b];
+    const int64_t rn = next_rows ? next_rows[b] : 0;
+    const bool ok = rs >= 0 && rs < n_src_rows && (!next_rows || (rn >= 0 && rn < n_src_rows));
+    const float* ps = traj + (size_t)(ok ? rs : 0) * CHW;
+    const float* pn = next_rows ? traj + (size_t)(ok ? rn : 0) * CHW : next_dense + (size_t)b * CHW;
+    const float two_beta = 2.f * beta[0];
+    const float nanv = __builtin_nanf("");
+    float acc = 0.f;
+    for (int i = threadIdx.x * 4; i < CHW; i += 256 * 4) {
+        f32x4 sv = *reinterpret_cast<const f32x4*>(ps + i);
+        f32x4 nv = *reinterpret_cast<const f32x4*>(pn + i);
+        if (!ok) { sv = f32x4{nanv, nanv, nanv, nanv}; nv = sv; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = nv[e] - sv[e];
+            acc += (d * d) / two_beta;
+        }
+        *reinterpret_cast<f32x4*>(out_state + (size_t)b * CHW + i) = sv;
+        if (out_next) *reinterpret_cast<f32x4*>(out_next + (size_t)b * CHW + i) = nv;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) cost[b] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)CHW;
+}
+
+// TD loss of one step and its gradient (trainer.py:300-302: F.mse_loss(v(x_t), target.detach()), target = v(x_{t+1}) + extra):
+// v = the value net's output on [next_state | state] ([2B]); grad[0..B) = 0 (the target half takes part in the forward only),
+// grad[B + i] = 2 (v[B+i] - target_i) / B; logs = (loss, mean v(x_t), mean running cost).  extra: DEVICE scalar (time-cost terms
+// of this step).  One workgroup, fixed order.
+__global__ __launch_bounds__(256) void td_loss_kernel(const float* __restrict__ v, const float* __restrict__ cost,
+                                                     const float* __restrict__ extra, float* __restrict__ grad,
+                                                     float* __restrict__ logs, int B) {
+    __shared__ float red[3][256];
+    const int tid = threadIdx.x;
+    const float ex = extra ? extra[0] : 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = tid; i < B; i += 256) {
+        const float target = v[i] + ex;
+        const float pred = v[B + i];
+        const float d = pred - target;
+        grad[i] = 0.f;
+        grad[B + i] = 2.f * d / (float)B;
+        a0 += d * d;
+        a1 += pred;
+        a2 += cost[i];
+    }
+    red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            red[0][tid] += red[0][tid + o];
+            red[1][tid] += red[1][tid + o];
+            red[2][tid] += red[2][tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        logs[0] = red[0][0] / (float)B;
+        logs[1] = red[1][0] / (float)B;
+        logs[2] = red[2][0] / (float)B;
+    }
+}
+
 // nearest-neighbour x2 upsample, NHWC bf16, 8 channels per thread (ResBlock up: x_upd, models/cm/unet.py:197-198)
 __global__ void upsample2x_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int N, int H, int W, int C) {
     const int C8 = C / 8, OH = 2 * H, OW = 2 * W;
@@ -428,6 +547,33 @@ extern "C" int dxmi_value_head_bwd(const void* feat, const float* w, const float
     hipLaunchKernelGGL(value_head_bwd_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, (const bf16*)feat, w, dy, (bf16*)dfeat,
                        s, HW, C);
     DXMI_CHECK_LAUNCH("dxmi_value_head_bwd");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_value_head_pgrad(const float* s, const float* w, const float* b, const float* dy, const float* out_w,
+                                     float* out, int32_t N, int32_t C, void* stream) {
+    DXMI_CHECK_ARG(s && w && b && dy && out && N > 0 && C > 0, "dxmi_value_head_pgrad: bad arguments");
+    hipLaunchKernelGGL(value_head_pgrad_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s, w, b, dy, out_w, out, N, C);
+    DXMI_CHECK_LAUNCH("dxmi_value_head_pgrad");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_td_gather_cost(const float* traj, const int64_t* state_rows, const int64_t* next_rows, const float* next_dense,
+                                   const float* beta, float* out_next, float* out_state, float* cost, int32_t B, int32_t CHW,
+                                   int64_t n_src_rows, void* stream) {
+    DXMI_CHECK_ARG(traj && state_rows && beta && out_state && cost && (next_rows || next_dense), "dxmi_td_gather_cost: null pointer");
+    DXMI_CHECK_ARG(B > 0 && CHW > 0 && CHW % 4 == 0 && n_src_rows > 0, "dxmi_td_gather_cost: B=%d CHW=%d (multiple of 4)", B, CHW);
+    hipLaunchKernelGGL(td_gather_cost_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, traj, state_rows, next_rows, next_dense, beta,
+                       out_next, out_state, cost, CHW, n_src_rows);
+    DXMI_CHECK_LAUNCH("dxmi_td_gather_cost");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_td_loss(const float* v, const float* cost, const float* extra, float* grad, float* logs3, int32_t B,
+                            void* stream) {
+    DXMI_CHECK_ARG(v && cost && grad && logs3 && B > 0, "dxmi_td_loss: bad arguments");
+    hipLaunchKernelGGL(td_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, v, cost, extra, grad, logs3, B);
+    DXMI_CHECK_LAUNCH("dxmi_td_loss");
     return DXMI_OK;
 }
 

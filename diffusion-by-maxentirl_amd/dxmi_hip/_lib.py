@@ -110,6 +110,9 @@ SIGNATURES = {
     "dxmi_gradnorm_clip": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_void_p]),
     "dxmi_dropout_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint32, c_void_p]),
     "dxmi_dropout_bf16_dev": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
+    "dxmi_td_gather_cost": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int64, c_void_p]),
+    "dxmi_td_loss": (c_int, [c_void_p] * 5 + [c_int, c_void_p]),
+    "dxmi_value_head_pgrad": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
     "dxmi_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
 }
 

@@ -551,6 +551,48 @@ def colsum_per_image(x):
     return out
 
 
+def value_head_pgrad(s, w, b, dy, ow=None):
+    """Parameter gradients of the value head in one launch (dxmi_value_head_pgrad): s [N, C] relu-sum features, w [C], b [1], dy [N],
+    ow: the out_scale weight (device scalar) or None -> fp32 [C + 3] = d linear.weight | d linear.bias | d out_scale.weight |
+    d out_scale.bias."""
+    _need_cuda(s, w, b, dy, ow)
+    N, C = s.shape
+    assert s.dtype == torch.float32 and s.is_contiguous() and dy.dtype == torch.float32 and dy.is_contiguous() and dy.numel() == N
+    out = torch.empty(C + 3, dtype=torch.float32, device=s.device)
+    check(load().dxmi_value_head_pgrad(_ptr(s), _ptr(w), _ptr(b), _ptr(dy), _ptr(ow), _ptr(out), N, C, _stream()), "dxmi_value_head_pgrad")
+    return out
+
+
+def td_gather_cost(traj2d, state_rows, beta, *, next_rows=None, next_dense=None, out_pair):
+    """One TD step's data (dxmi_td_gather_cost): out_pair [2B, ...] receives [next_state | state] gathered from the ring's trajectory
+    block traj2d [rows, CHW] (INT path), returns the running cost [B] = mean_CHW (x' - x)^2 / (2 beta); beta: device scalar."""
+    _need_cuda(traj2d, state_rows, beta, next_rows, next_dense, out_pair)
+    B = state_rows.numel()
+    CHW = traj2d.shape[1]
+    assert traj2d.dtype == torch.float32 and traj2d.is_contiguous() and state_rows.dtype == torch.int64 and state_rows.is_contiguous()
+    assert out_pair.dtype == torch.float32 and out_pair.is_contiguous() and out_pair.numel() == 2 * B * CHW
+    assert beta.dtype == torch.float32 and beta.numel() == 1
+    assert next_rows is None or (next_rows.dtype == torch.int64 and next_rows.is_contiguous() and next_rows.numel() == B)
+    cost = torch.empty(B, dtype=torch.float32, device=traj2d.device)
+    flat = out_pair.view(2 * B, CHW)
+    _prof("replay_gather", f"td_row{CHW * 4}", 0.0, 16.0 * B * CHW, lambda: check(
+        load().dxmi_td_gather_cost(_ptr(traj2d), _ptr(state_rows), _ptr(next_rows), _ptr(next_dense), _ptr(beta), _ptr(flat[:B]),
+                                   _ptr(flat[B:]), _ptr(cost), B, CHW, traj2d.shape[0], _stream()), "dxmi_td_gather_cost"))
+    return cost
+
+
+def td_loss(v, cost, extra=None):
+    """mse(v[B:], (v[:B] + extra).detach()) of one TD step (dxmi_td_loss) -> (d loss / d v [2B] with zeros in the target half,
+    logs fp32 [3] = (loss, mean v(x_t), mean running cost)); extra: device scalar or None."""
+    _need_cuda(v, cost, extra)
+    B = cost.numel()
+    assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == 2 * B and cost.dtype == torch.float32 and cost.is_contiguous()
+    grad = torch.empty(2 * B, dtype=torch.float32, device=v.device)
+    logs = torch.empty(3, dtype=torch.float32, device=v.device)
+    check(load().dxmi_td_loss(_ptr(v), _ptr(cost), _ptr(extra), _ptr(grad), _ptr(logs), B, _stream()), "dxmi_td_loss")
+    return grad, logs
+
+
 def pool_act_bwd(dout, act_out, pool, slope, out=None):
     _need_cuda(dout, act_out, out)
     N, OH, OW, C = dout.shape

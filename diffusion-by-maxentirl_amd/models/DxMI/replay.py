@@ -96,6 +96,11 @@ class TransitionRing:
             return base + self.T * self.B + r % self.B          # final: x_T of the row's trajectory
         return rows
 
+    def storage_rows(self, rows, key="state"):
+        """Row numbers inside the [slots * (T + 1) * B, C, H, W] trajectory block of reference rows `rows` (INT path); the
+        next_state of a row is its state row + B."""
+        return self._storage_rows(rows, key)
+
     def gather(self, key, rows):
         """== reference `state_dict[key][rows]` (rows: int64 device tensor of reference row numbers)."""
         rows = rows.contiguous()

@@ -250,7 +250,18 @@ class DxMI_Trainer:
         rows_all, ts_all = self._td_rows(state_dict, indices, n_steps, batchsize)
         need_entropy = bool(self.entropy_in_value or self.entropy_in_value == 0)
         running_cost = v_loss = None
-        for i in range(n_steps):
+        fused = (self.FUSED_TD_STEP and self.PAIR_TD_FORWARD and isinstance(state_dict, TransitionRing) and not self.value_resample
+                 and not need_entropy and self.velocity_in_value is None and getattr(self.v, "forward_pair_packed", None) is not None
+                 and torch.is_tensor(self.betas_for_q) and self.betas_for_q.device == device and self.betas_for_q.dtype == torch.float32)
+        if fused:
+            v_loss_t, cost_mean_t = self._td_steps_fused(state_dict, rows_all, n_steps, batchsize, device, d_running_cost, d_value)
+            if v_loss_t is None:
+                fused = False
+        if fused:
+            v_loss, running_cost_mean = v_loss_t, cost_mean_t
+        else:
+            running_cost_mean = None
+        for i in range(0 if not fused else n_steps, n_steps):
             update_t = n_steps - i - 1
             rows, timestep = rows_all[update_t], ts_all[update_t]             # == [indices][train_indices], gathered once
             state = buffer_gather(state_dict, "state", rows)
@@ -299,14 +310,60 @@ class DxMI_Trainer:
             self.optimizer_v.zero_grad()
             d_running_cost[f"running_cost/step_{update_t}_"] = running_cost.detach().mean()
             d_value[f"value/step_{update_t}_"] = v_xt.detach().mean()
+        if running_cost_mean is None:
+            running_cost_mean = running_cost.detach().mean()
         logs = {"ebm/d_loss_": d_loss.detach(), "ebm/v_loss_": v_loss.detach(), "ebm/pos_e_": pos_e.detach().mean(),
-                "ebm/neg_e_": neg_e.detach().mean(), "ebm/running_cost_": running_cost.detach().mean(), "ebm/reg_": reg.detach()}
+                "ebm/neg_e_": neg_e.detach().mean(), "ebm/running_cost_": running_cost_mean, "ebm/reg_": reg.detach()}
         logs.update(d_running_cost)
         logs.update(d_value)
         if self.adavelreg is not None:
             for t, beta in enumerate(self.betas_for_q):
                 logs[f"adavelreg/beta{t}_"] = beta
         return self._stack_logs(logs)
+
+    FUSED_TD_STEP = True          # ring buffer: one gather + cost launch and one loss launch per TD step (A/B switch)
+
+    def _td_steps_fused(self, ring, rows_all, n_steps, batchsize, device, d_running_cost, d_value):
+        """The T TD steps of update_f_v on a TransitionRing with the elementwise work of a step in TWO launches (round 6: it was ~40
+        torch launches per step — index arithmetic, two gathers, the cat of the paired forward, running cost, time-cost terms,
+        mse forward / backward, the logged means): dxmi_td_gather_cost writes [next_state | state] of the step's rows straight into
+        the batch the value net evaluates and reduces the running cost; dxmi_td_loss forms the TD target (v(x') + the step's
+        time-cost terms, detached), the loss, its gradient and the logged means.  Same arithmetic per element as the generic loop
+        (reference trainer.py:271-325); the means are summed in a fixed order of their own.  Every row of a step shares its
+        timestep on the ring, so the per-row gathers of beta and of the time-cost terms are one scalar per step."""
+        from dxmi_hip import ops
+        T, B = n_steps, batchsize
+        shape = ring.shape
+        srows = ring.storage_rows(rows_all.reshape(-1), "state").view(T, B)       # index arithmetic of all T steps at once
+        nrows = srows + B                                                           # next_state of a row: B rows further in the block
+        traj2d = ring.traj.view(-1, ring.traj[0, 0, 0].numel())
+        extra = None
+        if self.time_cost_sig is not None or self.time_cost is not None:
+            tt = torch.arange(T, device=device)
+            extra = self._time_cost_terms(tt) if self.time_cost_sig is not None else torch.zeros(T, device=device)
+            if self.time_cost is not None:
+                extra = extra + self.time_cost
+            extra = extra.float().contiguous()
+        v_loss = cost_mean = None
+        for i in range(T):
+            t = T - i - 1
+            pair_x = torch.empty((2 * B,) + tuple(shape), dtype=torch.float32, device=device)
+            cost = ops.td_gather_cost(traj2d, srows[t], self.betas_for_q[T - 1 - t:T - t], next_rows=nrows[t], out_pair=pair_x)
+            _set_mode(self.v, True)
+            res = self.v.forward_pair_packed(pair_x, B)
+            if res is None:
+                return None, None
+            grad, lg = ops.td_loss(res.detach().reshape(-1), cost, None if extra is None else extra[t:t + 1])
+            res.backward(gradient=grad.view_as(res))
+            self.sync_v()
+            if self.value_grad_clip:
+                self._clip(ops.fast_parameters(self.v), 0.1)
+            self.optimizer_v.step()
+            self.optimizer_v.zero_grad()
+            d_running_cost[f"running_cost/step_{t}_"] = lg[2]
+            d_value[f"value/step_{t}_"] = lg[1]
+            v_loss, cost_mean = lg[0], lg[2]
+        return v_loss, cost_mean
 
     # ------------------------------------------------------------------ policy update
     def update_sampler(self, state_dict, n_generator, d_sample=None):

@@ -159,6 +159,11 @@ class IGEBMEncoderV2(nn.Module):
         res = forward_with_grad(self, torch.cat((x_free.detach(), x_grad), 0), nfree=n0)
         return res[:n0].detach(), res[n0:]
 
+    def forward_pair_packed(self, x_cat, n_free):
+        """forward_pair on an already concatenated batch: values of all rows, autograd graph through rows n_free.. only."""
+        from .value_train import forward_with_grad
+        return forward_with_grad(self, x_cat, nfree=n_free)
+
     @torch.no_grad()
     def forward_inference(self, input):
         pk = self.packed()

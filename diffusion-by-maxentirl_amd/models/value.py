@@ -27,5 +27,11 @@ class TimeIndependentValue(nn.Module):
             return tgt, self.forward(x_grad, t_grad, y=y)
         return self.net.forward_pair(x_free, x_grad)
 
+    def forward_pair_packed(self, x_cat, n_free):
+        """forward_pair on an already concatenated batch [x_free | x_grad] (the trainers' fused TD step writes the two halves in
+        place): -> V of all 2B rows, with a graph through the second half only.  None when the wrapped network has no such form."""
+        fn = getattr(self.net, "forward_pair_packed", None)
+        return None if fn is None else fn(x_cat, n_free)
+
     def load_pretrained(self, ckpt):
         self.net.load_pretrained(ckpt)

@@ -71,12 +71,14 @@ class _ValueNetFn(torch.autograd.Function):
         dfeat, s = ops.value_head_bwd(feat, w.contiguous(), dy_pre.contiguous())
         dw = ctx.need_dw
         if dw:
-            grads[net.linear.weight] = (dy_pre[:, None] * s).sum(0, keepdim=True)
-            grads[net.linear.bias] = dy_pre.sum().reshape(1)
-        if dw and net.learn_out_scale:
-            y_pre = (s * w).sum(1) + net.linear.bias         # [N, C] x [C]: elementwise + row sums (no BLAS call)
-            grads[net.out_scale.weight] = (dy * y_pre).sum().reshape(1, 1)
-            grads[net.out_scale.bias] = dy.sum().reshape(1)
+            # the four head-parameter gradients from one launch (round 6: they were ~10 torch elementwise / reduce launches per backward)
+            C = w.numel()
+            hp = ops.value_head_pgrad(s, w.contiguous(), net.linear.bias, dy, net.out_scale.weight if net.learn_out_scale else None)
+            grads[net.linear.weight] = hp[:C].view(1, C)
+            grads[net.linear.bias] = hp[C:C + 1]
+            if net.learn_out_scale:
+                grads[net.out_scale.weight] = hp[C + 1:C + 2].view(1, 1)
+                grads[net.out_scale.bias] = hp[C + 2:C + 3]
         # dfeat is the gradient w.r.t. the last block's OUTPUT (post LeakyReLU)
         g_out = dfeat
         for i in reversed(range(len(net.blocks))):

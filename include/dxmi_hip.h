@@ -478,6 +478,26 @@ int dxmi_dropout_bf16(const void* x, void* y, int64_t n, float p, uint32_t seed,
  * before every replay). */
 int dxmi_dropout_bf16_dev(const void* x, void* y, int64_t n, float p, const uint32_t* seed, void* stream);
 
+/* TD step of DxMI_Trainer.update_f_v on the replay ring, data side in one launch (reference trainer.py:271-300, :163-169): rows
+ * `state_rows[b]` (and `next_rows[b]`, or the dense re-drawn next states of value_resample) of the ring's fp32 [n_src_rows, CHW]
+ * trajectory block are gathered into out_state / out_next — the two halves of the batch [next_state | state] the value net
+ * evaluates in one forward — and cost[b] = mean_CHW (x' - x)^2 / (2 beta) is reduced on the way.  INT path bit-exact; an index
+ * outside [0, n_src_rows) fills the row with NaN.  beta: DEVICE scalar (betas_for_q[T - 1 - t]).  out_next may be NULL. */
+int dxmi_td_gather_cost(const float* traj, const int64_t* state_rows, const int64_t* next_rows, const float* next_dense,
+                        const float* beta, float* out_next, float* out_state, float* cost, int32_t B, int32_t CHW,
+                        int64_t n_src_rows, void* stream);
+
+/* TD loss of one step and its gradient (trainer.py:300-302: F.mse_loss(v(x_t), (v(x_t+1) + extra).detach())): v = the value
+ * net's output on [next_state | state] ([2B]); grad[0..B) = 0, grad[B + i] = 2 (v[B + i] - v[i] - extra) / B;
+ * logs3 = (loss, mean v(x_t), mean cost).  extra: DEVICE scalar (time-cost terms of the step) or NULL. */
+int dxmi_td_loss(const float* v, const float* cost, const float* extra, float* grad, float* logs3, int32_t B, void* stream);
+
+/* Parameter gradients of the value head (models/modules.py:146-163: relu, spatial sum, Linear(C,1), out_scale Linear(1,1)) in one
+ * launch: s = the relu-sum features [N, C] dxmi_value_head_bwd returns, dy [N]; out = fp32 [C + 3] = d linear.weight |
+ * d linear.bias | d out_scale.weight | d out_scale.bias (zeros when out_w is NULL).  Fixed summation order. */
+int dxmi_value_head_pgrad(const float* s, const float* w, const float* b, const float* dy, const float* out_w, float* out,
+                          int32_t N, int32_t C, void* stream);
+
 /* Replay-buffer row gather (INT path; trainer.py:278-289 `state_dict[key][indices][train_indices]`, :357-359):
  * dst[r] = src[idx[r]], rows of row_bytes (multiple of 4), idx int64 on the device, negative indices wrap; an index
  * outside [-n_src_rows, n_src_rows) fills the row with 0xFF bytes instead of reading out of bounds. */

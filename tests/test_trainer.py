@@ -201,9 +201,10 @@ TRAINER_KW = {"trainer_step": dict(time_cost_sig=True), "trainer_step_T4_resampl
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("buffer", ["dict", "ring"])
 @pytest.mark.parametrize("fused", [False, True], ids=["torch_adam", "dxmi_adam"])
 @pytest.mark.parametrize("fixture", list(TRAINER_KW))
-def test_hip_trainer_step_vs_reference(golden_dir, fixture, fused):
+def test_hip_trainer_step_vs_reference(golden_dir, fixture, fused, buffer):
     """Full HIP train step at the reference's golden configurations: configs/cifar10/T10.yaml (T=10) and the
     T4_ddgan.yaml protocol (T=4, value_resample: sample_step inside the TD loop, trainer.py:281-285).
     bf16 activations / gradients against the reference's fp32:
@@ -216,7 +217,10 @@ def test_hip_trainer_step_vs_reference(golden_dir, fixture, fused):
         pattern: cosine of the update against the reference's update (measured 0.983-1.0; bound 0.97 — elements whose
         gradient is below the bf16 noise flip sign).
     fused: the shipped configuration — dxmi_hip.optim.Adam (multi-tensor kernel; the trainer's gradient clip is the
-    device-side dxmi_gradnorm_clip in both cases) instead of torch.optim.Adam."""
+    device-side dxmi_gradnorm_clip in both cases) instead of torch.optim.Adam.
+    buffer: "dict" = the reference-style dict of concatenated tensors (generic TD loop); "ring" = the shipped TransitionRing, where
+    the T10 configuration takes the fused TD step of round 6 (dxmi_td_gather_cost + dxmi_td_loss, paired value forward)."""
+    from models.DxMI.replay import TransitionRing
     from models.DxMI.trainer import DxMI_Trainer, append_buffer, reset_buffer
     from dxmi_hip.optim import Adam as FusedAdam
     AdamCls = FusedAdam if fused else torch.optim.Adam
@@ -242,8 +246,14 @@ def test_hip_trainer_step_vs_reference(golden_dir, fixture, fused):
     torch.manual_seed(int(g["seed"]))
     noise = [torch.randn(B, 3, 32, 32) for _ in range(T + 1)]      # the reference's CPU draws, in its order
     sampler.eval()
-    d = sampler.sample(B, device=DEV, noise=noise)
-    buf = append_buffer(reset_buffer(DEV), d)
+    if buffer == "ring":
+        ring = TransitionRing(1, T, B, (3, 32, 32), DEV)
+        d = sampler.sample(B, device=DEV, noise=noise, out=ring.next_slot())
+        buf = append_buffer(ring, d)
+        assert trainer.FUSED_TD_STEP
+    else:
+        d = sampler.sample(B, device=DEV, noise=noise)
+        buf = append_buffer(reset_buffer(DEV), d)
     assert torch.equal(buf["timestep"].cpu(), torch.from_numpy(g["buffer_timestep"]))
     assert [list(buf[k].shape) for k in ("state", "sigma", "logp")] == [[T * B, 3, 32, 32], [T * B, 1, 1, 1], [T * B]]
     w0 = {n: p.detach().clone() for n, p in nnamed.items()}
