@@ -1,4 +1,5 @@
-"""Full-size EDM DxMI train step on one GPU (synthetic data): python tools/edm_train_bench.py imagenet64_T10 16 [steps]"""
+"""Full-size EDM DxMI train step on one GPU (synthetic data): python tools/edm_train_bench.py imagenet64_T10 16 [steps] [graph]
+graph: the three phases replayed from hipGraphs on the device ring (train_image_large.py's default), else python-issued on a dict buffer."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "diffusion-by-maxentirl_amd")]
@@ -15,6 +16,7 @@ if os.environ.get("DXMI_BATCH_INVARIANT", "0") != "1":
     ops.tune_for_throughput()          # train_image_large.py's default
 name, B = sys.argv[1], int(sys.argv[2])
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+GRAPH = len(sys.argv) > 4 and sys.argv[4] == "graph"
 dev = "cuda:0"
 cfg = configs_builtin.get(name)
 torch.manual_seed(0)
@@ -32,6 +34,11 @@ trainer = dxmi_config.instantiate(cfg.trainer, batchsize=B)
 trainer.set_models(v=v, sampler=sampler, optimizer=opt, optimizer_v=opt_v)
 res = cfg.diffusion.image_size
 g = torch.Generator(device=dev).manual_seed(1)
+ring = None
+if GRAPH:
+    from models.DxMI.replay import TransitionRing
+    trainer.use_graphs = sampler.use_graph = True
+    ring = TransitionRing(1, trainer.n_timesteps, B, sampler.sample_shape, dev, with_y=bool(cfg.sampler.class_cond), sigma_dims=1)
 
 
 def step():
@@ -39,17 +46,20 @@ def step():
     y = torch.randint(0, 1000, (B,), device=dev, generator=g) if cfg.sampler.class_cond else None
     t = [time.perf_counter()]
     sampler.eval()
-    d = sampler.sample(B, device=dev, i_class=y)
+    d = sampler.sample(B, device=dev, i_class=y, out=ring.next_slot() if ring is not None else None)
     torch.cuda.synchronize(); t.append(time.perf_counter())
-    buf = append_buffer(reset_buffer(dev), d)
+    buf = append_buffer(ring if ring is not None else reset_buffer(dev), d)
     le = trainer.update_f_v(data, d, buf, y=y)
     torch.cuda.synchronize(); t.append(time.perf_counter())
     ls = trainer.update_sampler_mixed_precision(buf, mp_trainer=mp)
     torch.cuda.synchronize(); t.append(time.perf_counter())
+    if ring is not None:
+        reset_buffer(dev, ring=ring)
     return [b - a for a, b in zip(t[:-1], t[1:])], le, ls
 
 
-step()
+for _ in range(3 if GRAPH else 1):
+    step()
 tot = [0, 0, 0]
 for _ in range(steps):
     dt, le, ls = step()
