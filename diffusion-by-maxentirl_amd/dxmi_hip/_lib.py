@@ -113,6 +113,12 @@ SIGNATURES = {
     "dxmi_td_gather_cost": (c_int, [c_void_p] * 8 + [c_int, c_int, c_int64, c_void_p]),
     "dxmi_td_loss": (c_int, [c_void_p] * 5 + [c_int, c_void_p]),
     "dxmi_value_head_pgrad": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p]),
+    "dxmi_gconv_packed_elems": (c_int64, [c_int] * 4),
+    "dxmi_gconv_pack": (c_int, [c_void_p] * 5 + [c_float, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "dxmi_gconv_fwd": (c_int, [c_void_p] * 4 + [c_int] * 14 + [c_void_p]),
+    "dxmi_pool3x3": (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    "dxmi_global_avgpool": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dxmi_resize_bilinear_nhwc16": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "dxmi_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
 }
 

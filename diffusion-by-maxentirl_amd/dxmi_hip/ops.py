@@ -1230,3 +1230,74 @@ def gather_rows(src, idx, out=None):
         _prof("replay_gather", f"row{row_bytes}", 0.0, 2.0 * n * row_bytes, lambda: check(
             load().dxmi_gather_rows(_ptr(src), _ptr(idx), _ptr(out), n, src.shape[0], row_bytes, _stream()), "dxmi_gather_rows"))
     return out
+
+
+# ------------------------------------------------------------------------------------------ InceptionV3 of the FID (f4)
+class PackedGConv:
+    """BatchNorm-folded bf16 weights [ceil32(Cout)][KH * KW][ceil16(Cin)] + fp32 bias of one BasicConv2d (dxmi_gconv_pack)."""
+
+    __slots__ = ("w", "bias", "Cout", "Cin", "CinP", "KH", "KW")
+
+    def __init__(self, w, bias, Cout, Cin, CinP, KH, KW):
+        self.w, self.bias, self.Cout, self.Cin, self.CinP, self.KH, self.KW = w, bias, Cout, Cin, CinP, KH, KW
+
+
+def gconv_pack(weight, bn=None, eps=1e-3):
+    """weight fp32 [Cout, Cin, KH, KW]; bn = (gamma, beta, running_mean, running_var) or None."""
+    _need_cuda(weight)
+    w = weight.detach().float().contiguous()
+    Cout, Cin, KH, KW = w.shape
+    lib = load()
+    wp = torch.empty(int(lib.dxmi_gconv_packed_elems(Cout, Cin, KH, KW)), dtype=torch.bfloat16, device=w.device)
+    CoutP, CinP = (Cout + 31) // 32 * 32, (Cin + 15) // 16 * 16
+    bias = torch.empty(CoutP, dtype=torch.float32, device=w.device)
+    bnp = [t.detach().float().contiguous() for t in bn] if bn is not None else [None] * 4
+    check(lib.dxmi_gconv_pack(_ptr(w), _ptr(bnp[0]), _ptr(bnp[1]), _ptr(bnp[2]), _ptr(bnp[3]), float(eps), _ptr(wp), _ptr(bias), Cout, Cin, KH, KW,
+                              _stream()), "dxmi_gconv_pack")
+    return PackedGConv(wp, bias, Cout, Cin, CinP, KH, KW)
+
+
+def gconv(x, pk, stride=(1, 1), pad=(0, 0), relu=True, out=None, coff=0):
+    """x NHWC bf16 [N, IH, IW, pk.CinP] -> NHWC bf16 [N, OH, OW, Cout] (or the channel window [coff, coff + Cout) of `out`)."""
+    _need_cuda(x, out)
+    N, IH, IW, C = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and C == pk.CinP, f"gconv: input has {C} channels, the packed weight wants {pk.CinP}"
+    OH, OW = (IH + 2 * pad[0] - pk.KH) // stride[0] + 1, (IW + 2 * pad[1] - pk.KW) // stride[1] + 1
+    if out is None:
+        out = torch.empty((N, OH, OW, pk.Cout), dtype=torch.bfloat16, device=x.device)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous() and tuple(out.shape[:3]) == (N, OH, OW)
+    fl = 2.0 * N * OH * OW * pk.Cout * pk.Cin * pk.KH * pk.KW
+    _prof("inception", f"gconv{pk.KH}x{pk.KW}", fl, 2.0 * (x.numel() + N * OH * OW * pk.Cout + pk.w.numel()), lambda: check(
+        load().dxmi_gconv_fwd(_ptr(x), _ptr(pk.w), _ptr(pk.bias), _ptr(out), N, IH, IW, C, pk.Cout, pk.KH, pk.KW, stride[0], stride[1], pad[0],
+                              pad[1], out.shape[3], coff, int(relu), _stream()), "dxmi_gconv_fwd"))
+    return out
+
+
+def pool3x3(x, stride, pad, avg_exclude_pad=False, out=None, coff=0):
+    """3x3 max pool, or the average over the in-bounds pixels of the window (count_include_pad=False)."""
+    _need_cuda(x, out)
+    N, IH, IW, C = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    OH, OW = (IH + 2 * pad - 3) // stride + 1, (IW + 2 * pad - 3) // stride + 1
+    if out is None:
+        out = torch.empty((N, OH, OW, C), dtype=torch.bfloat16, device=x.device)
+    check(load().dxmi_pool3x3(_ptr(x), _ptr(out), N, IH, IW, C, stride, pad, int(avg_exclude_pad), out.shape[3], coff, _stream()), "dxmi_pool3x3")
+    return out
+
+
+def global_avgpool(x):
+    _need_cuda(x)
+    N, H, W, C = x.shape
+    out = torch.empty((N, C), dtype=torch.float32, device=x.device)
+    check(load().dxmi_global_avgpool(_ptr(x), _ptr(out), N, H * W, C, _stream()), "dxmi_global_avgpool")
+    return out
+
+
+def resize_bilinear_nhwc16(x, OH, OW, normalize=True):
+    """NCHW fp32 [N, 3, H, W] -> NHWC bf16 [N, OH, OW, 16] (bilinear, align_corners=False; 2 x - 1 when normalize)."""
+    _need_cuda(x)
+    N, C, H, W = x.shape
+    assert C == 3 and x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty((N, OH, OW, 16), dtype=torch.bfloat16, device=x.device)
+    check(load().dxmi_resize_bilinear_nhwc16(_ptr(x), _ptr(out), N, H, W, OH, OW, int(normalize), _stream()), "dxmi_resize_bilinear_nhwc16")
+    return out

@@ -6,10 +6,12 @@
     m1, s1 = activation_statistics(act)                                                # np.mean / np.cov -> HIP (f32 MFMA)
     fid = calculate_frechet_distance(m1, s1, m2, s2)                                   # float64 host algorithm, as the reference
 
-What is NOT here: the InceptionV3 network and its weights (`pytorch_fid/inception.py` downloads pt_inception-2015-12-05 and
-needs torchvision; neither exists in the target image).  The feature extractor is therefore an argument — any
-callable `extractor(batch) -> [features [B, dims, h, w]]` with the reference extractor's call convention (`model(batch)[0]`,
-fid_score.py:208) — e.g. a user's own InceptionV3 instance; `load_extractor("module:attr")` resolves one from the command line.
+The feature extractor is an argument — any callable `extractor(batch) -> [features [B, dims, h, w]]` with the reference
+extractor's call convention (`model(batch)[0]`, fid_score.py:208); `load_extractor("module:attr")` resolves one from the command
+line.  Round 6: `pytorch_fid.inception.InceptionV3` is the reference's extractor on the HIP kernels (the published torchvision
+Inception3 + the FID patches, one generic MFMA conv launch per BasicConv2d); what is still NOT here is its WEIGHT FILE
+(pt_inception-2015-12-05: the reference downloads it, this image has no network) — `--fid_extractor
+pytorch_fid.inception:FIDInceptionV3` loads it from DXMI_FID_WEIGHTS and fails loudly without it.
 
 Reference statistics files (`datasets/VIRTUAL_*.npz`, `mu` / `sigma` keys, train_image_large.py:225-232) load through
 `load_statistics`.  The names and argument meaning follow pytorch_fid/fid_score.py:170-281.

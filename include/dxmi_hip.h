@@ -498,6 +498,42 @@ int dxmi_td_loss(const float* v, const float* cost, const float* extra, float* g
 int dxmi_value_head_pgrad(const float* s, const float* w, const float* b, const float* dy, const float* out_w, float* out,
                           int32_t N, int32_t C, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * InceptionV3 feature extractor of the FID evaluation (reference pytorch_fid/inception.py:16-163 with the FID patches
+ * :193-310, called as `model(batch)[0]` by pytorch_fid/fid_score.py:170-221).  Shape-agnostic kernels (the net's maps are 149 ... 8
+ * pixels wide, its kernels 1x1 ... 7x1): NHWC bf16 activations whose channel count is a multiple of 16, outputs written at a
+ * channel offset of a wider tensor so that the blocks' concatenations are never materialised.
+ * ---------------------------------------------------------------------------------------- */
+
+/* bf16 elements of a packed generic-conv weight: [ceil32(Cout)][KH * KW][ceil16(Cin)]. */
+int64_t dxmi_gconv_packed_elems(int32_t Cout, int32_t Cin, int32_t KH, int32_t KW);
+
+/* BasicConv2d's weights for dxmi_gconv_fwd (torchvision Inception3: Conv2d(bias=False) + BatchNorm2d(eps) + ReLU): w fp32
+ * [Cout, Cin, KH, KW]; the BatchNorm scale gamma / sqrt(var + eps) is folded into the bf16 weights, bias[ceil32(Cout)] = beta -
+ * mean * scale.  bn_gamma NULL: plain conv (bias zero). */
+int dxmi_gconv_pack(const float* w, const float* bn_gamma, const float* bn_beta, const float* bn_mean, const float* bn_var,
+                    float bn_eps, void* w_packed, float* bias, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, void* stream);
+
+/* out[n, oy, ox, out_coff + co] = relu?(bias[co] + sum x[n, oy*SH - PH + ky, ox*SW - PW + kx, ci] * w[co][ky, kx][ci]) — implicit
+ * GEMM on the bf16 MFMA, fp32 accumulation; x NHWC bf16 with Cin % 16 == 0 channels (the packed weight's padded count), out NHWC
+ * bf16 with out_cstride channels per pixel.  OH = (IH + 2 PH - KH) / SH + 1 (likewise OW). */
+int dxmi_gconv_fwd(const void* x, const void* w_packed, const float* bias, void* out, int32_t N, int32_t IH, int32_t IW,
+                   int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t SH, int32_t SW, int32_t PH, int32_t PW,
+                   int32_t out_cstride, int32_t out_coff, int32_t relu, void* stream);
+
+/* 3x3 pooling, NHWC bf16: max (padding = -inf; F.max_pool2d) or, avg_exclude_pad != 0, the average over the window's IN-BOUNDS
+ * pixels only (F.avg_pool2d(count_include_pad=False): the FID patch of inception.py:209-212).  pad 0 or 1. */
+int dxmi_pool3x3(const void* x, void* out, int32_t N, int32_t IH, int32_t IW, int32_t C, int32_t stride, int32_t pad,
+                 int32_t avg_exclude_pad, int32_t out_cstride, int32_t out_coff, void* stream);
+
+/* adaptive_avg_pool2d(x, 1): [N, HW, C] bf16 -> [N, C] fp32 (pixels summed in order). */
+int dxmi_global_avgpool(const void* x, float* out, int32_t N, int32_t HW, int32_t C, void* stream);
+
+/* F.interpolate(x, (OH, OW), mode='bilinear', align_corners=False) (+ 2 x - 1 when normalize; inception.py:146-153): NCHW fp32
+ * [N, 3, IH, IW] -> NHWC bf16 [N, OH, OW, 16] (channels 3..15 zero). */
+int dxmi_resize_bilinear_nhwc16(const float* x, void* out, int32_t N, int32_t IH, int32_t IW, int32_t OH, int32_t OW,
+                                int32_t normalize, void* stream);
+
 /* Replay-buffer row gather (INT path; trainer.py:278-289 `state_dict[key][indices][train_indices]`, :357-359):
  * dst[r] = src[idx[r]], rows of row_bytes (multiple of 4), idx int64 on the device, negative indices wrap; an index
  * outside [-n_src_rows, n_src_rows) fills the row with 0xFF bytes instead of reading out of bounds. */
