@@ -208,7 +208,8 @@ extern "C" int dxmi_gconv_fwd(const void* x, const void* w_packed, const float* 
     a.N = N; a.IH = IH; a.IW = IW; a.Cin = Cin; a.Cout = Cout; a.CoutP = (Cout + 31) / 32 * 32;
     a.KH = KH; a.KW = KW; a.SH = SH; a.SW = SW; a.PH = PH; a.PW = PW;
     a.OH = (IH + 2 * PH - KH) / SH + 1; a.OW = (IW + 2 * PW - KW) / SW + 1;
-    DXMI_CHECK_ARG(a.OH > 0 && a.OW > 0, "dxmi_gconv_fwd: empty output");
+    // (the window must fit the padded map: a negative numerator truncates towards zero and would pass for a 1 x 1 output)
+    DXMI_CHECK_ARG(IH + 2 * PH >= KH && IW + 2 * PW >= KW && a.OH > 0 && a.OW > 0, "dxmi_gconv_fwd: the %dx%d kernel does not fit the padded %dx%d map", KH, KW, IH + 2 * PH, IW + 2 * PW);
     DXMI_CHECK_ARG(out_cstride >= out_coff + Cout && out_coff >= 0, "dxmi_gconv_fwd: channel window [%d, %d) outside the output's %d channels", out_coff, out_coff + Cout, out_cstride);
     a.out_cs = out_cstride; a.out_co = out_coff; a.relu = relu;
     const long P = (long)N * a.OH * a.OW;
@@ -223,7 +224,7 @@ extern "C" int dxmi_pool3x3(const void* x, void* out, int32_t N, int32_t IH, int
     DXMI_CHECK_ARG(x && out && N > 0 && IH > 0 && IW > 0 && C > 0 && C % 8 == 0 && stride > 0 && pad >= 0 && pad <= 1, "dxmi_pool3x3: bad arguments");
     DXMI_CHECK_ARG(out_cstride % 8 == 0 && out_coff % 8 == 0 && out_cstride >= out_coff + C, "dxmi_pool3x3: channel window must be 8-aligned inside the output");
     const int OH = (IH + 2 * pad - 3) / stride + 1, OW = (IW + 2 * pad - 3) / stride + 1;
-    DXMI_CHECK_ARG(OH > 0 && OW > 0, "dxmi_pool3x3: empty output");
+    DXMI_CHECK_ARG(IH + 2 * pad >= 3 && IW + 2 * pad >= 3 && OH > 0 && OW > 0, "dxmi_pool3x3: the 3x3 window does not fit the padded %dx%d map", IH + 2 * pad, IW + 2 * pad);
     hipLaunchKernelGGL(pool3x3_kernel, dim3(grid1d((long)N * OH * OW * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)out,
                        N, IH, IW, C, OH, OW, stride, pad, avg_exclude_pad, out_cstride, out_coff);
     DXMI_CHECK_LAUNCH("dxmi_pool3x3");

@@ -152,6 +152,35 @@ int main(void) {
     expect_einval("linear_splitk(K % 32 != 0)", dxmi_linear_splitk((const float*)FAKE(1), FAKE(2), (float*)FAKE(3), 16, 30700, 768, 0, NULL));
     if (dxmi_linear_splitk_slices(-1, 4096, 64) != 0 || dxmi_linear_splitk_slices(16, 0, 64) != 0 || dxmi_linear_splitk_slices(16, 30720, 768) < 2) { printf("FAIL linear_splitk_slices\n"); ++failures; }
     else printf("ok   linear_splitk_slices(bad) == 0, (16, 30720, 768) splits\n");
+    /* ---- round 6: replayed-step entry points, fused TD step, InceptionV3 ops ---------------------------------------- */
+    {
+        void* ptrs[2] = {FAKE(1), FAKE(2)};
+        int64_t numel[2] = {1024, 4096};
+        int64_t bad_numel[2] = {1024, 0};
+        expect_einval("adam_step_dev(NULL hyper)", dxmi_adam_step_dev(ptrs, ptrs, ptrs, ptrs, numel, 2, 0.9, 0.999, 1e-8, NULL, NULL, 0, NULL));
+        expect_einval("adam_step_dev(count = 0)", dxmi_adam_step_dev(ptrs, ptrs, ptrs, ptrs, numel, 0, 0.9, 0.999, 1e-8, (const float*)FAKE(3), NULL, 0, NULL));
+        expect_einval("adam_step_dev(empty tensor)", dxmi_adam_step_dev(ptrs, ptrs, ptrs, ptrs, bad_numel, 2, 0.9, 0.999, 1e-8, (const float*)FAKE(3), NULL, 0, NULL));
+        expect_einval("radam_step_dev(NULL grads)", dxmi_radam_step_dev(ptrs, NULL, ptrs, ptrs, numel, 2, 0.9, 0.999, 1e-8, (const float*)FAKE(3), NULL, NULL, NULL));
+        expect_einval("dropout_bf16_dev(NULL seed)", dxmi_dropout_bf16_dev(FAKE(1), FAKE(2), 1024, 0.1f, NULL, NULL));
+        expect_einval("dropout_bf16_dev(n % 8 != 0)", dxmi_dropout_bf16_dev(FAKE(1), FAKE(2), 1020, 0.1f, (const uint32_t*)FAKE(3), NULL));
+        expect_einval("td_gather_cost(no next source)", dxmi_td_gather_cost((const float*)FAKE(1), (const int64_t*)FAKE(2), NULL, NULL, (const float*)FAKE(3), (float*)FAKE(4), (float*)FAKE(5), (float*)FAKE(6), 32, 3072, 352, NULL));
+        expect_einval("td_gather_cost(CHW % 4 != 0)", dxmi_td_gather_cost((const float*)FAKE(1), (const int64_t*)FAKE(2), (const int64_t*)FAKE(7), NULL, (const float*)FAKE(3), (float*)FAKE(4), (float*)FAKE(5), (float*)FAKE(6), 32, 3070, 352, NULL));
+        expect_einval("td_gather_cost(NULL beta)", dxmi_td_gather_cost((const float*)FAKE(1), (const int64_t*)FAKE(2), (const int64_t*)FAKE(7), NULL, NULL, (float*)FAKE(4), (float*)FAKE(5), (float*)FAKE(6), 32, 3072, 352, NULL));
+        expect_einval("td_loss(B = 0)", dxmi_td_loss((const float*)FAKE(1), (const float*)FAKE(2), NULL, (float*)FAKE(3), (float*)FAKE(4), 0, NULL));
+        expect_einval("value_head_pgrad(NULL dy)", dxmi_value_head_pgrad((const float*)FAKE(1), (const float*)FAKE(2), (const float*)FAKE(3), NULL, NULL, (float*)FAKE(4), 32, 256, NULL));
+        expect_einval("gconv_fwd(Cin % 16 != 0)", dxmi_gconv_fwd(FAKE(1), FAKE(2), (const float*)FAKE(3), FAKE(4), 2, 35, 35, 40, 64, 5, 5, 1, 1, 2, 2, 64, 0, 1, NULL));
+        expect_einval("gconv_fwd(kernel larger than the padded map)", dxmi_gconv_fwd(FAKE(1), FAKE(2), (const float*)FAKE(3), FAKE(4), 2, 3, 3, 16, 32, 7, 7, 1, 1, 0, 0, 32, 0, 1, NULL));
+        expect_einval("gconv_fwd(channel window outside the output)", dxmi_gconv_fwd(FAKE(1), FAKE(2), (const float*)FAKE(3), FAKE(4), 2, 17, 17, 768, 192, 1, 1, 1, 1, 0, 0, 768, 600, 1, NULL));
+        expect_einval("gconv_fwd(3x3 s2 on a 2x2 map)", dxmi_gconv_fwd(FAKE(1), FAKE(2), (const float*)FAKE(3), FAKE(4), 2, 2, 2, 16, 32, 3, 3, 2, 2, 0, 0, 32, 0, 1, NULL));
+        expect_einval("gconv_fwd(stride 0)", dxmi_gconv_fwd(FAKE(1), FAKE(2), (const float*)FAKE(3), FAKE(4), 2, 17, 17, 768, 192, 1, 1, 0, 1, 0, 0, 192, 0, 1, NULL));
+        expect_einval("gconv_pack(gamma without var)", dxmi_gconv_pack((const float*)FAKE(1), (const float*)FAKE(2), (const float*)FAKE(3), (const float*)FAKE(4), NULL, 1e-3f, FAKE(5), (float*)FAKE(6), 64, 48, 5, 5, NULL));
+        expect_einval("pool3x3(C % 8 != 0)", dxmi_pool3x3(FAKE(1), FAKE(2), 2, 35, 35, 100, 1, 1, 1, 104, 0, NULL));
+        expect_einval("pool3x3(2x2 map, no padding)", dxmi_pool3x3(FAKE(1), FAKE(2), 2, 2, 2, 64, 2, 0, 0, 64, 0, NULL));
+        expect_einval("global_avgpool(HW = 0)", dxmi_global_avgpool(FAKE(1), (float*)FAKE(2), 2, 0, 2048, NULL));
+        expect_einval("resize_bilinear_nhwc16(OH < 0)", dxmi_resize_bilinear_nhwc16((const float*)FAKE(1), FAKE(2), 2, 32, 32, -299, 299, 1, NULL));
+        if (dxmi_gconv_packed_elems(80, 64, 1, 1) != 96 * 64 || dxmi_gconv_packed_elems(32, 3, 3, 3) != 32 * 9 * 16) { printf("FAIL gconv_packed_elems\n"); ++failures; }
+        else printf("ok   gconv_packed_elems pads couts to 32 and channels to 16\n");
+    }
     /* ---- kernel-selection knobs ---------------------------------------------------------------------------------- */
     {
         int32_t v = -1;
