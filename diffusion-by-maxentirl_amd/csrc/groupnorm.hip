@@ -357,6 +357,8 @@ struct GnApplyArgs {
     float eps;
     int silu;
     int nt;        // tuning (DXMI_GN_APPLY_NT): bit 0 non-temporal loads of x, bit 1 non-temporal stores of the output
+    float* ab;     // optional [N][C][2]: per-(image, channel) scale / offset written by gn_finalize_kernel and read here instead of
+                   // the statistics prologue (dxmi_groupnorm_apply_split)
 };
 
 constexpr int GN_APPLY_MAXP = 8;        // partials per image the prologue keeps in flight (ops.MAX_APPLY_PARTIALS folds larger P)
@@ -401,6 +403,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
             if (rr < row1) v[u] = gn_ld(src + (size_t)rr * Cs, p.nt & 1);
         }
     }
+    float A[8], Bv[8];
+    if (p.ab) {
+        // split form (round 6): the scale / offset pairs of this image were formed once by gn_finalize_kernel (same arithmetic, same
+        // order): ONE 64-byte read per thread under the first trip's loads, no LDS, no barrier — the statistics prologue below is two
+        // dependent memory latencies that every workgroup of the (single) resident wave of workgroups pays at the same moment
+        if (!active) return;
+        const f32x4* q = reinterpret_cast<const f32x4*>(p.ab + ((size_t)n * C + c) * 2);
+        const f32x4 t0 = q[0], t1 = q[1], t2 = q[2], t3 = q[3];
+        A[0] = t0[0]; Bv[0] = t0[1]; A[1] = t0[2]; Bv[1] = t0[3];
+        A[2] = t1[0]; Bv[2] = t1[1]; A[3] = t1[2]; Bv[3] = t1[3];
+        A[4] = t2[0]; Bv[4] = t2[1]; A[5] = t2[2]; Bv[5] = t2[3];
+        A[6] = t3[0]; Bv[6] = t3[1]; A[7] = t3[2]; Bv[7] = t3[3];
+    } else {
     // statistics prologue, one memory latency deep: every thread sums the <= GN_APPLY_MAXP partials of one channel pair (all
     // loads in flight together, added in partial order), then 32 threads add each group's pairs in channel order through LDS
     auto pair_sums = [&](const float* st, int P, int nbs, int off) {        // uniform base + 32-bit lane offsets
@@ -461,7 +476,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
     }
     __syncthreads();
     if (!active) return;
-    float A[8], Bv[8];
     {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -476,6 +490,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnApplyArgs p) {
             A[e] = a;
             Bv[e] = b;
         }
+    }
     }
     for (;;) {
 #pragma unroll
@@ -1225,6 +1240,66 @@ extern "C" int dxmi_groupnorm_generic_bwd(const void* in0, int32_t C0, const voi
                                             workspace, N, HW, groups, eps, apply_silu, stream);
 }
 
+// One workgroup per image: the statistics prologue of gn_apply_kernel run ONCE per image instead of once per workgroup of the apply
+// pass — block-statistics partials -> channel-pair sums (partial order) -> group sums (channel order) -> mean / rstd -> per-channel
+// (scale, offset) with gamma / beta and the FiLM scale-shift folded in, written to ab[n][c][2].  Same operations in the same order
+// as the prologue: the apply pass gives bit-identical results either way.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(GnApplyArgs p) {
+    __shared__ float mean_s[32], rstd_s[32];
+    __shared__ float2 pair_s[1024];
+    const int C = p.C0 + p.C1;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    auto pair_sums = [&](const float* st, int P, int nbs, int off) {
+        const float2* const base = reinterpret_cast<const float2*>(st) + (size_t)n * P * nbs;
+        for (int b = tid; b < nbs; b += 256) {
+            float2 t[GN_APPLY_MAXP];
+#pragma unroll
+            for (int k = 0; k < GN_APPLY_MAXP; ++k)
+                if (k < P) t[k] = base[(unsigned)(k * nbs + b)];
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int k = 0; k < GN_APPLY_MAXP; ++k)
+                if (k < P) {
+                    s += t[k].x;
+                    q += t[k].y;
+                }
+            for (int k = GN_APPLY_MAXP; k < P; ++k) {
+                const float2 tk = base[(unsigned)(k * nbs + b)];
+                s += tk.x;
+                q += tk.y;
+            }
+            pair_s[off + b] = make_float2(s, q);
+        }
+    };
+    pair_sums(p.st0, p.P0, p.C0 >> 1, 0);
+    if (p.C1) pair_sums(p.st1, p.P1, p.C1 >> 1, p.C0 >> 1);
+    __syncthreads();
+    if (tid < p.groups) {
+        const int bpg = p.cpg >> 1;
+        float s = 0.f, q = 0.f;
+        for (int b = tid * bpg; b < (tid + 1) * bpg; ++b) {
+            s += pair_s[b].x;
+            q += pair_s[b].y;
+        }
+        const float cnt = (float)p.HW * (float)p.cpg;
+        const float m = s / cnt;
+        mean_s[tid] = m;
+        rstd_s[tid] = rsqrtf(fmaxf(q / cnt - m * m, 0.f) + p.eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / p.cpg;
+        float a = rstd_s[g] * p.gamma[c];
+        float b = p.beta[c] - mean_s[g] * a;
+        if (p.ss) {
+            const float sc = 1.f + p.ss[(size_t)n * p.ss_ld + c];
+            a *= sc;
+            b = b * sc + p.ss[(size_t)n * p.ss_ld + C + c];
+        }
+        reinterpret_cast<float2*>(p.ab)[(size_t)n * C + c] = make_float2(a, b);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Streaming apply + block statistics (see gn_apply_kernel)
 static inline int gn_stats_chunks(int HW) { return HW >= 512 ? HW / 256 : 1; }
@@ -1250,10 +1325,32 @@ extern "C" int dxmi_gn_stats_fold(const float* stats, float* out, int32_t N, int
     return DXMI_OK;
 }
 
+static int gn_apply_impl(const void* in0, int32_t C0, const float* stats0, int32_t P0, const void* in1, int32_t C1,
+                         const float* stats1, int32_t P1, const float* gamma, const float* beta,
+                         const float* scale_shift, int32_t ss_ld, void* out, float* ab, int32_t N, int32_t HW, int32_t groups,
+                         float eps, int32_t apply_silu, void* stream);
+
 extern "C" int dxmi_groupnorm_apply(const void* in0, int32_t C0, const float* stats0, int32_t P0, const void* in1, int32_t C1,
                                     const float* stats1, int32_t P1, const float* gamma, const float* beta,
                                     const float* scale_shift, int32_t ss_ld, void* out, int32_t N, int32_t HW, int32_t groups,
                                     float eps, int32_t apply_silu, void* stream) {
+    return gn_apply_impl(in0, C0, stats0, P0, in1, C1, stats1, P1, gamma, beta, scale_shift, ss_ld, out, nullptr, N, HW, groups, eps,
+                         apply_silu, stream);
+}
+
+extern "C" int dxmi_groupnorm_apply_split(const void* in0, int32_t C0, const float* stats0, int32_t P0, const void* in1, int32_t C1,
+                                          const float* stats1, int32_t P1, const float* gamma, const float* beta,
+                                          const float* scale_shift, int32_t ss_ld, void* out, float* ab_workspace, int32_t N,
+                                          int32_t HW, int32_t groups, float eps, int32_t apply_silu, void* stream) {
+    DXMI_CHECK_ARG(ab_workspace, "dxmi_groupnorm_apply_split: null workspace (N * C * 2 floats)");
+    return gn_apply_impl(in0, C0, stats0, P0, in1, C1, stats1, P1, gamma, beta, scale_shift, ss_ld, out, ab_workspace, N, HW, groups,
+                         eps, apply_silu, stream);
+}
+
+static int gn_apply_impl(const void* in0, int32_t C0, const float* stats0, int32_t P0, const void* in1, int32_t C1,
+                         const float* stats1, int32_t P1, const float* gamma, const float* beta,
+                         const float* scale_shift, int32_t ss_ld, void* out, float* ab, int32_t N, int32_t HW, int32_t groups,
+                         float eps, int32_t apply_silu, void* stream) {
     DXMI_CHECK_ARG(in0 && stats0 && gamma && beta && out && P0 > 0, "dxmi_groupnorm_apply: null pointer");
     DXMI_CHECK_ARG(C1 == 0 || (in1 && stats1 && P1 > 0), "dxmi_groupnorm_apply: C1>0 needs in1 and stats1");
     const int C = C0 + C1;
@@ -1277,6 +1374,11 @@ extern "C" int dxmi_groupnorm_apply(const void* in0, int32_t C0, const float* st
     if (rpc > HW) rpc = HW;
     a.chunks = (HW + rpc - 1) / rpc;
     a.rows_per_chunk = rpc;
+    a.ab = ab;
+    if (ab) {
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, a);
+        DXMI_CHECK_LAUNCH("dxmi_groupnorm_apply_split(finalize)");
+    }
     if (U == 8) hipLaunchKernelGGL(gn_apply_kernel<8>, dim3(N * a.chunks), dim3(256), 0, (hipStream_t)stream, a);
     else if (U == 2) hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(N * a.chunks), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(N * a.chunks), dim3(256), 0, (hipStream_t)stream, a);

@@ -51,6 +51,8 @@ SIGNATURES = {
     "dxmi_gn_stats_fold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_groupnorm_apply": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                      c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "dxmi_groupnorm_apply_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dxmi_fid_stats_workspace_bytes": (c_int64, [c_int64, c_int]),
     "dxmi_fid_stats": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dxmi_packed_conv_weight_bytes": (c_int64, [c_int, c_int, c_int, c_int]),

@@ -718,6 +718,9 @@ def block_stats(x):
     return fold_stats(st) if P > MAX_APPLY_PARTIALS else st
 
 
+GN_APPLY_SPLIT = os.environ.get("DXMI_GN_APPLY_SPLIT", "0") == "1"      # dxmi_groupnorm_apply_split: finalize launch + prologue-free apply
+
+
 def groupnorm_apply(x, st, gamma, beta, *, in1=None, st1=None, groups=32, eps=1e-6, silu=True, out=None, scale_shift=None):
     """GroupNorm(+FiLM scale-shift)(+SiLU) of [x | in1] given their block statistics: one streaming read + write
     (dxmi_groupnorm_apply)."""
@@ -734,6 +737,13 @@ def groupnorm_apply(x, st, gamma, beta, *, in1=None, st1=None, groups=32, eps=1e
         ss_ld = scale_shift.stride(0)
     if out is None:
         out = torch.empty((N, H, W, C), dtype=torch.bfloat16, device=x.device)
+    if GN_APPLY_SPLIT:
+        ab = torch.empty((N, C, 2), dtype=torch.float32, device=x.device)
+        _prof("groupnorm", "apply", 0.0, 4.0 * N * H * W * C, lambda: check(
+            load().dxmi_groupnorm_apply_split(_ptr(x), C0, _ptr(st.buf), st.P, _ptr(in1), C1, _ptr(st1.buf) if st1 is not None else None,
+                                              st1.P if st1 is not None else 0, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld, _ptr(out),
+                                              _ptr(ab), N, H * W, groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_apply_split"))
+        return out
     _prof("groupnorm", "apply", 0.0, 4.0 * N * H * W * C, lambda: check(
         load().dxmi_groupnorm_apply(_ptr(x), C0, _ptr(st.buf), st.P, _ptr(in1), C1, _ptr(st1.buf) if st1 is not None else None,
                                     st1.P if st1 is not None else 0, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld, _ptr(out),

@@ -262,6 +262,15 @@ int dxmi_groupnorm_apply(const void* in0, int32_t C0, const float* stats0, int32
                          int32_t ss_ld, void* out, int32_t N, int32_t HW, int32_t groups, float eps, int32_t apply_silu,
                          void* stream);
 
+/* dxmi_groupnorm_apply as TWO launches (round 6): a one-workgroup-per-image kernel forms the per-(image, channel) scale / offset
+ * pairs (statistics partials -> group mean / rstd -> gamma, beta and the FiLM scale-shift folded in) into ab_workspace
+ * (N * (C0 + C1) * 2 floats), and the streaming pass reads them instead of running that prologue in every one of its workgroups.
+ * Same operations in the same order: bit-identical output.  Pays when the extra launch is cheap (a node of a replayed hipGraph). */
+int dxmi_groupnorm_apply_split(const void* in0, int32_t C0, const float* stats0, int32_t P0, const void* in1, int32_t C1,
+                               const float* stats1, int32_t P1, const float* gamma, const float* beta,
+                               const float* scale_shift, int32_t ss_ld, void* out, float* ab_workspace, int32_t N, int32_t HW,
+                               int32_t groups, float eps, int32_t apply_silu, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Single-/multi-head self-attention over a fused qkv tensor, MFMA QK^T and PV with an
  * online softmax.  qkv: NHWC bf16 [N,T,3*C] laid out [q | k | v] along channels, heads are

@@ -229,3 +229,25 @@ def test_conv1x1_rw8(ops, N, H, C0, C1, Cout, res, rw8):
         d.N = 1
         assert not (550000 <= _lib.load().dxmi_conv2d_kernel_id(ctypes.byref(d)) < 600000)
         assert torch.equal(one[0], y[0])
+
+
+def test_groupnorm_apply_split_is_bit_identical():
+    """dxmi_groupnorm_apply_split (round 6: per-image finalize launch + prologue-free streaming pass) against dxmi_groupnorm_apply on
+    a plain, a virtual-concat and a FiLM scale-shift case: same operations in the same order, so the outputs are equal bit for bit."""
+    import torch
+    from dxmi_hip import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    for (N, H, C0, C1, ss) in [(5, 32, 128, 0, False), (3, 16, 256, 128, False), (4, 32, 192, 0, True)]:
+        C = C0 + C1
+        x0 = torch.randn(N, H, H, C0, generator=g).to(torch.bfloat16).to(dev)
+        x1 = torch.randn(N, H, H, C1, generator=g).to(torch.bfloat16).to(dev) if C1 else None
+        s0, s1 = ops.block_stats(x0), (ops.block_stats(x1) if C1 else None)
+        ga, be = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+        sst = (torch.randn(N, 2 * C, generator=g) * 0.1).to(dev) if ss else None
+        outs = []
+        for split in (False, True):
+            ops.GN_APPLY_SPLIT = split
+            outs.append(ops.groupnorm_apply(x0, s0, ga, be, in1=x1, st1=s1, eps=1e-5, silu=True, scale_shift=sst))
+        ops.GN_APPLY_SPLIT = False
+        assert torch.equal(outs[0], outs[1]), (N, H, C0, C1, ss)

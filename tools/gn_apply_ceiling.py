@@ -42,8 +42,12 @@ for (B, H, C) in SHAPES:
     sts = [ops.block_stats(x) for x in xs]
     g, b = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
     mb = 4.0 * B * H * H * C / 1e6
+    ops.GN_APPLY_SPLIT = False
     t_gn = graph_time([lambda i=i: ops.groupnorm_apply(xs[i], sts[i], g, b, eps=1e-6, silu=True, out=outs[i]) for i in range(R)])
+    ops.GN_APPLY_SPLIT = True        # finalize launch (one workgroup per image) + prologue-free apply: both launches are in the time
+    t_sp = graph_time([lambda i=i: ops.groupnorm_apply(xs[i], sts[i], g, b, eps=1e-6, silu=True, out=outs[i]) for i in range(R)])
+    ops.GN_APPLY_SPLIT = False
     t_cp = graph_time([lambda i=i: outs[i].copy_(xs[i]) for i in range(R)])
     t_ax = graph_time([lambda i=i: torch.add(xs[i], 1.0, out=outs[i]) for i in range(R)])
     print(f"B={B} {H}x{H}x{C} ({mb:6.1f} MB in+out, P={sts[0].P}): gn_apply {t_gn:6.1f} us {mb / t_gn:5.2f} TB/s | copy_ {t_cp:6.1f} us {mb / t_cp:5.2f} TB/s"
-          f" | x+1 {t_ax:6.1f} us {mb / t_ax:5.2f} TB/s | gn_apply / copy = {t_gn / t_cp:.2f}")
+          f" | x+1 {t_ax:6.1f} us {mb / t_ax:5.2f} TB/s | gn_apply / copy = {t_gn / t_cp:.2f} | split (finalize + apply) {t_sp:6.1f} us")
