@@ -377,6 +377,60 @@ __global__ void edm_step_kernel(const float* __restrict__ x, const float* __rest
     }
 }
 
+// Backward of the two sampler transitions (the differentiable `sample_step` of the policy update: reference var_sampler.py:357-408,
+// openai_diffusion.py:71-94 under torch autograd).  One workgroup per sample: the incoming gradients are read once, the gradient of
+// the network output written once, the per-sample sigma gradient reduced in-kernel (fp32, fixed order).  Any of g_* may be NULL.
+//   VAR:  x' = xm x + c eps + sigma z ; mean = xm x + c eps ; control = c eps ; logp = mean_CHW(-(x'.detach() - mean)^2 / (2 sigma^2)) - log sigma - log sqrt(2 pi)
+//         d eps = c (g_x' + g_mean + g_control + g_logp z / (sigma CHW))          (c = theta multiplier x adhoc_scale1)
+//         d sigma = sum_CHW g_x' z + g_logp (mean_CHW z^2 - 1) / sigma
+//   EDM:  mu = x + (x - c_out F - c_skip x) / sigma (sigma_down - sigma) ; x' = mu + z sigma_up
+//         d F = -(c_out (sigma_down - sigma) / sigma) (g_x' + g_mu) ;  d sigma_up = sum_CHW g_x' z
+__global__ __launch_bounds__(256) void step_bwd_kernel(const float* __restrict__ g_next, const float* __restrict__ g_mean,
+                                                      const float* __restrict__ g_control, const float* __restrict__ g_logp,
+                                                      const float* __restrict__ z, const float* __restrict__ cmul,
+                                                      const float* __restrict__ sigma, const float* __restrict__ sigma_down, float sd,
+                                                      int edm, float* __restrict__ d_eps, float* __restrict__ d_sigma, int CHW) {
+    __shared__ float red[2][4];
+    const int b = blockIdx.x;
+    float coef, lp_mean = 0.f, lp_sig = 0.f;
+    if (edm) {
+        const float s = sigma[b];
+        const float c_out = s * sd / powf(s * s + sd * sd, 0.5f);
+        coef = -(c_out * (sigma_down[b] - s) / s);
+    } else {
+        coef = cmul[b];
+        if (g_logp) {
+            lp_mean = g_logp[b] / (sigma[b] * (float)CHW);
+            lp_sig = g_logp[b] / sigma[b];
+        }
+    }
+    const size_t base = (size_t)b * CHW;
+    float acc = 0.f, zz = 0.f;
+    for (int i = threadIdx.x * 4; i < CHW; i += 256 * 4) {
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(z + base + i);
+        f32x4 gn = {0.f, 0.f, 0.f, 0.f}, gm = gn, gc = gn, de;
+        if (g_next) gn = *reinterpret_cast<const f32x4*>(g_next + base + i);
+        if (g_mean) gm = *reinterpret_cast<const f32x4*>(g_mean + base + i);
+        if (g_control) gc = *reinterpret_cast<const f32x4*>(g_control + base + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            de[e] = coef * (gn[e] + gm[e] + gc[e] + lp_mean * zv[e]);
+            acc += gn[e] * zv[e];
+            zz += zv[e] * zv[e];
+        }
+        *reinterpret_cast<f32x4*>(d_eps + base + i) = de;
+    }
+    acc = wave_sum(acc);
+    zz = wave_sum(zz);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = acc; red[1][threadIdx.x >> 6] = zz; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float a = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const float q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        d_sigma[b] = a + lp_sig * (q / (float)CHW - 1.f);
+    }
+}
+
 // im2col of a 3-channel NCHW fp32 image for the 3x3/s1/p1 stem convs: out[n,y,x,k] (64 wide, bf16),
 // k = ci*9 + ky*3 + kx for k < 27, zero otherwise.  Feeds the 1x1 weight-gradient GEMM of the stem.
 __global__ void im2col27_kernel(const float* __restrict__ x, bf16* __restrict__ out, int N, int H, int W) {
@@ -610,6 +664,28 @@ extern "C" int dxmi_edm_step_fwd(const float* x, const float* model_out, const f
     hipLaunchKernelGGL(edm_step_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, x, model_out, z, sigma, sigma_down, sigma_up,
                        sample, mean, CHW, sigma_data);
     DXMI_CHECK_LAUNCH("dxmi_edm_step_fwd");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_var_step_bwd(const float* g_next, const float* g_mean, const float* g_control, const float* g_logp,
+                                 const float* z, const float* cmul, const float* sigma, float* d_eps, float* d_sigma, int32_t N,
+                                 int32_t CHW, void* stream) {
+    DXMI_CHECK_ARG(z && cmul && sigma && d_eps && d_sigma, "dxmi_var_step_bwd: null pointer");
+    DXMI_CHECK_ARG(N > 0 && CHW > 0 && CHW % 4 == 0, "dxmi_var_step_bwd: CHW (%d) must be a multiple of 4", CHW);
+    hipLaunchKernelGGL(step_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, g_next, g_mean, g_control, g_logp, z, cmul, sigma,
+                       (const float*)nullptr, 0.f, 0, d_eps, d_sigma, CHW);
+    DXMI_CHECK_LAUNCH("dxmi_var_step_bwd");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_edm_step_bwd(const float* g_sample, const float* g_mean, const float* z, const float* sigma,
+                                 const float* sigma_down, float* d_model_out, float* d_sigma_up, int32_t N, int32_t CHW,
+                                 float sigma_data, void* stream) {
+    DXMI_CHECK_ARG(z && sigma && sigma_down && d_model_out && d_sigma_up, "dxmi_edm_step_bwd: null pointer");
+    DXMI_CHECK_ARG(N > 0 && CHW > 0 && CHW % 4 == 0, "dxmi_edm_step_bwd: CHW (%d) must be a multiple of 4", CHW);
+    hipLaunchKernelGGL(step_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, g_sample, g_mean, (const float*)nullptr,
+                       (const float*)nullptr, z, (const float*)nullptr, sigma, sigma_down, sigma_data, 1, d_model_out, d_sigma_up, CHW);
+    DXMI_CHECK_LAUNCH("dxmi_edm_step_bwd");
     return DXMI_OK;
 }
 

@@ -87,6 +87,8 @@ SIGNATURES = {
     "dxmi_linear_splitk_slices": (c_int, [c_int, c_int, c_int]),
     "dxmi_linear_splitk": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_var_step_fwd": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int, c_void_p]),
+    "dxmi_var_step_bwd": (c_int, [c_void_p] * 9 + [c_int, c_int, c_void_p]),
+    "dxmi_edm_step_bwd": (c_int, [c_void_p] * 7 + [c_int, c_int, c_float, c_void_p]),
     "dxmi_var_gather_sched": (c_int, [c_void_p] * 9 + [c_int, c_int, c_void_p]),
     "dxmi_pool_act": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "dxmi_value_head": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -1041,6 +1041,35 @@ def var_step(x, eps, z, xmul, cmul, sigma, want_mean=True, want_control=True, ou
     return x_next, mean, control, logp
 
 
+def var_step_bwd(g_next, g_mean, g_control, g_logp, z, cmul, sigma):
+    """Backward of the VAR transition (dxmi_var_step_bwd): -> (d eps [N, ...], d sigma [N]); any gradient may be None."""
+    _need_cuda(g_next, g_mean, g_control, g_logp, z, cmul, sigma)
+    N = z.shape[0]
+    CHW = z.numel() // N
+    for t_ in (g_next, g_mean, g_control, z):
+        assert t_ is None or (t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == N * CHW)
+    assert g_logp is None or (g_logp.dtype == torch.float32 and g_logp.is_contiguous() and g_logp.numel() == N)
+    d_eps = torch.empty_like(z)
+    d_sigma = torch.empty(N, dtype=torch.float32, device=z.device)
+    check(load().dxmi_var_step_bwd(_ptr(g_next), _ptr(g_mean), _ptr(g_control), _ptr(g_logp), _ptr(z), _ptr(cmul), _ptr(sigma), _ptr(d_eps),
+                                   _ptr(d_sigma), N, CHW, _stream()), "dxmi_var_step_bwd")
+    return d_eps, d_sigma
+
+
+def edm_step_bwd(g_sample, g_mean, z, sigma, sigma_down, sigma_data=0.5):
+    """Backward of the EDM transition (dxmi_edm_step_bwd): -> (d model_output, d sigma_up [N])."""
+    _need_cuda(g_sample, g_mean, z, sigma, sigma_down)
+    N = z.shape[0]
+    CHW = z.numel() // N
+    for t_ in (g_sample, g_mean, z):
+        assert t_ is None or (t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == N * CHW)
+    d_out = torch.empty_like(z)
+    d_up = torch.empty(N, dtype=torch.float32, device=z.device)
+    check(load().dxmi_edm_step_bwd(_ptr(g_sample), _ptr(g_mean), _ptr(z), _ptr(sigma), _ptr(sigma_down), _ptr(d_out), _ptr(d_up), N, CHW,
+                                   float(sigma_data), _stream()), "dxmi_edm_step_bwd")
+    return d_out, d_up
+
+
 def pool_act(x, pool, act, out=None):
     _need_cuda(x, out)
     N, H, W, C = x.shape

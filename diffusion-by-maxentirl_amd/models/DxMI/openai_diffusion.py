@@ -20,6 +20,27 @@ from dxmi_hip._lib import DxmiError
 from models.cm.karras_diffusion import get_sigmas_karras
 
 
+class _EdmStepFn(torch.autograd.Function):
+    """(x, model_output, z, sigma, sigma_down, sigma_up) -> (x', mu); gradients flow to model_output and sigma_up (x is the buffered
+    state, z the draw, the sigma ladder a constant table)."""
+
+    @staticmethod
+    def forward(ctx, x, model_output, z, sigma, sigma_down, sigma_up, sigma_data):
+        z, sg, sdn = z.contiguous().float(), sigma.contiguous().float(), sigma_down.contiguous().float()
+        samples, mu = ops.edm_step(x.contiguous().float(), model_output.contiguous().float(), z, sg, sdn,
+                                   sigma_up.detach().float().contiguous(), sigma_data)
+        ctx.save_for_backward(z, sg, sdn)
+        ctx.sigma_data = sigma_data
+        return samples, mu
+
+    @staticmethod
+    def backward(ctx, g_sample, g_mu):
+        z, sg, sdn = ctx.saved_tensors
+        c = lambda g: None if g is None else g.contiguous().float()
+        d_out, d_up = ops.edm_step_bwd(c(g_sample), c(g_mu), z, sg, sdn, ctx.sigma_data)
+        return None, d_out, None, None, None, d_up, None
+
+
 class OpenAIDiffusion:
     def __init__(self, model, diffusion, n_timesteps, sample_shape, class_cond=False, num_classes=0, trainable_beta=False,
                  sigma_min=0.002, sigma_max=80., stochastic_last=False, rho=7.0):
@@ -92,19 +113,14 @@ class OpenAIDiffusion:
 
     def _sample_step_grad(self, x, z, sigma, sigma_down, sigma_up, model_kwargs):
         """Training path (policy update, trainer.py:693-746): the U-Net runs its HIP forward/backward through
-        models/cm/unet_train.py; the few element-wise lines around it stay torch autograd ops so that the loss reaches
-        the network output and the learnable `log_betas` exactly as in the reference (:71-94)."""
-        sd = self.diffusion.sigma_data
-        e = lambda v: v[:, None, None, None]
-        c_skip = sd ** 2 / (sigma ** 2 + sd ** 2)
-        c_out = sigma * sd / (sigma ** 2 + sd ** 2) ** 0.5
-        c_in = 1 / (sigma ** 2 + sd ** 2) ** 0.5
-        rescaled_t = 1000 * 0.25 * torch.log(sigma + 1e-44)
-        model_output = self.net(e(c_in) * x, rescaled_t, **model_kwargs)
-        denoised = e(c_out) * model_output + e(c_skip) * x
-        d = (x - denoised) / e(sigma)
-        mu = x + d * e(sigma_down - sigma)
-        samples = mu + z * e(sigma_up)
+        models/cm/unet_train.py; the transition around it is the fused forward kernels of the inference path (dxmi_edm_precond,
+        dxmi_edm_step_fwd) and ONE backward kernel (dxmi_edm_step_bwd: the gradient of the network output and the per-sample
+        sigma_up gradient, reduced on the device) — round 6; it was ~15 torch elementwise launches forward and as many backward.
+        The loss reaches the network output and the learnable `log_betas` (through `sigma_up = exp(log_betas[idx])`, torch ops) exactly
+        as in the reference (:71-94)."""
+        x_in, rescaled_t = ops.edm_precond(x, sigma.contiguous(), self.diffusion.sigma_data)
+        model_output = self.net(x_in, rescaled_t, **model_kwargs)
+        samples, mu = _EdmStepFn.apply(x, model_output, z, sigma, sigma_down, sigma_up, self.diffusion.sigma_data)
         return {"sample": samples, "mean": mu, "sigma": sigma_up.clamp(1e-4, None)}
 
     def sample(self, n_sample, device, i_class=None, enable_grad=False, x0=None, noise=None, out=None):

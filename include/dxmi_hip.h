@@ -349,6 +349,20 @@ int dxmi_var_step_fwd(const float* x, const float* eps, const float* z,
                       float* x_next, float* mean, float* control, float* logp,
                       int32_t N, int32_t CHW, int32_t assoc, void* stream);
 
+/* Backward of the VAR transition for the differentiable `sample_step` of the policy update (reference var_sampler.py:357-408 under
+ * torch autograd): with x' = xm x + c eps + sigma z, mean = xm x + c eps, control = c eps and logp as dxmi_var_step_fwd forms it
+ * (x' detached inside), given the gradients of the loss w.r.t. x' / mean / control ([N, CHW]) and logp ([N]) — any may be NULL —
+ *   d_eps = c (g_next + g_mean + g_control + g_logp z / (sigma CHW))       d_sigma[n] = sum g_next z + g_logp (mean z^2 - 1) / sigma
+ * (cmul = theta multiplier x adhoc_scale1, per sample).  The sigma gradient is reduced in-kernel in a fixed order; the caller chains it
+ * into log_betas (sigma = exp(log_betas[t])). */
+int dxmi_var_step_bwd(const float* g_next, const float* g_mean, const float* g_control, const float* g_logp, const float* z,
+                      const float* cmul, const float* sigma, float* d_eps, float* d_sigma, int32_t N, int32_t CHW, void* stream);
+
+/* Backward of the EDM transition (openai_diffusion.py:71-94): d_model_out = -(c_out (sigma_down - sigma) / sigma) (g_sample + g_mean),
+ * d_sigma_up[n] = sum g_sample z; g_sample / g_mean may be NULL. */
+int dxmi_edm_step_bwd(const float* g_sample, const float* g_mean, const float* z, const float* sigma, const float* sigma_down,
+                      float* d_model_out, float* d_sigma_up, int32_t N, int32_t CHW, float sigma_data, void* stream);
+
 /* INT path: per-sample gather of schedule tables by integer timestep
  * (var_sampler.py:363-376,389; models/diffusion.py:18-22).  Writes
  *   tau[b] = continuous_steps[t[b]], xmul[b], cmul[b] (theta multiplier), sigma[b] =

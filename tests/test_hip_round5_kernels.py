@@ -251,3 +251,55 @@ def test_groupnorm_apply_split_is_bit_identical():
             outs.append(ops.groupnorm_apply(x0, s0, ga, be, in1=x1, st1=s1, eps=1e-5, silu=True, scale_shift=sst))
         ops.GN_APPLY_SPLIT = False
         assert torch.equal(outs[0], outs[1]), (N, H, C0, C1, ss)
+
+
+def test_var_and_edm_step_backward_vs_torch_autograd():
+    """dxmi_var_step_bwd / dxmi_edm_step_bwd (round 6) against torch autograd over the reference's elementwise expressions
+    (var_sampler.py:357-408 incl. the log-prob with x' detached; openai_diffusion.py:71-94), every output contributing to the loss."""
+    import math
+    import torch
+    from models.DxMI.openai_diffusion import _EdmStepFn
+    from models.DxMI.var_sampler_train import _VarStepFn
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(17)
+    B, shape = 6, (3, 32, 32)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    x, z = r(B, *shape), r(B, *shape)
+    xm, cm = r(B).abs() + 0.5, -r(B).abs() - 0.1
+    wn, wm, wc, wl = r(B, *shape), r(B, *shape), r(B, *shape), r(B)          # weights of the four outputs in the loss
+    e = lambda v: v[:, None, None, None]
+
+    def loss_of(xn, mean, control, logp):
+        return (xn * wn).sum() + (mean * wm).sum() + (control * wc).sum() + (logp * wl).sum()
+    eps1 = r(B, *shape).requires_grad_(True)
+    lb1 = (r(B) * 0.3 - 1.0).requires_grad_(True)
+    sg = torch.exp(lb1)
+    mean = x * e(xm) + e(cm) * eps1
+    xn = mean + e(sg) * z
+    lp = (-((xn.detach() - mean) ** 2) / (2 * e(sg) ** 2) - torch.log(e(sg)) - math.log(math.sqrt(2 * math.pi))).mean((1, 2, 3))
+    loss_of(xn, mean, e(cm) * eps1, lp).backward()
+    eps2 = eps1.detach().clone().requires_grad_(True)
+    lb2 = lb1.detach().clone().requires_grad_(True)
+    out = _VarStepFn.apply(x, eps2, z, xm, cm, torch.exp(lb2))
+    assert torch.allclose(out[0], xn.detach(), atol=1e-5) and torch.allclose(out[3], lp.detach(), atol=1e-5)
+    loss_of(*out).backward()
+    assert torch.allclose(eps2.grad, eps1.grad, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(lb2.grad, lb1.grad, rtol=1e-4, atol=1e-4), (lb2.grad, lb1.grad)
+    # EDM
+    sd = 0.5
+    sigma, sdn = r(B).abs() * 3 + 0.05, r(B).abs() * 0.5 + 0.01
+    f1 = r(B, *shape).requires_grad_(True)
+    u1 = (r(B) * 0.3 - 0.5).requires_grad_(True)
+    c_skip = sd ** 2 / (sigma ** 2 + sd ** 2)
+    c_out = sigma * sd / (sigma ** 2 + sd ** 2) ** 0.5
+    den = e(c_out) * f1 + e(c_skip) * x
+    mu = x + (x - den) / e(sigma) * e(sdn - sigma)
+    smp = mu + z * e(torch.exp(u1))
+    ((smp * wn).sum() + (mu * wm).sum()).backward()
+    f2 = f1.detach().clone().requires_grad_(True)
+    u2 = u1.detach().clone().requires_grad_(True)
+    s2, m2 = _EdmStepFn.apply(x, f2, z, sigma, sdn, torch.exp(u2), sd)
+    assert torch.allclose(s2, smp.detach(), rtol=1e-5, atol=1e-4) and torch.allclose(m2, mu.detach(), rtol=1e-5, atol=1e-4)
+    ((s2 * wn).sum() + (m2 * wm).sum()).backward()
+    assert torch.allclose(f2.grad, f1.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(u2.grad, u1.grad, rtol=1e-4, atol=1e-3)
