@@ -24,6 +24,16 @@ namespace {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define LDS_S16X4(p) ((__attribute__((address_space(3))) s16x4*)(p))
 
+// Workgroup b runs on XCD b % 8 (round-robin dispatch, one L2 per XCD): with consecutive block ids the query blocks of one (image,
+// head) — which all stream the SAME K and V — sat on different XCDs and K / V were fetched once per query block.  Logical ids that are
+// consecutive within an XCD put them behind one L2 (any grid size).
+__device__ __forceinline__ int attn_xcd_logical(int b, int G, int on) {
+    if (!on) return b;
+    const int x = b & 7, k = b >> 3;
+    const int q = G >> 3, r = G & 7;
+    return x * q + (x < r ? x : r) + k;
+}
+
 struct AttnArgs {
     const bf16* qkv;
     bf16* out;
@@ -35,6 +45,7 @@ struct AttnArgs {
     const float* pbias;     // [256]
     const bf16* res;        // [N,256,256] (the AttnBlock's input x)
     float* gn_stats;        // optional: GroupNorm block statistics of the output, [N][8][128][2] (a partial per 32 tokens)
+    int xcd;             // XCD-aware block order (round 6): the query blocks of one (image, head) share K / V behind one L2
 };
 
 #ifndef ATTN_WPE
@@ -58,9 +69,10 @@ __global__ __launch_bounds__(256, D == 64 ? ATTN_WPE : 1) void attention_kernel(
     const int tr_krow = 4 * (trg >> 1) + trq;   // key order of a k-step follows the S^T accumulator layout: 8(j>>2) + 4h + (j&3)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qblocks = (p.T + 127) / 128;
-    const int qb = blockIdx.x % qblocks;
-    const int hd = (blockIdx.x / qblocks) % p.heads;
-    const int n = blockIdx.x / (qblocks * p.heads);
+    const int bid = attn_xcd_logical(blockIdx.x, gridDim.x, p.xcd);
+    const int qb = bid % qblocks;
+    const int hd = (bid / qblocks) % p.heads;
+    const int n = bid / (qblocks * p.heads);
     const int C3 = 3 * p.C;
     const bf16* base = p.qkv + (size_t)n * p.T * C3;
     const int qc = p.q_off + hd * p.head_stride;
@@ -265,9 +277,10 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs p) {
     const int tr_krow = 4 * (trg >> 1) + trq;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qblocks = p.T >> 8;
-    const int qb = blockIdx.x % qblocks;
-    const int hd = (blockIdx.x / qblocks) % p.heads;
-    const int n = blockIdx.x / (qblocks * p.heads);
+    const int bid = attn_xcd_logical(blockIdx.x, gridDim.x, p.xcd);
+    const int qb = bid % qblocks;
+    const int hd = (bid / qblocks) % p.heads;
+    const int n = bid / (qblocks * p.heads);
     const int C3 = 3 * p.C;
     const bf16* base = p.qkv + (size_t)n * p.T * C3;
     const int qc = p.q_off + hd * p.head_stride, kc = p.k_off + hd * p.head_stride, vc = p.v_off + hd * p.head_stride;
@@ -786,6 +799,7 @@ extern "C" int dxmi_attention_proj_fwd(const void* qkv, const void* wproj_packed
     a.qkv = (const bf16*)qkv; a.out = (bf16*)out; a.N = N; a.T = T; a.C = C; a.heads = heads;
     a.q_off = 0; a.k_off = C; a.v_off = 2 * C; a.head_stride = C; a.scale = scale;
     a.wproj = (const bf16*)wproj_packed; a.pbias = bias; a.res = (const bf16*)residual; a.gn_stats = gn_stats;
+    a.xcd = 0;
     return launch_attn256(a, (hipStream_t)stream);
 }
 
@@ -798,6 +812,8 @@ extern "C" int dxmi_attention_fwd(const void* qkv, void* out, int32_t N, int32_t
     a.qkv = (const bf16*)qkv; a.out = (bf16*)out; a.N = N; a.T = T; a.C = C; a.heads = heads;
     a.q_off = 0; a.k_off = C; a.v_off = 2 * C; a.head_stride = D; a.scale = scale;
     a.wproj = nullptr; a.pbias = nullptr; a.res = nullptr; a.gn_stats = nullptr;
+    static const int xcd_env = getenv("DXMI_ATTN_XCD") ? atoi(getenv("DXMI_ATTN_XCD")) : 1;      // 0: hardware block order (A/B timing)
+    a.xcd = xcd_env;
     hipStream_t st = (hipStream_t)stream;
     static const int v1 = getenv("DXMI_ATTN_GENERIC") ? atoi(getenv("DXMI_ATTN_GENERIC")) : 0;   // 1: generic kernel for every shape
     if (D == 256 && T == 256 && heads == 1 && !v1) return launch_attn256(a, st);

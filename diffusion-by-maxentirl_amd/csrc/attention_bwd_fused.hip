@@ -29,6 +29,13 @@ namespace {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 #define LDS_S16X4(p) ((__attribute__((address_space(3))) s16x4*)(p))
 
+__device__ __forceinline__ int ab_xcd_logical(int b, int G, int on) {
+    if (!on) return b;
+    const int x = b & 7, k = b >> 3;
+    const int q = G >> 3, r = G & 7;
+    return x * q + (x < r ? x : r) + k;
+}
+
 struct AttnBwdArgs {
     const bf16* qkv;     // [N, T, 3C]  q | k | v, heads = contiguous channel blocks of D
     const bf16* o;       // [N, T, C]   attention output of the forward pass
@@ -38,6 +45,7 @@ struct AttnBwdArgs {
     float* delta;        // [N, heads, T]
     int N, T, C, heads;
     float scale;
+    int xcd;             // XCD-aware block order: the query / key blocks of one (image, head) behind one L2 (see attention.hip)
 };
 
 constexpr int AB_D = 64;
@@ -86,9 +94,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int tr_krow = 4 * (trg >> 1) + trq;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qblocks = (p.T + 127) / 128;
-    const int qb = blockIdx.x % qblocks;
-    const int hd = (blockIdx.x / qblocks) % p.heads;
-    const int n = blockIdx.x / (qblocks * p.heads);
+    const int bid = ab_xcd_logical(blockIdx.x, gridDim.x, p.xcd);
+    const int qb = bid % qblocks;
+    const int hd = (bid / qblocks) % p.heads;
+    const int n = bid / (qblocks * p.heads);
     const int C3 = 3 * p.C;
     const bf16* base = p.qkv + (size_t)n * p.T * C3;
     const int qc = hd * AB_D, kc = p.C + hd * AB_D, vc = 2 * p.C + hd * AB_D;
@@ -229,9 +238,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
     const int tr_krow = 4 * (trg >> 1) + trq;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kblocks = (p.T + 127) / 128;
-    const int kbk = blockIdx.x % kblocks;
-    const int hd = (blockIdx.x / kblocks) % p.heads;
-    const int n = blockIdx.x / (kblocks * p.heads);
+    const int bid = ab_xcd_logical(blockIdx.x, gridDim.x, p.xcd);
+    const int kbk = bid % kblocks;
+    const int hd = (bid / kblocks) % p.heads;
+    const int n = bid / (kblocks * p.heads);
     const int C3 = 3 * p.C;
     const bf16* base = p.qkv + (size_t)n * p.T * C3;
     const bf16* dob = p.dout + (size_t)n * p.T * p.C + hd * AB_D;
@@ -350,6 +360,8 @@ extern "C" int dxmi_attention_bwd(const void* qkv, const void* o, const void* do
     a.qkv = (const bf16*)qkv; a.o = (const bf16*)o; a.dout = (const bf16*)dout; a.dqkv = (bf16*)dqkv;
     a.lse = (float*)workspace; a.delta = a.lse + (size_t)N * heads * T;
     a.N = N; a.T = T; a.C = C; a.heads = heads; a.scale = scale;
+    static const int xcd_env = getenv("DXMI_ATTN_XCD") ? atoi(getenv("DXMI_ATTN_XCD")) : 1;      // 0: hardware block order (A/B timing)
+    a.xcd = xcd_env;
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (T + 127) / 128;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(N * heads * blocks), dim3(256), 0, st, a);

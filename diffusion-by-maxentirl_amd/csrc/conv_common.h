@@ -29,7 +29,18 @@ struct ConvArgs {
     float gn_eps;
     int gn_flags;            // bit 0: SiLU, bit 1: skip the raw output
     int res_is_mask;         // conv_ws_kernel: `residual` carries the activation-mask source (out *= mask > 0 ? 1 : mask_slope), set by its launcher
+    int xcd_order;           // conv_ws_kernel / conv_ws8_kernel (set by their launchers): tiles handed out in XCD-aware order
 };
+
+// Persistent kernels: workgroup b runs on XCD b % 8 (round-robin dispatch; each XCD has its own L2).  Logical workgroup ids that are
+// consecutive WITHIN an XCD make the tiles a launch works on at the same time — the cout tiles of one pixel tile, the neighbouring
+// strips of one image (shared halo rows) — neighbours behind ONE L2 (any grid size: XCD j owns G / 8 + (j < G % 8) workgroups).
+__device__ __forceinline__ int dxmi_xcd_logical(int b, int G, int on) {
+    if (!on) return b;
+    const int x = b & 7, k = b >> 3;
+    const int q = G >> 3, r = G & 7;
+    return x * q + (x < r ? x : r) + k;
+}
 
 // Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15): every lane of the row ends with the row's total.  Each step adds
 // two partial sums over disjoint, equally shaped lane sets, so all lanes hold bitwise the same value.

@@ -36,7 +36,20 @@ struct WgradArgs {
     int TWl, THl, SUBS, HH, HWd;  // 128-pixel tile geometry + halo
     int PT, S;                    // pixel tiles, pixel splits
     int CIB, COB;                 // 64-wide ci / co blocks
+    int xcd;                      // XCD-aware block order (round 6; DXMI_WGRAD_XCD=0: hardware order)
 };
+
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8), each with its own L2.  The (co, ci) blocks of one
+// pixel split stream the SAME dY and X tiles; with consecutive block ids they sat on different XCDs and every tile was fetched from
+// HBM once per block that needs it (128 -> 128 @32x32, 256 images: 208 MB per launch against 67 MB of operands, round-5 PMC pass —
+// the kernel ran at the HBM rate of that traffic, not at its MFMA rate).  Logical ids that are consecutive WITHIN an XCD put the
+// blocks of a split behind one L2 (any grid size: XCD j owns G / 8 + (j < G % 8) workgroups).
+__device__ __forceinline__ int wg_logical_block(int b, int G, int on) {
+    if (!on) return b;
+    const int x = b & 7, k = b >> 3;
+    const int q = G >> 3, r = G & 7;
+    return x * q + (x < r ? x : r) + k;
+}
 
 constexpr int WG_PITCH = 192;  // bytes per LDS pixel row (64 channels bf16 + 64 pad)
 
@@ -66,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;  // 32-co / 32-ci sub-block of the 64x64 block
     // block -> (split, co block, ci block)
-    int b = blockIdx.x;
+    int b = wg_logical_block(blockIdx.x, gridDim.x, p.xcd);
     const int cib = b % p.CIB; b /= p.CIB;
     const int cob = b % p.COB; b /= p.COB;
     const int split = b;
@@ -252,7 +265,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_ws_kernel(WgradArgs p, const c
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int b = blockIdx.x;
+    int b = wg_logical_block(blockIdx.x, gridDim.x, p.xcd);
     const int cib = b % p.CIB; b /= p.CIB;
     const int cob = b % p.COB; b /= p.COB;
     const int split = b;
@@ -413,7 +426,7 @@ __global__ __launch_bounds__(768) void conv_wgrad1x1_b128_kernel(WgradArgs p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int b = blockIdx.x;
+    int b = wg_logical_block(blockIdx.x, gridDim.x, p.xcd);
     const int cib = b % p.CIB; b /= p.CIB;
     const int cob = b % p.COB; b /= p.COB;
     const int split = b;
@@ -849,6 +862,11 @@ static int wgrad_impl(const void* x0, int32_t C0, const void* x1, int32_t C1, co
     DXMI_CHECK_ARG((OW & (OW - 1)) == 0 && (OH & (OH - 1)) == 0 && OW >= 4 && OH >= 4, "dxmi_conv2d_wgrad: OH/OW must be powers of two >= 4");
     DXMI_CHECK_ARG(C1 == 0 || x1, "dxmi_conv2d_wgrad: C1>0 but x1 NULL");
     WgradArgs a;
+    static const int xcd_env = getenv("DXMI_WGRAD_XCD") ? atoi(getenv("DXMI_WGRAD_XCD")) : 1;
+    // measured (tools/wgrad_time.py, same box alternating): 1x1 256 -> 768 @16x16 57.5 -> 35.7 us, 256 -> 256 28.5 -> 20.2 us, 3x3 384 -> 128
+    // @32x32 216 -> 203.5 us, 256 -> 128 142.8 -> 136.9 us, 128 -> 128 unchanged; the 8x8 / 4x4 maps lose 5-10 % (their tiles already
+    // share an L2 by accident of the split count): hardware order there
+    a.xcd = xcd_env && (long)OH * OW >= 256;
     a.x0 = (const bf16*)x0; a.x1 = (const bf16*)x1; a.dy = (const bf16*)dy; a.partial = (float*)workspace;
     a.N = N; a.IH = IH; a.IW = IW; a.C0 = C0; a.C1 = C1; a.OH = OH; a.OW = OW; a.Cout = Cout;
     a.ksize = ksize; a.pad = pad; a.ups = upsample ? 1 : 0; a.stride = stride;

@@ -224,7 +224,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
         t.ox0 = tx * TW;
     };
 
-    int q = blockIdx.x;
+    const int q0 = dxmi_xcd_logical(blockIdx.x, gridDim.x, p.xcd_order);
+    int q = q0;
     if (q >= ntiles) return;
     const int qstride = gridDim.x;
     if (blockIdx.x == 0 && tid == 0) {
@@ -310,9 +311,9 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            WS_TSTAMP(158, wave == 0 && q == (int)blockIdx.x);
+            WS_TSTAMP(158, wave == 0 && q == q0);
             ws_barrier();                               // E1: residual tile + bias / temb table of this tile landed
-            WS_TSTAMP(159, wave == 0 && q == (int)blockIdx.x);
+            WS_TSTAMP(159, wave == 0 && q == q0);
             {
                 // acc + bias + temb (+ residual) -> activation -> bf16 -> output tile, in place, accumulator layout:
                 // lane = pixel (lane & 15) of a 16-pixel block, couts 4 * (lane >> 4) .. + 3 of a 16-cout block.  The epilogue is
@@ -401,9 +402,9 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
                     else epi(F_{}, F_{}, T_{}, T_{});
                 }
             }
-            WS_TSTAMP(166, wave == 0 && q == (int)blockIdx.x);
+            WS_TSTAMP(166, wave == 0 && q == q0);
             ws_barrier();                               // E2: output tile complete, the bulk movers may drain it
-            WS_TSTAMP(157, wave == 0 && q == (int)blockIdx.x);
+            WS_TSTAMP(157, wave == 0 && q == q0);
             if (!more) {
                 WS_CLOCKSTAMP(170, wave == 0);
                 break;
@@ -540,7 +541,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
                         }
                     }
                     if (G > 0 || first_group0) load_group(G + 3, cur.cot, more ? nxt.cot : cur.cot, fq[(j + 1) & 1]);
-                    WS_TSTAMP(151, wave == 4 && G == 0 && q == (int)blockIdx.x + qstride);
+                    WS_TSTAMP(151, wave == 4 && G == 0 && q == q0 + qstride);
                     WS_VALU_RUN();
                     if (!(WS_DBG(16))) ws_barrier();                        // end of group step G
                 }
@@ -557,7 +558,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
             }
             ws_barrier();                                        // E1
             ws_barrier();                                        // E2
-            WS_TSTAMP(150, wave == 4 && q == (int)blockIdx.x);
+            WS_TSTAMP(150, wave == 4 && q == q0);
             if (!more) break;
             q += qstride;
             cur = nxt;
@@ -746,7 +747,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& p) {
     // ==================================================================== last tile out: all eight waves
     // (every wave has passed the last E2; the two bulk movers alone needed ~3 us for the 64 KB)
     {
-        const int qlast = (int)blockIdx.x + ((ntiles - 1 - (int)blockIdx.x) / qstride) * qstride;
+        const int qlast = q0 + ((ntiles - 1 - q0) / qstride) * qstride;
         WsTile lt;
         tile_of(qlast, lt);
         bf16* const ob = reinterpret_cast<bf16*>(p.out) + ((((size_t)lt.n0 * p.OH + lt.oy0) * p.OW + lt.ox0) * p.Cout + lt.cot * 128);
@@ -829,6 +830,8 @@ int conv_ws_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     b.PT = a.N * (a.OH / TH) * (a.OW / TW);
     b.CT = (a.Cout + 127) / 128;
     b.tile_px = 256;
+    static const int xcd_env = getenv("DXMI_CONV_WS_XCD") ? atoi(getenv("DXMI_CONV_WS_XCD")) : 1;
+    b.xcd_order = xcd_env;
 #ifdef DXMI_CONV_STAMPS
     static const int dbg = getenv("DXMI_CONV_WS_DBG") ? atoi(getenv("DXMI_CONV_WS_DBG")) : 0;
     b.stagger = dbg;

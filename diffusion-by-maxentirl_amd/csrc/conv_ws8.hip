@@ -92,7 +92,7 @@ __global__ __launch_bounds__(512, 1) void conv_ws8_kernel(ConvArgs p) {
         t.n0 = (q / p.CT) * 4;
     };
 
-    int q = blockIdx.x;
+    int q = dxmi_xcd_logical(blockIdx.x, gridDim.x, p.xcd_order);
     if (q >= ntiles) return;
     const int qstride = gridDim.x;
 
@@ -584,6 +584,8 @@ int conv_ws8_try_launch(ConvArgs& a, hipStream_t st, int* kernel_id) {
     b.PT = (a.N + 3) / 4;      // the last tile may hold fewer than four images (masked)
     b.CT = a.Cout / 64;
     b.tile_px = 256;
+    static const int xcd_env = getenv("DXMI_CONV_WS_XCD") ? atoi(getenv("DXMI_CONV_WS_XCD")) : 1;
+    b.xcd_order = xcd_env;
     const size_t lds = 2 * W8_HALO + W8_A_RING + W8_RO + W8_TB;
     int grid = b.PT * b.CT;
     if (grid > 256) grid = 256;
