@@ -44,7 +44,7 @@ MFMA_BF16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md, 
 HBM_PEAK_GBPS = 8000.0                # same table (spec; ~6.3 TB/s achievable)
 UNET_KW = dict(ch=128, out_ch=3, ch_mult=(1, 2, 2, 2), num_res_blocks=2, attn_resolutions=[16], dropout=0.1,
                in_channels=3, resolution=32)  # reference configs/cifar10/T10.yaml:1-10
-PMC_FILE = "profiles/r05_pmc_traffic.json"
+PMC_FILE = "profiles/r06_pmc_traffic.json"
 
 
 def parse_args():

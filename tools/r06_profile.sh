@@ -1,19 +1,19 @@
-# Round-6 profile passes (run on the GPU box through gpurun; writes under gpurun_out/).  rocprofv3 is given the program
+# Round-6 profile passes (the --pmc passes issue every launch from python, DXMI_GRAPH=0: counters are collected per dispatch) (run on the GPU box through gpurun; writes under gpurun_out/).  rocprofv3 is given the program
 # itself (python3 ...), counters in their own passes without trace domains, as MI355X_MICROARCH.md prescribes.
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 rm -rf gpurun_out/r06_prof_* gpurun_out/r06_pmc_*
 B="python3 bench.py --no-cpu-baseline --no-eager-reference --no-events --no-edm --no-small-batch"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r06_prof_bench -- $B --steps 5 --warmup 2 --train-steps 0 > gpurun_out/r06_prof_bench.json 2> gpurun_out/r06_prof_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r06_prof_train -- $B --steps 1 --warmup 1 --train-steps 3 > gpurun_out/r06_prof_train.json 2> gpurun_out/r06_prof_train.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r06_pmc_FETCH_SIZE -- $B --steps 2 --warmup 1 --train-steps 0 > /dev/null 2> gpurun_out/r06_pmc_f.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/r06_pmc_WRITE_SIZE -- $B --steps 2 --warmup 1 --train-steps 0 > /dev/null 2> gpurun_out/r06_pmc_w.err
+DXMI_GRAPH=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r06_pmc_FETCH_SIZE -- $B --steps 2 --warmup 1 --train-steps 0 > /dev/null 2> gpurun_out/r06_pmc_f.err
+DXMI_GRAPH=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/r06_pmc_WRITE_SIZE -- $B --steps 2 --warmup 1 --train-steps 0 > /dev/null 2> gpurun_out/r06_pmc_w.err
 # train leg: HBM traffic of the backward kernels (wgrad, GroupNorm backward ...)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r06_pmc_train_FETCH_SIZE -- $B --steps 1 --warmup 0 --train-steps 1 > /dev/null 2> gpurun_out/r06_pmc_tf.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/r06_pmc_train_WRITE_SIZE -- $B --steps 1 --warmup 0 --train-steps 1 > /dev/null 2> gpurun_out/r06_pmc_tw.err
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/r06_pmc_sq1 -- $B --steps 2 --warmup 1 --train-steps 0 > /dev/null 2> gpurun_out/r06_pmc_s1.err
-rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/r06_pmc_sq2 -- $B --steps 2 --warmup 1 --train-steps 0 > /dev/null 2> gpurun_out/r06_pmc_s2.err
+DXMI_GRAPH=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/r06_pmc_train_FETCH_SIZE -- $B --steps 1 --warmup 0 --train-steps 1 > /dev/null 2> gpurun_out/r06_pmc_tf.err
+DXMI_GRAPH=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/r06_pmc_train_WRITE_SIZE -- $B --steps 1 --warmup 0 --train-steps 1 > /dev/null 2> gpurun_out/r06_pmc_tw.err
+DXMI_GRAPH=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/r06_pmc_sq1 -- $B --steps 2 --warmup 1 --train-steps 0 > /dev/null 2> gpurun_out/r06_pmc_s1.err
+DXMI_GRAPH=0 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_MFMA SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/r06_pmc_sq2 -- $B --steps 2 --warmup 1 --train-steps 0 > /dev/null 2> gpurun_out/r06_pmc_s2.err
 # train leg SQ pass (MFMA busy of the wgrad kernel)
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/r06_pmc_train_sq1 -- $B --steps 1 --warmup 0 --train-steps 1 > /dev/null 2> gpurun_out/r06_pmc_ts1.err
+DXMI_GRAPH=0 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/r06_pmc_train_sq1 -- $B --steps 1 --warmup 0 --train-steps 1 > /dev/null 2> gpurun_out/r06_pmc_ts1.err
 # EDM: ImageNet-64 generation, LSUN generation, ImageNet-64 train step
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r06_prof_edm_in64 -- python3 tools/edm_bench.py imagenet64_T10 100 > gpurun_out/r06_prof_edm_in64.out 2> gpurun_out/r06_prof_edm_in64.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r06_prof_edm_lsun -- python3 tools/edm_bench.py lsun_bedroom_T4 16 > gpurun_out/r06_prof_edm_lsun.out 2> gpurun_out/r06_prof_edm_lsun.err
