@@ -29,6 +29,11 @@ python3 tools/graph_node_cost.py > gpurun_out/r06_graph_node_cost.txt 2>&1
 python3 tools/td_fused_ab.py > gpurun_out/r06_td_fused_ab.txt 2>&1
 python3 tools/small_batch_routing.py > gpurun_out/r06_small_batch_routing.txt 2>&1
 python3 bench.py > gpurun_out/r06_bench_final.json 2> gpurun_out/r06_bench_final.err
-# keep the merge-back small: the traces are only needed as per-kernel statistics
-find gpurun_out -name "*kernel_trace.csv" -size +20M -delete
+# summaries are made HERE (the raw traces / counter dumps exceed what gpurun merges back): profiles/r06_* -> gpurun_out/r06_profiles/
+python3 tools/refresh_profiles.py r06 > gpurun_out/r06_refresh.log 2>&1
+mkdir -p gpurun_out/r06_profiles && cp profiles/r06_* gpurun_out/r06_profiles/
+for f in gpurun_out/r06_graph_*_b32 gpurun_out/r06_prof_edm_train_graph; do python3 tools/kstats.py $f 45 > gpurun_out/r06_profiles/$(basename $f)_kernel_stats_summary.txt 2>&1; done
+cp gpurun_out/r06_graph_*.out gpurun_out/r06_prof_edm_train_graph.out gpurun_out/r06_*.txt gpurun_out/r06_profiles/ 2>/dev/null
+tail -3 gpurun_out/*.err | tail -40
+rm -rf gpurun_out/r06_prof_* gpurun_out/r06_pmc_* gpurun_out/r06_graph_gen_b32 gpurun_out/r06_graph_train_b32
 ls gpurun_out | grep r06 | head -40; du -sh gpurun_out
