@@ -15,8 +15,15 @@ import torch.distributed as dist  # noqa: E402
 
 def main():
     rank = int(os.environ["RANK"])
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+    backend = os.environ.get("DXMI_TEST_BACKEND", "nccl")
+    if backend == "gloo":
+        # world-size-2 run on ONE GPU: RCCL refuses two ranks on a device, gloo moves device tensors through the host — the
+        # collectives are real (two processes, different data), only the transport differs
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
     import test_hip_graph as tg
     out = tg.cut_check()
     if rank == 0:

@@ -146,7 +146,46 @@ def cut_check():
     allc = [torch.zeros_like(chk) for _ in range(world)]
     dist.all_gather(allc, chk)
     out["ranks_identical"] = all(torch.equal(allc[0], c) for c in allc)
+    if world > 1:
+        # the EDM iteration too: MixedPrecisionTrainer exchanges the U-Net's gradients inside optimize() — one cut per policy iteration
+        ee, es, _ = _edm_train("eager", 3, data_seed=9 + rank)
+        eg, gs, tr2 = _edm_train("graph", 3, data_seed=9 + rank)
+        segs2 = {k[0]: [kind for kind, _ in g.segments] for k, g in tr2._graphs.items()}
+        out["edm_sampler_cuts"] = segs2["update_sampler_mp"].count("eager")
+        out["edm_params_equal"] = all(torch.equal(es[n][k], gs[n][k]) for n in ("unet", "v") for k in es[n]) and es["lg"] == gs["lg"] and es["steps"] == gs["steps"]
+        chk = torch.tensor([sum(t.double().sum().item() for t in gs[n].values() if t.is_floating_point()) for n in ("unet", "v")], device=dev, dtype=torch.float64)
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        out["edm_ranks_identical"] = all(torch.equal(allc[0], c) for c in allc)
     return out
+
+
+def test_graph_cut_two_ranks_on_one_gpu_gloo():
+    """The captured train step with a REAL two-rank exchange on the one GPU of the test box: two processes share cuda:0 and
+    all-reduce their (different) gradients over gloo at the graph cuts.  Every rank must end the replayed steps with the parameters
+    the python-issued two-rank run gives (bitwise) and with its peer's parameters."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DXMI_TEST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(here, "_graph_cut_worker.py")], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    line = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
+    T = line["T"]
+    assert line["world"] == 2 and line["f_v_eager_cuts"] == T + 1 and line["sampler_eager_cuts"] == 1
+    assert line["logs_close"] and line["params_equal"] and line["ranks_identical"]
+    assert line["edm_sampler_cuts"] == 4 and line["edm_params_equal"] and line["edm_ranks_identical"]        # T * B / B = 4 policy iterations
 
 
 def test_graph_cut_runs_collective_between_segments():
@@ -190,7 +229,7 @@ EDM_TRAINER_KW = dict(tau1=0.1, tau2=0.01, gamma=1, n_timesteps=4, use_sampler_b
                       velocity_in_value=None, value_grad_clip=True, time_cost=0, skip_sampler_tau=1, time_cost_sig=1)
 
 
-def _edm_train(mode, steps, lg0=20.0, B=4):
+def _edm_train(mode, steps, lg0=20.0, B=4, data_seed=9):
     from dxmi_hip.optim import Adam, RAdam
     from models.cm.fp16_util import MixedPrecisionTrainer
     from models.cm.script_util import create_model_and_diffusion
@@ -219,7 +258,7 @@ def _edm_train(mode, steps, lg0=20.0, B=4):
     ring = TransitionRing(1, T, B, (3, 32, 32), dev, with_y=True, sigma_dims=1)
     torch.manual_seed(5)
     torch.cuda.manual_seed(6)
-    g = torch.Generator(device=dev).manual_seed(9)
+    g = torch.Generator(device=dev).manual_seed(data_seed)
     logs = []
     for _ in range(steps):
         img = torch.rand(B, 3, 32, 32, device=dev, generator=g) * 2 - 1
