@@ -1322,6 +1322,47 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(GnApplyArgs p) {
     }
 }
 
+// Block statistics (per channel pair and partial: what the conv epilogues / gn_block_stats_kernel write, what gn_apply_kernel reads)
+// -> the generic kernels' statistics partials [N][chunks][groups][2] (what gn_gen_bwd_* read as `fwd_stats`): the training forward of
+// the ADM nets normalises with the streaming apply pass fed by its producers' statistics (round 6) and hands the generic backward the
+// same sums in its own format — the whole image's (sum, sum of squares) per group in chunk 0, zeros in the other chunks (the
+// backward adds the chunks in order).  One workgroup per image; pair sums in partial order, group sums in channel order.
+__global__ __launch_bounds__(256) void gn_blockstats_to_generic_kernel(const float* __restrict__ st0, int P0, int C0, const float* __restrict__ st1,
+                                                                      int P1, int C1, float* __restrict__ part, int groups, int chunks) {
+    __shared__ float2 pair_s[1024];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int C = C0 + C1, cpg = C / groups;
+    auto pair_sums = [&](const float* st, int P, int nbs, int off) {
+        const float2* const base = reinterpret_cast<const float2*>(st) + (size_t)n * P * nbs;
+        for (int b = tid; b < nbs; b += 256) {
+            float s = 0.f, q = 0.f;
+            for (int k = 0; k < P; ++k) {
+                const float2 t = base[(size_t)k * nbs + b];
+                s += t.x;
+                q += t.y;
+            }
+            pair_s[off + b] = make_float2(s, q);
+        }
+    };
+    pair_sums(st0, P0, C0 >> 1, 0);
+    if (C1) pair_sums(st1, P1, C1 >> 1, C0 >> 1);
+    __syncthreads();
+    float* const out = part + (size_t)n * chunks * groups * 2;
+    for (int i = tid; i < chunks * groups; i += 256) {
+        const int k = i / groups, g = i - k * groups;
+        float s = 0.f, q = 0.f;
+        if (k == 0) {
+            const int bpg = cpg >> 1;
+            for (int b = g * bpg; b < (g + 1) * bpg; ++b) {
+                s += pair_s[b].x;
+                q += pair_s[b].y;
+            }
+        }
+        out[(size_t)i * 2] = s;
+        out[(size_t)i * 2 + 1] = q;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Streaming apply + block statistics (see gn_apply_kernel)
 static inline int gn_stats_chunks(int HW) { return HW >= 512 ? HW / 256 : 1; }
@@ -1336,6 +1377,18 @@ extern "C" int dxmi_gn_block_stats(const void* x, float* stats, int32_t N, int32
     hipLaunchKernelGGL(gn_block_stats_kernel, dim3(N * chunks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, stats, HW, C,
                        chunks, rpc);
     DXMI_CHECK_LAUNCH("dxmi_gn_block_stats");
+    return DXMI_OK;
+}
+
+extern "C" int dxmi_gn_blockstats_to_generic(const float* stats0, int32_t P0, int32_t C0, const float* stats1, int32_t P1, int32_t C1,
+                                             float* generic_stats, int32_t N, int32_t HW, int32_t groups, void* stream) {
+    DXMI_CHECK_ARG(stats0 && generic_stats && N > 0 && HW > 0 && P0 > 0 && C0 > 0 && C1 >= 0, "dxmi_gn_blockstats_to_generic: bad arguments");
+    const int C = C0 + C1;
+    DXMI_CHECK_ARG(groups > 0 && groups <= 32 && C % groups == 0 && (C / groups) % 2 == 0 && C0 % 2 == 0 && C1 % 2 == 0 && C <= 2048 &&
+                   (C1 == 0 || (stats1 && P1 > 0)), "dxmi_gn_blockstats_to_generic: C0=%d C1=%d groups=%d (even channels per group)", C0, C1, groups);
+    hipLaunchKernelGGL(gn_blockstats_to_generic_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, stats0, P0, C0, stats1, P1, C1, generic_stats,
+                       groups, gn_gen_chunks(HW, N));
+    DXMI_CHECK_LAUNCH("dxmi_gn_blockstats_to_generic");
     return DXMI_OK;
 }
 

@@ -752,7 +752,8 @@ def groupnorm_apply(x, st, gamma, beta, *, in1=None, st1=None, groups=32, eps=1e
 
 
 def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, out=None, scale_shift=None, stats=None, saved=None):
-    """GroupNorm(+SiLU).  stats = (BlockStats of x, BlockStats of in1 | None): the streaming apply kernel.  Otherwise the
+    """GroupNorm(+SiLU).  stats = (BlockStats of x, BlockStats of in1 | None): the streaming apply kernel.  saved: a list that
+    receives the statistics tensor groupnorm_generic_bwd(fwd_stats=...) takes, on the streaming and the generic path.  Otherwise the
     register-resident one-pass kernel serves channels-per-group % 4 == 0 slices that fit; everything else (EDM shapes,
     scale-shift norm) goes to the generic two-kernel path."""
     _need_cuda(x, in1, gamma, beta, out, scale_shift)
@@ -760,6 +761,8 @@ def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, 
     C1 = in1.shape[3] if in1 is not None else 0
     if stats is not None and stats[0] is not None and (in1 is None or stats[1] is not None) \
             and ((C0 + C1) // groups) % 2 == 0 and C0 % 8 == 0 and C1 % 8 == 0:
+        if saved is not None:       # the training forward: the same sums in the generic backward's format
+            saved.append(gn_blockstats_to_generic(stats[0], stats[1] if in1 is not None else None, N, H * W, C0, C1, groups))
         return groupnorm_apply(x, stats[0], gamma, beta, in1=in1, st1=stats[1] if in1 is not None else None, groups=groups,
                                eps=eps, silu=silu, out=out, scale_shift=scale_shift)
     if scale_shift is not None or not load().dxmi_groupnorm_silu_supported(C0, C1, H * W, groups):
@@ -772,6 +775,15 @@ def groupnorm_silu(x, gamma, beta, *, in1=None, groups=32, eps=1e-6, silu=True, 
         load().dxmi_groupnorm_silu_fwd(_ptr(x), C0, _ptr(in1), C1, _ptr(gamma), _ptr(beta), _ptr(out), N, H * W,
                                        groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_silu_fwd"))
     return out
+
+
+def gn_blockstats_to_generic(st0, st1, N, HW, C0, C1, groups=32):
+    """BlockStats of x (| in1) -> the fp32 statistics tensor groupnorm_generic_bwd(fwd_stats=...) takes (dxmi_gn_blockstats_to_generic)."""
+    lib = load()
+    ws = torch.empty(lib.dxmi_groupnorm_generic_workspace_bytes(N, HW, C0 + C1) // 4, dtype=torch.float32, device=st0.buf.device)
+    check(lib.dxmi_gn_blockstats_to_generic(_ptr(st0.buf), st0.P, C0, _ptr(st1.buf) if st1 is not None else None, st1.P if st1 is not None else 0,
+                                            C1, _ptr(ws), N, HW, groups, _stream()), "dxmi_gn_blockstats_to_generic")
+    return ws
 
 
 def groupnorm_generic(x, gamma, beta, *, in1=None, groups=32, eps=1e-5, silu=True, out=None, scale_shift=None, saved=None):
@@ -823,7 +835,8 @@ def groupnorm_generic_bwd(x, dy, gamma, beta, *, in1=None, add0=None, add1=None,
                                                groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_generic_bwd")
     g0, g1 = g[0], g[1]
     if scale_shift is None:
-        return dx0, dx1, colsum_f32(g1.contiguous()), colsum_f32(g0.contiguous()), None
+        red = colsum_f32(g)          # [2, N, C] -> [2, C]: both parameter gradients from ONE launch (fixed order over the images)
+        return dx0, dx1, red[1], red[0], None
     one_s = 1.0 + scale_shift[:, :C]
     d_ss = torch.cat([g1 * gamma + g0 * beta, g0], 1)
     return dx0, dx1, (g1 * one_s).sum(0), (g0 * one_s).sum(0), d_ss

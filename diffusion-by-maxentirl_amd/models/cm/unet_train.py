@@ -15,6 +15,7 @@ package) plus a tape of saved NHWC bf16 activations; backward() walks the tape i
 Dropout must be 0 (every DxMI EDM config sets dropout: 0.0).  Parameter gradients come back in net.parameters() order.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -68,6 +69,11 @@ def _pack_t(net):
     return pk
 
 
+# Training forward: GroupNorm on the producers' block statistics (streaming apply) where the inference path uses them; 0 = the generic
+# statistics + apply pair everywhere (rounds 3-5).
+STREAM_GN = os.environ.get("DXMI_TRAIN_STREAM_GN", "1") == "1"
+
+
 def _up_sum(g):
     """transpose of nearest x2: sum over each 2x2 block (mean * 4, exact in bf16)."""
     out = ops.pool_act(g, True, ops.ACT_NONE)
@@ -98,16 +104,22 @@ class _EDMUNetFn(torch.autograd.Function):
         emb_all = ops.linear(emb, pk["emb_w"], pk["emb_b"], pre_act=ops.ACT_SILU)
         tape = []
 
-        def gn_fwd(norm, xin, **kw):
-            """GroupNorm(+SiLU) + the forward's statistics partials (generic path only; None otherwise): the backward then skips
-            its own statistics pass over `xin` (autograd saves mean / rstd the same way)."""
+        def conv_s(*a, **kw):
+            """-> (out, BlockStats of out from the conv's epilogue | None)"""
+            return ops.conv2d(*a, want_stats=True, **kw) if STREAM_GN else (ops.conv2d(*a, **kw), None)
+
+        def gn_fwd(norm, xin, st=None, st1=None, **kw):
+            """GroupNorm(+SiLU) + the statistics partials the backward reads (it then skips its own statistics pass over `xin`;
+            autograd saves mean / rstd the same way).  With block statistics from the producer (st; round 6, as in
+            forward_inference) the forward is the one-pass streaming apply and the partials are those sums converted
+            (dxmi_gn_blockstats_to_generic); otherwise the generic statistics + apply pair, which leaves its partials."""
             sv = []
-            out = ops.groupnorm_silu(xin, norm.weight, norm.bias, eps=norm.eps, saved=sv, **kw)
+            out = ops.groupnorm_silu(xin, norm.weight, norm.bias, eps=norm.eps, saved=sv, stats=(st, st1), **kw)
             return out, (sv[0] if sv else None)
 
-        def res(b, x0, x1):
+        def res(b, x0, x1, st0, st1):
             gn1, conv1, gn2, conv2 = b.in_layers[0], b.in_layers[2], b.out_layers[0], b.out_layers[3]
-            a1, s1 = gn_fwd(gn1, x0, in1=x1, silu=True)
+            a1, s1 = gn_fwd(gn1, x0, st0, st1, in1=x1, silu=True)
             a1p, xs = a1, x0
             if b.up:
                 xs = ops.upsample2x(x0)
@@ -116,56 +128,66 @@ class _EDMUNetFn(torch.autograd.Function):
             off, eo = pk[id(b), "eoff"], b.emb_layers[1].out_features
             e = emb_all[:, off:off + eo]
             if b.use_scale_shift_norm:
-                h = ops.conv2d(a1p, pk[id(b), "conv1"], bias=conv1.bias, upsample=b.up)
-                a2, s2 = gn_fwd(gn2, h, silu=True, scale_shift=e)
+                h, sh = conv_s(a1p, pk[id(b), "conv1"], bias=conv1.bias, upsample=b.up)
+                a2, s2 = gn_fwd(gn2, h, sh, silu=True, scale_shift=e)
             else:
-                h = ops.conv2d(a1p, pk[id(b), "conv1"], bias=conv1.bias, upsample=b.up, addvec=e)
-                a2, s2 = gn_fwd(gn2, h, silu=True)
+                h, sh = conv_s(a1p, pk[id(b), "conv1"], bias=conv1.bias, upsample=b.up, addvec=e)
+                a2, s2 = gn_fwd(gn2, h, sh, silu=True)
             if (id(b), "skip") in pk:
                 xs = ops.conv2d(x0, pk[id(b), "skip"], in1=x1, bias=b.skip_connection.bias)
-            out = ops.conv2d(a2, pk[id(b), "conv2"], bias=conv2.bias, residual=xs)
+            out, so = conv_s(a2, pk[id(b), "conv2"], bias=conv2.bias, residual=xs)
             tape.append(("res", b, x0, x1, a1p, h, a2, s1, s2))
-            return out
+            return out, (so if so is not None else stats_of(out))
 
-        def attn(m, xa):
+        def attn(m, xa, sx):
             N, H, W, C = xa.shape
-            hn, sn = gn_fwd(m.norm, xa, silu=False)
+            hn, sn = gn_fwd(m.norm, xa, sx, silu=False)
             qkv = ops.conv2d(hn, pk[id(m), "qkv"], bias=m.qkv.bias)
             a = ops.attention(qkv.view(N, H * W, 3 * C), heads=m.num_heads, scale=1.0 / math.sqrt(C // m.num_heads))
             out = ops.conv2d(a.view(N, H, W, C), pk[id(m), "proj"], bias=m.proj_out.bias, residual=xa)
             tape.append(("attn", m, xa, hn, qkv, a, sn))
-            return out
+            return out, stats_of(out)
 
-        def seq(mods, h, skip):
+        def seq(mods, h, skip, sh, sskip):
             for m in mods:
                 if isinstance(m, ResBlock):
-                    h = res(m, h, skip)
-                    skip = None
+                    h, sh = res(m, h, skip, sh, sskip)
+                    skip = sskip = None
                 elif isinstance(m, AttentionBlock):
-                    h = attn(m, h)
+                    h, sh = attn(m, h, sh)
                 elif isinstance(m, Downsample):
                     tape.append(("down", m, h))
-                    h = ops.conv2d(h, pk[id(m), "conv"], bias=m.op.bias, stride=2, pad=1) if m.use_conv \
-                        else ops.pool_act(h, True, ops.ACT_NONE)
+                    if m.use_conv:
+                        h, sh = conv_s(h, pk[id(m), "conv"], bias=m.op.bias, stride=2, pad=1)
+                    else:
+                        h, sh = ops.pool_act(h, True, ops.ACT_NONE), None
+                    sh = sh if sh is not None else stats_of(h)
                 elif isinstance(m, Upsample):
                     tape.append(("up", m, h))
-                    h = ops.conv2d(h, pk[id(m), "conv"], bias=m.conv.bias, upsample=True) if m.use_conv else ops.upsample2x(h)
-            return h
+                    if m.use_conv:
+                        h, sh = conv_s(h, pk[id(m), "conv"], bias=m.conv.bias, upsample=True)
+                    else:
+                        h, sh = ops.upsample2x(h), None
+                    sh = sh if sh is not None else stats_of(h)
+            return h, sh
 
+        stats_of = net._stats_of if STREAM_GN else (lambda t: None)
         conv_in = net.input_blocks[0][0]
         h = ops.conv2d(x, pk["conv_in"], bias=conv_in.bias) if pk["conv_in"].k27 else \
             ops.conv2d(ops.nchw_f32_to_nhwc_bf16(x), pk["conv_in"], bias=conv_in.bias)
-        hs = [h]
+        sh = stats_of(h)
+        hs = [(h, sh)]
         for i in range(1, len(net.input_blocks)):
-            h = seq(net.input_blocks[i], h, None)
+            h, sh = seq(net.input_blocks[i], h, None, sh, None)
             tape.append(("push", None, len(hs)))
-            hs.append(h)
-        h = seq(net.middle_block, h, None)
+            hs.append((h, sh))
+        h, sh = seq(net.middle_block, h, None, sh, None)
         for blk in net.output_blocks:
             tape.append(("skip", None, len(hs) - 1))
-            h = seq(blk, h, hs.pop())
+            skip, sskip = hs.pop()
+            h, sh = seq(blk, h, skip, sh, sskip)
         gn = net.out[0]
-        a_out, ctx.s_out = gn_fwd(gn, h, silu=True)
+        a_out, ctx.s_out = gn_fwd(gn, h, sh, silu=True)
         out = ops.conv2d(a_out, pk["conv_out"], bias=net.out[2].bias, out_nchw_f32=True)
         ctx.net, ctx.tape, ctx.h_last, ctx.a_out, ctx.x, ctx.sinus, ctx.y = net, tape, h, a_out, x, sinus, y
         ctx.emb_all_shape = emb_all.shape

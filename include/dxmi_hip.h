@@ -271,6 +271,13 @@ int dxmi_groupnorm_apply_split(const void* in0, int32_t C0, const float* stats0,
                                const float* scale_shift, int32_t ss_ld, void* out, float* ab_workspace, int32_t N, int32_t HW,
                                int32_t groups, float eps, int32_t apply_silu, void* stream);
 
+/* Block statistics ([N][P][C/2][2], as dxmi_conv_desc.gn_stats / dxmi_gn_block_stats write them; st1 for the second part of a virtual
+ * concat or NULL) -> the statistics partials of the generic GroupNorm kernels (dxmi_groupnorm_generic_workspace_bytes(N, HW, C) bytes:
+ * what dxmi_groupnorm_generic_bwd_saved takes as fwd_stats): a training forward that normalised with dxmi_groupnorm_apply hands the
+ * generic backward the same sums without another pass over the input. */
+int dxmi_gn_blockstats_to_generic(const float* stats0, int32_t P0, int32_t C0, const float* stats1, int32_t P1, int32_t C1,
+                                  float* generic_stats, int32_t N, int32_t HW, int32_t groups, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Single-/multi-head self-attention over a fused qkv tensor, MFMA QK^T and PV with an
  * online softmax.  qkv: NHWC bf16 [N,T,3*C] laid out [q | k | v] along channels, heads are

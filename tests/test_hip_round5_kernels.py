@@ -253,6 +253,39 @@ def test_groupnorm_apply_split_is_bit_identical():
         assert torch.equal(outs[0], outs[1]), (N, H, C0, C1, ss)
 
 
+def test_blockstats_to_generic_feeds_the_generic_backward():
+    """dxmi_gn_blockstats_to_generic (round 6): the block statistics the streaming forward normalised with, in the generic backward's
+    partial format — per-group sums equal the generic forward's own partials added up (fp32 summation-order tolerance), and the
+    backward run from them matches the backward that recomputes its statistics."""
+    import torch
+    from dxmi_hip import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(11)
+    for (N, H, C0, C1, ss) in [(5, 32, 192, 0, False), (3, 16, 384, 192, False), (4, 32, 192, 0, True), (2, 64, 192, 0, False)]:
+        C = C0 + C1
+        x0 = (torch.randn(N, H, H, C0, generator=g) + 0.3).to(torch.bfloat16).to(dev)
+        x1 = torch.randn(N, H, H, C1, generator=g).to(torch.bfloat16).to(dev) if C1 else None
+        ga, be = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+        sst = (torch.randn(N, 2 * C, generator=g) * 0.1).to(dev) if ss else None
+        dy = torch.randn(N, H, H, C, generator=g).to(torch.bfloat16).to(dev)
+        sv_gen, sv_str = [], []
+        y_gen = ops.groupnorm_generic(x0, ga, be, in1=x1, eps=1e-5, silu=True, scale_shift=sst, saved=sv_gen)
+        y_str = ops.groupnorm_silu(x0, ga, be, in1=x1, eps=1e-5, silu=True, scale_shift=sst, saved=sv_str,
+                                   stats=(ops.block_stats(x0), ops.block_stats(x1) if C1 else None))
+        assert len(sv_str) == 1 and sv_str[0].shape == sv_gen[0].shape
+        a, b = sv_gen[0].view(N, -1, 32, 2).sum(1), sv_str[0].view(N, -1, 32, 2)
+        assert float(b[:, 1:].abs().max()) == 0.0                       # the whole image in chunk 0
+        torch.testing.assert_close(b[:, 0], a, rtol=2e-5, atol=1e-2)
+        torch.testing.assert_close(y_str.float(), y_gen.float(), rtol=2e-2, atol=2e-2)
+        ref = ops.groupnorm_generic_bwd(x0, dy, ga, be, in1=x1, eps=1e-5, silu=True, scale_shift=sst)
+        got = ops.groupnorm_generic_bwd(x0, dy, ga, be, in1=x1, eps=1e-5, silu=True, scale_shift=sst, fwd_stats=sv_str[0])
+        for r, t in zip(ref, got):
+            assert (r is None) == (t is None)
+            if r is not None:
+                rel = float((r.float() - t.float()).norm() / r.float().norm().clamp_min(1e-9))
+                assert rel < 2e-3, (N, H, C0, C1, ss, rel)
+
+
 def test_var_and_edm_step_backward_vs_torch_autograd():
     """dxmi_var_step_bwd / dxmi_edm_step_bwd (round 6) against torch autograd over the reference's elementwise expressions
     (var_sampler.py:357-408 incl. the log-prob with x' detached; openai_diffusion.py:71-94), every output contributing to the loss."""
