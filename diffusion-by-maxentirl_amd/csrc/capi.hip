@@ -29,6 +29,7 @@ Knob g_knobs[] = {
     // Defaults keep an image's result independent of the batch it rides in (one kernel per layer shape whatever N is); the training
     // entry points switch to the throughput values 96 / 13 (dxmi_hip.ops.tune_for_throughput): small grids on smaller tiles.
     {"conv_ws_min_tiles", "DXMI_CONV_WS_MIN_TILES", 0, false},    // conv_ws.hip: fewer (256-pixel, 128-cout) tiles -> conv_pipe_kernel
+    {"gn_bwd_fused", "DXMI_GN_BWD_FUSED", 1, false},              // groupnorm.hip: generic GroupNorm backward as one launch on <= 256-pixel maps (2: everywhere it fits, 0: reduce + apply launches)
     {"conv_sm_mask", "DXMI_CONV_SM", 9, false},                   // conv_sm.hip: bit 0 4x4 maps, bit 1 every 8x8 map, bit 2 8x8 maps on under-filled grids, bit 3 8x8 maps with >= 1024 channels
 };
 Knob* find_knob(const char* name) {

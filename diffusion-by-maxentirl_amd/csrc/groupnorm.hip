@@ -955,6 +955,11 @@ struct GnGenBwdArgs {
     int C0, C1, HW, groups, cpg, chunks, rows_per_chunk, ss_ld, N;
     float eps;
     int silu;
+    // one-launch form (gn_gen_bwd_fused_kernel): arrival counter per image, (group, channel) partials as 8-byte granules
+    unsigned* cnt;                 // [N], zeroed by gn_zero_counters_kernel in front of the launch
+    unsigned long long* grp;       // [N][wchunks][groups]: (sum_c ga*G0, sum_c ga*G1) of a work chunk
+    unsigned long long* cpart;     // [N][wchunks][C]: (G0, G1) of a work chunk
+    int wchunks, wrows;
 };
 
 __device__ __forceinline__ void gn_gen_group_stats(const GnGenBwdArgs& p, int n, float* mean_s, float* rstd_s) {
@@ -1136,6 +1141,264 @@ __global__ __launch_bounds__(256) void gn_gen_bwd_apply_kernel(GnGenBwdArgs p) {
     }
 }
 
+// One-launch form of the two kernels above (round 6).  A workgroup owns a WORK chunk of KMAX x (256 / c8n) pixel rows that its
+// threads keep in registers: (1) partial G0 / G1 of its rows; per-group (sum_c ga G0, sum_c ga G1) and the per-channel pairs are
+// published as 8-byte granules with agent-scope write-through stores, then ONE counter add per workgroup; (2) lane 0 polls the
+// image's counter until every work chunk of the image has arrived (the chunks of an image are consecutive workgroup ids, the
+// dispatcher hands workgroups out in id order and an image has <= 128 of them, far below what the chip holds: the chunks a
+// workgroup waits for are always resident or ahead of every later image's in their XCD's queue); (3) the group means are added in
+// chunk order from the granules (agent-scope loads: no acquire fence is needed in front of them) and dx is formed from the
+// REGISTERS — x and dy are read once instead of twice, and the second launch with its statistics prologue is gone; (4) the
+// image's chunk-0 workgroup adds the per-channel pairs in chunk order into g_out.  Every sum has a fixed order.  The spin is
+// bounded: a workgroup that gives up writes NaN over its rows (a loss that cannot be missed) instead of hanging the device.
+__device__ __forceinline__ unsigned long long gn_pack2(float a, float b) {
+    return ((unsigned long long)__float_as_uint(b) << 32) | (unsigned long long)__float_as_uint(a);
+}
+
+__global__ void gn_zero_counters_kernel(unsigned* cnt, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) __hip_atomic_store(cnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void gn_gen_bwd_fused_kernel(GnGenBwdArgs p) {
+    __shared__ float mean_s[32], rstd_s[32], m1_s[32], m2_s[32];
+    __shared__ unsigned long long pool[4096];       // 32 KB: (row-group sums | per-channel sums) first, then the image's group granules
+    __shared__ int ok_s;
+    float (*sm)[2048] = reinterpret_cast<float (*)[2048]>(pool);
+    float (*gs)[2048] = reinterpret_cast<float (*)[2048]>(reinterpret_cast<float*>(pool) + 4096);
+    const int C = p.C0 + p.C1, c8n = C / 8;
+    const int n = blockIdx.x / p.wchunks, w = blockIdx.x % p.wchunks;
+    const int tid = threadIdx.x;
+    gn_gen_group_stats(p, n, mean_s, rstd_s);
+    const int rows_par = 256 / c8n;
+    const int pc = tid % c8n, rl = tid / c8n;
+    const bool active = rl < rows_par;
+    const int c = pc * 8;
+    const int row0 = w * p.wrows;
+    const int row1 = min(row0 + p.wrows, p.HW);
+    const bool from0 = c < p.C0;
+    const int Cs = from0 ? p.C0 : p.C1;
+    const size_t soff = (size_t)n * p.HW * Cs + (from0 ? c : c - p.C0);
+    const bf16* src = (from0 ? p.in0 : p.in1) + soff;
+    const bf16* add = from0 ? p.add0 : p.add1;
+    if (add) add += soff;
+    bf16* dst = (from0 ? p.dx0 : p.dx1) + soff;
+    const bf16* dyp = p.dy + (size_t)n * p.HW * C + c;
+    bf16x8 v[KMAX], d[KMAX];
+    float A[8], Bv[8], mu[8], rs[8];
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int rr = row0 + rl + k * rows_par;
+            if (rr < row1) {
+                v[k] = *reinterpret_cast<const bf16x8*>(src + (size_t)rr * Cs);
+                d[k] = *reinterpret_cast<const bf16x8*>(dyp + (size_t)rr * C);
+            }
+        }
+        float s0[8], s1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / p.cpg;
+            mu[e] = mean_s[g]; rs[e] = rstd_s[g];
+            float ga = p.gamma[c + e], be = p.beta[c + e];
+            if (p.ss) {
+                const float sc = 1.f + p.ss[(size_t)n * p.ss_ld + c + e];
+                ga *= sc;
+                be = be * sc + p.ss[(size_t)n * p.ss_ld + C + c + e];
+            }
+            A[e] = ga; Bv[e] = be; s0[e] = 0.f; s1[e] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (row0 + rl + k * rows_par < row1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = ((float)v[k][e] - mu[e]) * rs[e];
+                    float dyy = (float)d[k][e];
+                    if (p.silu) dyy *= gn_dsilu(xh * A[e] + Bv[e]);
+                    s0[e] += dyy; s1[e] += dyy * xh;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sm[0][rl * C + c + e] = s0[e];
+            sm[1][rl * C + c + e] = s1[e];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * C; i += 256) {
+        const int h = i / C, cc = i - h * C;
+        float t = 0.f;
+        for (int r = 0; r < rows_par; ++r) t += sm[h][r * C + cc];
+        gs[h][cc] = t;
+    }
+    __syncthreads();
+    const size_t wg = (size_t)n * p.wchunks + w;
+    for (int cc = tid; cc < C; cc += 256)
+        __hip_atomic_store(p.cpart + wg * C + cc, gn_pack2(gs[0][cc], gs[1][cc]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < p.groups) {
+        float a = 0.f, b = 0.f;
+        for (int cc = tid * p.cpg; cc < (tid + 1) * p.cpg; ++cc) {
+            float ga = p.gamma[cc];
+            if (p.ss) ga *= 1.f + p.ss[(size_t)n * p.ss_ld + cc];
+            a += ga * gs[0][cc];
+            b += ga * gs[1][cc];
+        }
+        __hip_atomic_store(p.grp + wg * p.groups + tid, gn_pack2(a, b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the additive input's rows: requested in front of the wait (short forms only: registers)
+    bf16x8 av[KMAX <= 8 ? KMAX : 1];
+    if (KMAX <= 8 && add && active) {
+#pragma unroll
+        for (int k = 0; k < (KMAX <= 8 ? KMAX : 1); ++k)
+            if (row0 + rl + k * rows_par < row1) av[k] = *reinterpret_cast<const bf16x8*>(add + (size_t)(row0 + rl + k * rows_par) * Cs);
+    }
+    // every storing wave drains its write-through stores, the workgroup meets, one lane signals and waits
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(p.cnt + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 0;
+        for (unsigned spins = 0; spins < (1u << 24); ++spins) {
+            if (__hip_atomic_load(p.cnt + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.wchunks) {
+                ok = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        ok_s = ok;
+    }
+    __syncthreads();
+    const bool ok = ok_s != 0;
+    {
+        // the image's wchunks x groups granules: ONE round trip (every thread up to 16 loads in flight) into LDS, then one thread per
+        // group adds them in chunk order
+        const int total = p.wchunks * p.groups;        // <= 128 x 32 = 4096
+        const unsigned long long* gp = p.grp + (size_t)n * total;
+        unsigned long long t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (tid + u * 256 < total) t[u] = __hip_atomic_load(gp + tid + u * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (tid + u * 256 < total) pool[tid + u * 256] = t[u];
+    }
+    __syncthreads();
+    if (tid < p.groups) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < p.wchunks; ++k) {
+            const unsigned long long t = pool[k * p.groups + tid];
+            a += __uint_as_float((unsigned)t);
+            b += __uint_as_float((unsigned)(t >> 32));
+        }
+        const float cnt = (float)p.HW * p.cpg;
+        m1_s[tid] = a / cnt;
+        m2_s[tid] = b / cnt;
+    }
+    __syncthreads();
+    if (active) {
+        float m1[8], m2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / p.cpg;
+            m1[e] = m1_s[g]; m2[e] = m2_s[g];
+        }
+        if (KMAX > 8 && add) {
+            // long form: the additive rows are fetched here, in two batches
+#pragma unroll
+            for (int k0 = 0; k0 < KMAX; k0 += 8) {
+                bf16x8 a8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (row0 + rl + (k0 + u) * rows_par < row1)
+                        a8[u] = *reinterpret_cast<const bf16x8*>(add + (size_t)(row0 + rl + (k0 + u) * rows_par) * Cs);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + u;
+                    const int rr = row0 + rl + k * rows_par;
+                    if (k < KMAX && rr < row1) {
+                        bf16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float xh = ((float)v[k][e] - mu[e]) * rs[e];
+                            float dyy = (float)d[k][e];
+                            if (p.silu) dyy *= gn_dsilu(xh * A[e] + Bv[e]);
+                            float dx = rs[e] * (A[e] * dyy - m1[e] - xh * m2[e]) + (float)a8[u][e];
+                            o[e] = ok ? (bf16)dx : (bf16)__builtin_nanf("");
+                        }
+                        *reinterpret_cast<bf16x8*>(dst + (size_t)rr * Cs) = o;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int rr = row0 + rl + k * rows_par;
+                if (rr < row1) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float xh = ((float)v[k][e] - mu[e]) * rs[e];
+                        float dyy = (float)d[k][e];
+                        if (p.silu) dyy *= gn_dsilu(xh * A[e] + Bv[e]);
+                        float dx = rs[e] * (A[e] * dyy - m1[e] - xh * m2[e]);
+                        if (KMAX <= 8 && add) dx += (float)av[KMAX <= 8 ? k : 0][e];
+                        o[e] = ok ? (bf16)dx : (bf16)__builtin_nanf("");
+                    }
+                    *reinterpret_cast<bf16x8*>(dst + (size_t)rr * Cs) = o;
+                }
+            }
+        }
+    }
+    // g_out: every workgroup of the image adds the chunks' (G0, G1) pairs of ITS share of the channels — one round trip of agent-scope
+    // loads into LDS, then one thread per channel adds them in chunk order
+    __syncthreads();                 // pool: the group granules have been consumed
+    {
+        const int cpw = (C + p.wchunks - 1) / p.wchunks;
+        const int c_lo = w * cpw, c_n = min(C, c_lo + cpw) - c_lo;         // may be <= 0 for the last workgroups
+        const int total = c_n > 0 ? c_n * p.wchunks : 0;                    // <= C + wchunks <= 2176
+        const unsigned long long* cp = p.cpart + (size_t)n * p.wchunks * C + c_lo;
+        unsigned long long t[9];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const int i = tid + u * 256;           // i = k * c_n + j: chunk k, channel c_lo + j (consecutive threads: consecutive channels)
+            if (i < total) t[u] = __hip_atomic_load(cp + (size_t)(i / c_n) * C + (i % c_n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 9; ++u)
+            if (tid + u * 256 < total) pool[tid + u * 256] = t[u];
+        __syncthreads();
+        for (int j = tid; j < c_n; j += 256) {
+            float a = 0.f, b = 0.f;
+            for (int k = 0; k < p.wchunks; ++k) {
+                const unsigned long long q = pool[k * c_n + j];
+                a += __uint_as_float((unsigned)q);
+                b += __uint_as_float((unsigned)(q >> 32));
+            }
+            p.g_out[(size_t)n * C + c_lo + j] = ok ? a : __builtin_nanf("");
+            p.g_out[((size_t)p.N + n) * C + c_lo + j] = ok ? b : __builtin_nanf("");
+        }
+    }
+}
+
+// work split of the one-launch backward: rows per workgroup = KMAX (8, else 16) x rows in parallel; 0 = not served (too many work
+// chunks per image: LSUN-size maps keep the two-launch form)
+static inline int gn_fused_plan(int HW, int C, int* wrows, int* wchunks) {
+    const int rows_par = 256 / (C / 8);
+    if (rows_par < 1) return 0;
+    for (int kmax = 8; kmax <= 16; kmax *= 2) {
+        const int wr = kmax * rows_par, wc = (HW + wr - 1) / wr;
+        if (wc <= (kmax == 8 ? 64 : 128)) {
+            *wrows = wr;
+            *wchunks = wc;
+            return kmax;
+        }
+    }
+    return 0;
+}
+
 // 1 when the one-pass register-resident kernel (dxmi_groupnorm_silu_fwd) can serve the shape, else 0
 // (callers then use dxmi_groupnorm_generic_fwd).  Same slicing walk as the launcher below.
 extern "C" int dxmi_groupnorm_silu_supported(int32_t C0, int32_t C1, int32_t HW, int32_t groups) {
@@ -1210,9 +1473,16 @@ extern "C" int dxmi_groupnorm_silu_fwd(const void* in0, int32_t C0, const void* 
     return VEC == 8 ? launch_gn<8>(a, N, pieces, threads, st) : launch_gn<4>(a, N, pieces, threads, st);
 }
 
+static inline int64_t gn_round16(int64_t b) { return (b + 15) / 16 * 16; }
+
 extern "C" int64_t dxmi_groupnorm_generic_bwd_workspace_bytes(int32_t N, int32_t HW, int32_t C) {
     const int chunks = gn_gen_chunks(HW, N);
-    return (int64_t)N * chunks * 32 * 2 * 4 + (int64_t)N * chunks * C * 2 * 4;
+    const int64_t two_launch = (int64_t)N * chunks * 32 * 2 * 4 + (int64_t)N * chunks * C * 2 * 4;
+    int wrows = 0, wchunks = 0;
+    if (C < 8 || !gn_fused_plan(HW, C, &wrows, &wchunks)) return two_launch;
+    // one-launch form: [counters, padded to 16 bytes][statistics partials][group granules][channel granules]
+    const int64_t fused = gn_round16((int64_t)N * 4) + (int64_t)N * chunks * 32 * 2 * 4 + (int64_t)N * wchunks * 32 * 8 + (int64_t)N * wchunks * C * 8;
+    return fused > two_launch ? fused : two_launch;
 }
 
 // g_out: fp32 [2][N][C] (G0, G1 above).  dx1 / add0 / add1 / scale_shift may be NULL.
@@ -1242,6 +1512,39 @@ extern "C" int dxmi_groupnorm_generic_bwd_saved(const void* in0, int32_t C0, con
     a.C0 = C0; a.C1 = C1; a.HW = HW; a.groups = groups; a.cpg = C / groups; a.chunks = chunks; a.rows_per_chunk = f.rows_per_chunk;
     a.ss_ld = ss_ld; a.N = N; a.eps = eps; a.silu = apply_silu;
     hipStream_t st = (hipStream_t)stream;
+    int wrows = 0, wchunks = 0;
+    // knob gn_bwd_fused: 1 = where the one-launch form measured faster (maps of <= 256 pixels: every workgroup reads the image's
+    // wchunks x 32 group granules with agent-scope loads, a cost that grows with the SQUARE of the chunk count — 16 x 64x64x192:
+    // 52 chunks 85 us, 104 chunks 153 us, against 49 us for the two launches; 16 x 8x8x1536: 29 against 80 us), 2 = wherever it
+    // fits (tests), 0 = never
+    const int fused_knob = dxmi_tuning("gn_bwd_fused");
+    const int kmax = (fused_knob >= 2 || (fused_knob == 1 && HW <= 256)) ? gn_fused_plan(HW, C, &wrows, &wchunks) : 0;
+    if (kmax) {
+        // one launch (gn_gen_bwd_fused_kernel) behind the node that zeroes the arrival counters
+        char* base = (char*)workspace;
+        const int64_t cnt_bytes = gn_round16((int64_t)N * 4);
+        float* part2 = (float*)(base + cnt_bytes);
+        a.cnt = (unsigned*)base;
+        a.grp = (unsigned long long*)(base + cnt_bytes + (int64_t)N * chunks * 32 * 2 * 4);
+        a.cpart = a.grp + (size_t)N * wchunks * 32;
+        a.wchunks = wchunks; a.wrows = wrows;
+        if (!fwd_stats) {
+            f.part = part2;
+            a.part = part2;
+            hipLaunchKernelGGL(gn_gen_stats_kernel, dim3(N * chunks), dim3(256), 0, st, f);
+            DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_bwd(stats)");
+        }
+        // The counters are zeroed by a KERNEL node, not by hipMemsetAsync: behind a memset node the replayed EDM train step was not
+        // reproducible (three replays of the same step: v_loss 77.3227 / 77.3596 / 77.3130; python-issued launches and the kernel node:
+        // identical every time) — on this ROCm a replayed graph does not order a memset node's write against the agent-scope atomics of
+        // the kernel node behind it.
+        hipLaunchKernelGGL(gn_zero_counters_kernel, dim3((N + 255) / 256), dim3(256), 0, st, a.cnt, N);
+        DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_bwd(counters)");
+        if (kmax == 8) hipLaunchKernelGGL(gn_gen_bwd_fused_kernel<8>, dim3(N * wchunks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(gn_gen_bwd_fused_kernel<16>, dim3(N * wchunks), dim3(256), 0, st, a);
+        DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_bwd(fused)");
+        return DXMI_OK;
+    }
     if (!fwd_stats) {
         hipLaunchKernelGGL(gn_gen_stats_kernel, dim3(N * chunks), dim3(256), 0, st, f);
         DXMI_CHECK_LAUNCH("dxmi_groupnorm_generic_bwd(stats)");
@@ -1377,6 +1680,50 @@ extern "C" int dxmi_gn_block_stats(const void* x, float* stats, int32_t N, int32
     hipLaunchKernelGGL(gn_block_stats_kernel, dim3(N * chunks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, stats, HW, C,
                        chunks, rpc);
     DXMI_CHECK_LAUNCH("dxmi_gn_block_stats");
+    return DXMI_OK;
+}
+
+// Parameter and FiLM gradients of a scale-shift GroupNorm from the backward's per-image sums g [2][N][C] (G0 = sum dyy, G1 = sum
+// dyy * xh; the kernels above): with s = 1 + scale[n, c]
+//   d_ss[n, c] = G1 gamma + G0 beta ; d_ss[n, C + c] = G0 ; dgamma[c] = sum_n G1 s ; dbeta[c] = sum_n G0 s       (images in order)
+// One thread per channel, one launch (it was seven torch launches per FiLM GroupNorm of the EDM backward).
+__global__ __launch_bounds__(256) void gn_ss_grads_kernel(const float* __restrict__ g, const float* __restrict__ ss, int ss_ld,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ d_ss, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          int N, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float ga = gamma[c], be = beta[c];
+    float dg = 0.f, db = 0.f;
+    for (int n0 = 0; n0 < N; n0 += 8) {
+        float g0[8], g1[8], sc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (n0 + u < N) {
+                g0[u] = g[(size_t)(n0 + u) * C + c];
+                g1[u] = g[((size_t)N + n0 + u) * C + c];
+                sc[u] = 1.f + ss[(size_t)(n0 + u) * ss_ld + c];
+            }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (n0 + u < N) {
+                d_ss[(size_t)(n0 + u) * 2 * C + c] = g1[u] * ga + g0[u] * be;
+                d_ss[(size_t)(n0 + u) * 2 * C + C + c] = g0[u];
+                dg += g1[u] * sc[u];
+                db += g0[u] * sc[u];
+            }
+    }
+    dgamma[c] = dg;
+    dbeta[c] = db;
+}
+
+extern "C" int dxmi_gn_ss_grads(const float* g, const float* scale_shift, int32_t ss_ld, const float* gamma, const float* beta,
+                                float* d_scale_shift, float* dgamma, float* dbeta, int32_t N, int32_t C, void* stream) {
+    DXMI_CHECK_ARG(g && scale_shift && gamma && beta && d_scale_shift && dgamma && dbeta, "dxmi_gn_ss_grads: null pointer");
+    DXMI_CHECK_ARG(N > 0 && C > 0 && ss_ld >= 2 * C, "dxmi_gn_ss_grads: N=%d C=%d ss_ld=%d", N, C, ss_ld);
+    hipLaunchKernelGGL(gn_ss_grads_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, scale_shift, ss_ld, gamma, beta,
+                       d_scale_shift, dgamma, dbeta, N, C);
+    DXMI_CHECK_LAUNCH("dxmi_gn_ss_grads");
     return DXMI_OK;
 }
 

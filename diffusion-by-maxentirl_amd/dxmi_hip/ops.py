@@ -833,13 +833,14 @@ def groupnorm_generic_bwd(x, dy, gamma, beta, *, in1=None, add0=None, add1=None,
     check(lib.dxmi_groupnorm_generic_bwd_saved(_ptr(x), C0, _ptr(in1), C1, _ptr(dy), _ptr(add0), _ptr(add1), _ptr(gamma), _ptr(beta),
                                                _ptr(scale_shift), ss_ld, _ptr(dx0), _ptr(dx1), _ptr(g), _ptr(fwd_stats), _ptr(ws), N, H * W,
                                                groups, float(eps), int(silu), _stream()), "dxmi_groupnorm_generic_bwd")
-    g0, g1 = g[0], g[1]
     if scale_shift is None:
         red = colsum_f32(g)          # [2, N, C] -> [2, C]: both parameter gradients from ONE launch (fixed order over the images)
         return dx0, dx1, red[1], red[0], None
-    one_s = 1.0 + scale_shift[:, :C]
-    d_ss = torch.cat([g1 * gamma + g0 * beta, g0], 1)
-    return dx0, dx1, (g1 * one_s).sum(0), (g0 * one_s).sum(0), d_ss
+    d_ss = torch.empty((N, 2 * C), dtype=torch.float32, device=x.device)
+    dgb = torch.empty((2, C), dtype=torch.float32, device=x.device)
+    check(lib.dxmi_gn_ss_grads(_ptr(g), _ptr(scale_shift), ss_ld, _ptr(gamma), _ptr(beta), _ptr(d_ss), _ptr(dgb[0]), _ptr(dgb[1]), N, C,
+                               _stream()), "dxmi_gn_ss_grads")
+    return dx0, dx1, dgb[0], dgb[1], d_ss
 
 
 def upsample2x(x, out=None):

@@ -60,6 +60,9 @@ int dxmi_device_check(void);
  *   "conv_sm_mask"      [DXMI_CONV_SM, 9]: bit 0 4x4 maps, bit 1 every 8x8 map, bit 2 8x8 maps whose 256-pixel-tile grid is
  *                        under-filled, bit 3 8x8 maps with >= 1024 channels in and out (a rule on the layer shape, not on the
  *                        batch), on the feed-tiled small-map kernel.
+ *   "gn_bwd_fused"      [DXMI_GN_BWD_FUSED, 1]: dxmi_groupnorm_generic_bwd[_saved] as ONE launch that keeps a workgroup's rows
+ *                        in registers across an in-launch per-image hand-off, on maps of <= 256 pixels where it measured faster
+ *                        (2: on every shape it fits; 0: the reduce + apply launches of rounds 2-5 everywhere).
  * Defaults: one kernel per layer shape whatever the batch size, so an image's result does not depend on the batch it rides in.
  * The training entry points set 96 / 13 (throughput at small per-GPU batches; +5..8 % on the EDM train step).  The answers of
  * dxmi_conv2d_gn_stats_partials / dxmi_conv2d_gn_fuse_supported depend on the knobs: query again after changing one.
@@ -277,6 +280,12 @@ int dxmi_groupnorm_apply_split(const void* in0, int32_t C0, const float* stats0,
  * generic backward the same sums without another pass over the input. */
 int dxmi_gn_blockstats_to_generic(const float* stats0, int32_t P0, int32_t C0, const float* stats1, int32_t P1, int32_t C1,
                                   float* generic_stats, int32_t N, int32_t HW, int32_t groups, void* stream);
+
+/* Parameter and FiLM gradients of a scale-shift GroupNorm from dxmi_groupnorm_generic_bwd's g_out [2][N][C] in one launch:
+ * d_scale_shift [N][2C] = (G1 gamma + G0 beta | G0), dgamma [C] = sum_n G1 (1 + scale), dbeta [C] = sum_n G0 (1 + scale); scale_shift as the
+ * backward took it ([N][ss_ld], scale first).  Replaces the reference's autograd of models/cm/unet.py:252-256. */
+int dxmi_gn_ss_grads(const float* g, const float* scale_shift, int32_t ss_ld, const float* gamma, const float* beta,
+                     float* d_scale_shift, float* dgamma, float* dbeta, int32_t N, int32_t C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Single-/multi-head self-attention over a fused qkv tensor, MFMA QK^T and PV with an

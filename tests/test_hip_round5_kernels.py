@@ -286,6 +286,75 @@ def test_blockstats_to_generic_feeds_the_generic_backward():
                 assert rel < 2e-3, (N, H, C0, C1, ss, rel)
 
 
+def test_generic_groupnorm_backward_one_launch_vs_two():
+    """gn_gen_bwd_fused_kernel (round 6; knob gn_bwd_fused): rows kept in registers across an in-launch per-image hand-off.  Same
+    arithmetic as the reduce + apply launches with the row sums grouped by work chunk instead of statistics chunk: dx within one
+    bf16 step, the per-(image, channel) sums to fp32 summation-order tolerance; deterministic (two runs bitwise equal); repeated
+    back to back (the counters are re-zeroed per call) and on the EDM nets' shapes incl. a virtual concat, FiLM, an additive
+    gradient, ragged last work chunks and the 16-rows-per-thread form."""
+    import torch
+    from dxmi_hip import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(5)
+    cases = [(16, 64, 192, 0, False, True), (3, 64, 192, 192, False, False), (16, 32, 384, 0, True, True), (5, 32, 384, 384, False, True),
+             (16, 16, 576, 0, True, False), (4, 16, 576, 576, False, True), (16, 8, 768, 0, True, True), (7, 8, 768, 768, False, False),
+             (2, 24, 96, 0, False, True), (3, 5, 64, 0, False, False), (3, 4, 1024, 1024, False, True), (2, 8, 2048, 0, True, False)]
+    for (N, H, C0, C1, ss, with_add) in cases:
+        C = C0 + C1
+        x0 = (torch.randn(N, H, H, C0, generator=g) * 1.3 + 0.2).to(torch.bfloat16).to(dev)
+        x1 = torch.randn(N, H, H, C1, generator=g).to(torch.bfloat16).to(dev) if C1 else None
+        ga, be = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev)
+        sst = (torch.randn(N, 2 * C, generator=g) * 0.1).to(dev) if ss else None
+        dy = torch.randn(N, H, H, C, generator=g).to(torch.bfloat16).to(dev)
+        a0 = torch.randn(N, H, H, C0, generator=g).to(torch.bfloat16).to(dev) if with_add else None
+        a1 = torch.randn(N, H, H, C1, generator=g).to(torch.bfloat16).to(dev) if with_add and C1 else None
+        sv = []
+        ops.groupnorm_generic(x0, ga, be, in1=x1, eps=1e-5, silu=True, scale_shift=sst, saved=sv)
+        run = lambda st: ops.groupnorm_generic_bwd(x0, dy, ga, be, in1=x1, add0=a0, add1=a1, eps=1e-5, silu=True, scale_shift=sst, fwd_stats=st)
+        old = ops.set_tuning("gn_bwd_fused", 0)
+        try:
+            ref = run(sv[0])
+            ops.set_tuning("gn_bwd_fused", 2)        # 2: on every shape the plan fits (1, the default: maps of <= 256 pixels)
+            got, again, fresh = run(sv[0]), run(sv[0]), run(None)
+        finally:
+            ops.set_tuning("gn_bwd_fused", old)
+        for i, (r, t, t2, t3) in enumerate(zip(ref, got, again, fresh)):
+            assert (r is None) == (t is None)
+            if r is None:
+                continue
+            assert torch.isfinite(t.float()).all()
+            assert torch.equal(t, t2) and torch.equal(t, t3), (N, H, C0, C1, i)
+            if i < 2:       # dx0, dx1: bf16
+                diff = (r.float() - t.float()).abs()
+                assert float((diff > 0).float().mean()) < 0.05 and float((diff / r.float().abs().clamp_min(1e-2)).max()) < 2e-2, (N, H, C0, C1, i)
+            else:
+                torch.testing.assert_close(t, r, rtol=2e-4, atol=2e-3 * float(r.abs().max()))
+
+
+def test_gn_ss_grads_vs_torch():
+    """dxmi_gn_ss_grads (round 6): the FiLM GroupNorm's parameter / scale-shift gradients from the backward's per-image sums, against
+    the torch expressions it replaced (autograd of models/cm/unet.py:252-256 on G0 / G1)."""
+    import ctypes
+    import torch
+    from dxmi_hip import ops, _lib
+    dev = "cuda:0"
+    gen = torch.Generator().manual_seed(2)
+    for (N, C, pad) in [(16, 384, 0), (5, 1536, 64), (1, 192, 0), (19, 200, 8)]:
+        g = torch.randn(2, N, C, generator=gen).to(dev)
+        emb = torch.randn(N, 2 * C + pad, generator=gen).to(dev)
+        ss = emb[:, pad // 2: pad // 2 + 2 * C]                      # a strided view, as the U-Net passes a slice of emb_all
+        ga, be = torch.randn(C, generator=gen).to(dev), torch.randn(C, generator=gen).to(dev)
+        d_ss = torch.empty(N, 2 * C, device=dev)
+        dgb = torch.empty(2, C, device=dev)
+        lib = _lib.load()
+        ops.check(lib.dxmi_gn_ss_grads(g.data_ptr(), ss.data_ptr(), ss.stride(0), ga.data_ptr(), be.data_ptr(), d_ss.data_ptr(),
+                                       dgb[0].data_ptr(), dgb[1].data_ptr(), N, C, None), "dxmi_gn_ss_grads")
+        one_s = 1.0 + ss[:, :C]
+        torch.testing.assert_close(d_ss, torch.cat([g[1] * ga + g[0] * be, g[0]], 1), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(dgb[0], (g[1] * one_s).sum(0), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(dgb[1], (g[0] * one_s).sum(0), rtol=1e-5, atol=1e-5)
+
+
 def test_var_and_edm_step_backward_vs_torch_autograd():
     """dxmi_var_step_bwd / dxmi_edm_step_bwd (round 6) against torch autograd over the reference's elementwise expressions
     (var_sampler.py:357-408 incl. the log-prob with x' detached; openai_diffusion.py:71-94), every output contributing to the loss."""
