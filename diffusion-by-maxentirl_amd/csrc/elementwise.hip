@@ -130,22 +130,34 @@ __global__ void pool_act_kernel(const bf16* __restrict__ in, bf16* __restrict__ 
     }
 }
 
-// value head: relu -> sum over HW -> dot(w[C]) + b -> out_w*y + out_b ; one wave per image
-__global__ __launch_bounds__(64) void value_head_kernel(const bf16* __restrict__ in, const float* __restrict__ w,
-                                                       const float* __restrict__ b, const float* __restrict__ out_w,
-                                                       const float* __restrict__ out_b, float* __restrict__ out, int HW, int C) {
-    const int n = blockIdx.x, lane = threadIdx.x;
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) {
+// value head: relu -> sum over HW -> dot(w[C]) + b -> out_w*y + out_b ; one workgroup per image.  Four waves walk the channels
+// (eight pixels of loads in flight, pixels added in order), the relu-sums s[c] meet in LDS and wave 0 adds s[c] w[c] in the order
+// the one-wave form of rounds 1-5 did (lane: c = lane, lane + 64, ...; then the butterfly): the same bits, a quarter of the chain.
+__global__ __launch_bounds__(256) void value_head_kernel(const bf16* __restrict__ in, const float* __restrict__ w,
+                                                        const float* __restrict__ b, const float* __restrict__ out_w,
+                                                        const float* __restrict__ out_b, float* __restrict__ out, int HW, int C) {
+    __shared__ float sw[4096];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        const bf16* p = in + (size_t)n * HW * C + c;
         float s = 0.f;
-        for (int px = 0; px < HW; ++px) {
-            const float v = (float)in[((size_t)n * HW + px) * C + c];
-            s += v > 0.f ? v : 0.f;
+        for (int px = 0; px < HW; px += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (px + u < HW) v[u] = (float)p[(size_t)(px + u) * C];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (px + u < HW) s += v[u] > 0.f ? v[u] : 0.f;
         }
-        acc += s * w[c];
+        sw[c] = s;
     }
+    __syncthreads();
+    if (tid >= 64) return;
+    float acc = 0.f;
+    for (int c = tid; c < C; c += 64) acc += sw[c] * w[c];      // the expression of the one-wave form (same contraction)
     acc = wave_sum(acc);
-    if (lane == 0) {
+    if (tid == 0) {
         float y = acc + b[0];
         if (out_w) y = y * out_w[0] + out_b[0];  // out_scale = Linear(1,1), models/modules.py:157-158
         out[n] = y;
@@ -176,19 +188,25 @@ __global__ void pool_act_bwd_kernel(const bf16* __restrict__ dout, const bf16* _
 }
 
 // backward of the value head w.r.t. the feature map (+ the relu/sum features for the parameter grads)
-__global__ __launch_bounds__(64) void value_head_bwd_kernel(const bf16* __restrict__ feat, const float* __restrict__ w,
-                                                           const float* __restrict__ dy, bf16* __restrict__ dfeat,
-                                                           float* __restrict__ s, int HW, int C) {
-    const int n = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void value_head_bwd_kernel(const bf16* __restrict__ feat, const float* __restrict__ w,
+                                                            const float* __restrict__ dy, bf16* __restrict__ dfeat,
+                                                            float* __restrict__ s, int HW, int C) {
+    const int n = blockIdx.x;
     const float g = dy[n];
-    for (int c = lane; c < C; c += 64) {
+    for (int c = threadIdx.x; c < C; c += 256) {
         float acc = 0.f;
         const float gw = g * w[c];
-        for (int px = 0; px < HW; ++px) {
-            const size_t o = ((size_t)n * HW + px) * C + c;
-            const float v = (float)feat[o];
-            acc += v > 0.f ? v : 0.f;
-            dfeat[o] = (bf16)(v > 0.f ? gw : 0.f);
+        for (int px = 0; px < HW; px += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (px + u < HW) v[u] = (float)feat[((size_t)n * HW + px + u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (px + u < HW) {
+                    acc += v[u] > 0.f ? v[u] : 0.f;
+                    dfeat[((size_t)n * HW + px + u) * C + c] = (bf16)(v[u] > 0.f ? gw : 0.f);
+                }
         }
         s[(size_t)n * C + c] = acc;
     }
@@ -198,41 +216,70 @@ __global__ __launch_bounds__(64) void value_head_bwd_kernel(const bf16* __restri
 // twelve backwards per train step).  y = (s . w + b) * ow + ob with s = relu-sum features [N, C]; dy [N]:
 //   d_linear_w[c] = sum_n (dy[n] * ow) * s[n, c]     d_linear_b = sum_n dy[n] * ow
 //   d_ow = sum_n dy[n] * (s[n] . w + b)              d_ob = sum_n dy[n]
-// One workgroup, fixed summation order (n ascending per thread, then a fixed tree): bitwise reproducible.  out = [C + 3] fp32:
-// d_linear_w | d_linear_b | d_ow | d_ob.  ow == nullptr: no out_scale (the last two are written as zero).
+// Fixed summation order everywhere: bitwise reproducible.  out = [C + 3] fp32: d_linear_w | d_linear_b | d_ow | d_ob.  ow == nullptr: no out_scale (the last two are written as zero).
+// Workgroups 0 .. ceil(C / 64) - 1: d_linear_w of 64 channels (thread = channel x one of four row slices, eight rows of loads in
+// flight, the slices added in order); the last workgroup: the three scalars (a wave per row for the dot product s[n] . w — coalesced,
+// a fixed butterfly over the lanes — rows in order per wave, the four waves added in order).  The first form of this kernel was ONE
+// workgroup walking N rows / C channels one dependent load at a time: 96 us per launch at 256 images, 22 launches per train step.
 __global__ __launch_bounds__(256) void value_head_pgrad_kernel(const float* __restrict__ s, const float* __restrict__ w,
                                                               const float* __restrict__ b, const float* __restrict__ dy,
                                                               const float* __restrict__ ow, float* __restrict__ out, int N, int C) {
-    __shared__ float red[3][256];
+    __shared__ float red[4][64];
     const int tid = threadIdx.x;
     const float scale = ow ? ow[0] : 1.f;
-    for (int c = tid; c < C; c += 256) {
+    const int CB = (C + 63) / 64;
+    if ((int)blockIdx.x < CB) {
+        const int c = blockIdx.x * 64 + (tid & 63), sl = tid >> 6;
+        const int n0 = (int)((long)N * sl / 4), n1 = (int)((long)N * (sl + 1) / 4);
         float acc = 0.f;
-        for (int n = 0; n < N; ++n) acc += (dy[n] * scale) * s[(size_t)n * C + c];
-        out[c] = acc;
-    }
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int n = tid; n < N; n += 256) {
-        float y = b[0];
-        for (int c = 0; c < C; ++c) y += s[(size_t)n * C + c] * w[c];
-        a0 += dy[n] * scale;
-        a1 += dy[n] * y;
-        a2 += dy[n];
-    }
-    red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) {
-            red[0][tid] += red[0][tid + o];
-            red[1][tid] += red[1][tid + o];
-            red[2][tid] += red[2][tid + o];
+        if (c < C) {
+            for (int n = n0; n < n1; n += 8) {
+                float sv[8], dv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (n + u < n1) {
+                        sv[u] = s[(size_t)(n + u) * C + c];
+                        dv[u] = dy[n + u];
+                    }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (n + u < n1) acc += (dv[u] * scale) * sv[u];
+            }
         }
+        red[sl][tid & 63] = acc;
         __syncthreads();
+        if (sl == 0 && c < C) out[c] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        return;
     }
+    const int lane = tid & 63, wv = tid >> 6;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int n = wv; n < N; n += 4) {
+        float part = 0.f;
+        for (int c0 = lane; c0 < C; c0 += 64 * 8) {
+            float sv[8], wvv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u * 64 < C) {
+                    sv[u] = s[(size_t)n * C + c0 + u * 64];
+                    wvv[u] = w[c0 + u * 64];
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u * 64 < C) part += sv[u] * wvv[u];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        const float y = part + b[0], d = dy[n];
+        a0 += d * scale;
+        a1 += d * y;
+        a2 += d;
+    }
+    if (lane == 0) { red[0][wv] = a0; red[1][wv] = a1; red[2][wv] = a2; }
+    __syncthreads();
     if (tid == 0) {
-        out[C] = red[0][0];
-        out[C + 1] = ow ? red[1][0] : 0.f;
-        out[C + 2] = ow ? red[2][0] : 0.f;
+        out[C] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        out[C + 1] = ow ? ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3] : 0.f;
+        out[C + 2] = ow ? ((red[2][0] + red[2][1]) + red[2][2]) + red[2][3] : 0.f;
     }
 }
 
@@ -598,7 +645,7 @@ extern "C" int dxmi_pool_act_bwd(const void* dout, const void* act_out, void* di
 extern "C" int dxmi_value_head_bwd(const void* feat, const float* w, const float* dy, void* dfeat, float* s, int32_t N,
                                    int32_t HW, int32_t C, void* stream) {
     DXMI_CHECK_ARG(feat && w && dy && dfeat && s, "dxmi_value_head_bwd: null pointer");
-    hipLaunchKernelGGL(value_head_bwd_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, (const bf16*)feat, w, dy, (bf16*)dfeat,
+    hipLaunchKernelGGL(value_head_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16*)feat, w, dy, (bf16*)dfeat,
                        s, HW, C);
     DXMI_CHECK_LAUNCH("dxmi_value_head_bwd");
     return DXMI_OK;
@@ -607,7 +654,7 @@ extern "C" int dxmi_value_head_bwd(const void* feat, const float* w, const float
 extern "C" int dxmi_value_head_pgrad(const float* s, const float* w, const float* b, const float* dy, const float* out_w,
                                      float* out, int32_t N, int32_t C, void* stream) {
     DXMI_CHECK_ARG(s && w && b && dy && out && N > 0 && C > 0, "dxmi_value_head_pgrad: bad arguments");
-    hipLaunchKernelGGL(value_head_pgrad_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s, w, b, dy, out_w, out, N, C);
+    hipLaunchKernelGGL(value_head_pgrad_kernel, dim3((C + 63) / 64 + 1), dim3(256), 0, (hipStream_t)stream, s, w, b, dy, out_w, out, N, C);
     DXMI_CHECK_LAUNCH("dxmi_value_head_pgrad");
     return DXMI_OK;
 }
@@ -634,7 +681,8 @@ extern "C" int dxmi_td_loss(const float* v, const float* cost, const float* extr
 extern "C" int dxmi_value_head(const void* in, const float* w, const float* b, const float* out_w, const float* out_b,
                                float* out, int32_t N, int32_t HW, int32_t C, void* stream) {
     DXMI_CHECK_ARG(in && w && b && out && (!out_w == !out_b), "dxmi_value_head: null pointer");
-    hipLaunchKernelGGL(value_head_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, (const bf16*)in, w, b, out_w,
+    DXMI_CHECK_ARG(C > 0 && C <= 4096, "dxmi_value_head: C=%d (at most 4096 channels)", C);
+    hipLaunchKernelGGL(value_head_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, w, b, out_w,
                        out_b, out, HW, C);
     DXMI_CHECK_LAUNCH("dxmi_value_head");
     return DXMI_OK;

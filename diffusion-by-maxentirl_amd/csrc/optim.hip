@@ -169,7 +169,17 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
                                                        float* __restrict__ out) {
     __shared__ float red[4];
     float acc = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) acc += partials[i];
+    // sixteen loads in flight per thread, added in index order (a plain loop was one round trip per 256 partials: 62 us for the
+    // ImageNet-64 net's ~5 k partials)
+    for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (i0 + u * 256 < n) v[u] = partials[i0 + u * 256];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (i0 + u * 256 < n) acc += v[u];
+    }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
