@@ -253,26 +253,40 @@ __global__ __launch_bounds__(256) void value_head_pgrad_kernel(const float* __re
     }
     const int lane = tid & 63, wv = tid >> 6;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int n = wv; n < N; n += 4) {
-        float part = 0.f;
+    // a wave owns the rows n = wv, wv + 4, ...; four of its rows per trip (their loads in flight together), added in row order
+    for (int n = wv; n < N; n += 16) {
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
         for (int c0 = lane; c0 < C; c0 += 64 * 8) {
-            float sv[8], wvv[8];
+            float sv[4][8], wvv[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (c0 + u * 64 < C) {
-                    sv[u] = s[(size_t)n * C + c0 + u * 64];
                     wvv[u] = w[c0 + u * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + 4 * r < N) sv[r][u] = s[(size_t)(n + 4 * r) * C + c0 + u * 64];
                 }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (c0 + u * 64 < C) part += sv[u] * wvv[u];
+            for (int r = 0; r < 4; ++r)
+                if (n + 4 * r < N) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (c0 + u * 64 < C) part[r] += sv[r][u] * wvv[u];
+                }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-        const float y = part + b[0], d = dy[n];
-        a0 += d * scale;
-        a1 += d * y;
-        a2 += d;
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part[r] += __shfl_xor(part[r], o, 64);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n + 4 * r < N) {
+                const float y = part[r] + b[0], d = dy[n + 4 * r];
+                a0 += d * scale;
+                a1 += d * y;
+                a2 += d;
+            }
     }
     if (lane == 0) { red[0][wv] = a0; red[1][wv] = a1; red[2][wv] = a2; }
     __syncthreads();

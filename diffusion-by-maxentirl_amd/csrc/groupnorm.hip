@@ -1518,7 +1518,10 @@ extern "C" int dxmi_groupnorm_generic_bwd_saved(const void* in0, int32_t C0, con
     // 52 chunks 85 us, 104 chunks 153 us, against 49 us for the two launches; 16 x 8x8x1536: 29 against 80 us), 2 = wherever it
     // fits (tests), 0 = never
     const int fused_knob = dxmi_tuning("gn_bwd_fused");
-    const int kmax = (fused_knob >= 2 || (fused_knob == 1 && HW <= 256)) ? gn_fused_plan(HW, C, &wrows, &wchunks) : 0;
+    int kmax = (fused_knob >= 2 || (fused_knob == 1 && HW <= 256)) ? gn_fused_plan(HW, C, &wrows, &wchunks) : 0;
+    // ... and only while the launch is ONE round of resident workgroups (two per CU: 190 registers): it is the latency chain of a small
+    // launch that the hand-off shortens; at 256 images x 16x16x384 (1 792 workgroups) it measured 121 us against 79 us
+    if (fused_knob == 1 && (long)N * wchunks > 512) kmax = 0;
     if (kmax) {
         // one launch (gn_gen_bwd_fused_kernel) behind the node that zeroes the arrival counters
         char* base = (char*)workspace;
