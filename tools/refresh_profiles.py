@@ -8,7 +8,7 @@ B = "python3 bench.py --no-cpu-baseline --no-eager-reference --no-events" + (" -
 open(f"profiles/{tag}_bench_kernel_stats_summary.txt", "w").write(
     f"# rocprofv3 --kernel-trace --stats summary, round {tag[1:]}\n"
     f"# command: rocprofv3 --kernel-trace --stats --output-format csv -- {B} --steps 5 --warmup 2 --train-steps 0   (1x MI355X)\n"
-    (f"# (7 generation steps of 256 images x T=10 in the trace: 2 warm-up + 5 timed; bench line of the same run in {tag}_bench_under_rocprof.json)\n\n" if tag < "r06" else
+    + (f"# (7 generation steps of 256 images x T=10 in the trace: 2 warm-up + 5 timed; bench line of the same run in {tag}_bench_under_rocprof.json)\n\n" if tag < "r06" else
      f"# (9 generation steps of 256 images x T=10 in the trace: 2 warm-up + the eager first call and the capture call of the hipGraph, python-issued, + 5 timed REPLAYS;\n"
      f"#  bench line of the same run in {tag}_bench_under_rocprof.json)\n\n")
     + run("tools/kstats.py", f"gpurun_out/{tag}_prof_bench", "40"))
