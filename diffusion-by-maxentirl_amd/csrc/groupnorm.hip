@@ -1170,7 +1170,6 @@ __global__ __launch_bounds__(256) void gn_gen_bwd_fused_kernel(GnGenBwdArgs p) {
     const int C = p.C0 + p.C1, c8n = C / 8;
     const int n = blockIdx.x / p.wchunks, w = blockIdx.x % p.wchunks;
     const int tid = threadIdx.x;
-    gn_gen_group_stats(p, n, mean_s, rstd_s);
     const int rows_par = 256 / c8n;
     const int pc = tid % c8n, rl = tid / c8n;
     const bool active = rl < rows_par;
@@ -1196,18 +1195,25 @@ __global__ __launch_bounds__(256) void gn_gen_bwd_fused_kernel(GnGenBwdArgs p) {
                 d[k] = *reinterpret_cast<const bf16x8*>(dyp + (size_t)rr * C);
             }
         }
-        float s0[8], s1[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int g = (c + e) / p.cpg;
-            mu[e] = mean_s[g]; rs[e] = rstd_s[g];
             float ga = p.gamma[c + e], be = p.beta[c + e];
             if (p.ss) {
                 const float sc = 1.f + p.ss[(size_t)n * p.ss_ld + c + e];
                 ga *= sc;
                 be = be * sc + p.ss[(size_t)n * p.ss_ld + C + c + e];
             }
-            A[e] = ga; Bv[e] = be; s0[e] = 0.f; s1[e] = 0.f;
+            A[e] = ga; Bv[e] = be;
+        }
+    }
+    gn_gen_group_stats(p, n, mean_s, rstd_s);       // behind the rows' and parameters' loads: its round trip (statistics partials) overlaps theirs
+    if (active) {
+        float s0[8], s1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c + e) / p.cpg;
+            mu[e] = mean_s[g]; rs[e] = rstd_s[g];
+            s0[e] = 0.f; s1[e] = 0.f;
         }
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {

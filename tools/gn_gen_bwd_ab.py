@@ -44,7 +44,7 @@ for (H, C0, C1, ss) in [(64, 192, 0, False), (64, 192, 0, True), (64, 192, 192, 
     saved = []
     ops.groupnorm_generic(x0, g_, b_, in1=x1, eps=1e-5, silu=True, scale_shift=sst, saved=saved)
     us = []
-    for fused in (0, 1):
+    for fused in (0, int(os.environ.get("FUSED", 1))):      # FUSED=2: the one-launch form on every shape it fits (the default knob: <= 256-pixel maps)
         ops.set_tuning("gn_bwd_fused", fused)
         us.append(graph_time(lambda: ops.groupnorm_generic_bwd(x0, dy, g_, b_, in1=x1, add0=add, eps=1e-5, silu=True, scale_shift=sst, fwd_stats=saved[0])))
     by = 2.0 * N * H * H * (3 * C + (C0 if add is not None else 0))
