@@ -1155,9 +1155,13 @@ __device__ __forceinline__ unsigned long long gn_pack2(float a, float b) {
     return ((unsigned long long)__float_as_uint(b) << 32) | (unsigned long long)__float_as_uint(a);
 }
 
+// one arrival counter per image, 256 bytes apart: every workgroup of an image polls its counter, and sixteen counters in one 64-byte
+// line put all those polls (and the arrivals they wait for) on ONE memory channel
+constexpr int GN_CNT_STRIDE = 64;     // words
+
 __global__ void gn_zero_counters_kernel(unsigned* cnt, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) __hip_atomic_store(cnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i < n) __hip_atomic_store(cnt + (size_t)i * GN_CNT_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int KMAX>
@@ -1265,14 +1269,14 @@ __global__ __launch_bounds__(256) void gn_gen_bwd_fused_kernel(GnGenBwdArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __hip_atomic_fetch_add(p.cnt + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(p.cnt + (size_t)n * GN_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 0;
         for (unsigned spins = 0; spins < (1u << 24); ++spins) {
-            if (__hip_atomic_load(p.cnt + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.wchunks) {
+            if (__hip_atomic_load(p.cnt + (size_t)n * GN_CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.wchunks) {
                 ok = 1;
                 break;
             }
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(16);
         }
         ok_s = ok;
     }
@@ -1487,7 +1491,7 @@ extern "C" int64_t dxmi_groupnorm_generic_bwd_workspace_bytes(int32_t N, int32_t
     int wrows = 0, wchunks = 0;
     if (C < 8 || !gn_fused_plan(HW, C, &wrows, &wchunks)) return two_launch;
     // one-launch form: [counters, padded to 16 bytes][statistics partials][group granules][channel granules]
-    const int64_t fused = gn_round16((int64_t)N * 4) + (int64_t)N * chunks * 32 * 2 * 4 + (int64_t)N * wchunks * 32 * 8 + (int64_t)N * wchunks * C * 8;
+    const int64_t fused = (int64_t)N * GN_CNT_STRIDE * 4 + (int64_t)N * chunks * 32 * 2 * 4 + (int64_t)N * wchunks * 32 * 8 + (int64_t)N * wchunks * C * 8;
     return fused > two_launch ? fused : two_launch;
 }
 
@@ -1531,7 +1535,7 @@ extern "C" int dxmi_groupnorm_generic_bwd_saved(const void* in0, int32_t C0, con
     if (kmax) {
         // one launch (gn_gen_bwd_fused_kernel) behind the node that zeroes the arrival counters
         char* base = (char*)workspace;
-        const int64_t cnt_bytes = gn_round16((int64_t)N * 4);
+        const int64_t cnt_bytes = (int64_t)N * GN_CNT_STRIDE * 4;
         float* part2 = (float*)(base + cnt_bytes);
         a.cnt = (unsigned*)base;
         a.grp = (unsigned long long*)(base + cnt_bytes + (int64_t)N * chunks * 32 * 2 * 4);
