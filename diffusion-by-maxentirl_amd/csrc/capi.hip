@@ -67,6 +67,20 @@ extern "C" int dxmi_get_tuning(const char* name, int32_t* value) {
     return DXMI_OK;
 }
 
+// Compute units of the current device (cached per device; 0 when there is none): residency bound of the kernels that hand data
+// over between workgroups inside a launch (groupnorm.hip).
+int dxmi_device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus[dev] = prop.multiProcessorCount;
+    }
+    return cus[dev];
+}
+
 extern "C" int dxmi_device_check(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {

@@ -15,6 +15,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 void dxmi_set_error(const char* fmt, ...);
+int dxmi_device_cus();                  // capi.hip: compute units of the current device (0: none)
 int dxmi_tuning(const char* name);      // capi.hip: value of a kernel-selection knob (dxmi_set_tuning)
 
 #define DXMI_CHECK_ARG(cond, ...)                 \

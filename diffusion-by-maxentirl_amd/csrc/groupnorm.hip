@@ -1532,6 +1532,9 @@ extern "C" int dxmi_groupnorm_generic_bwd_saved(const void* in0, int32_t C0, con
     // ... and only while the launch is ONE round of resident workgroups (two per CU: 190 registers): it is the latency chain of a small
     // launch that the hand-off shortens; at 256 images x 16x16x384 (1 792 workgroups) it measured 121 us against 79 us
     if (fused_knob == 1 && (long)N * wchunks > 512) kmax = 0;
+    // residency: the workgroups of an image wait for each other, so an image's work chunks must fit the device at one workgroup per CU
+    // whatever else holds (a 32-CU partition of the chip included); otherwise the two launches
+    if (kmax && wchunks > dxmi_device_cus()) kmax = 0;
     if (kmax) {
         // one launch (gn_gen_bwd_fused_kernel) behind the node that zeroes the arrival counters
         char* base = (char*)workspace;
