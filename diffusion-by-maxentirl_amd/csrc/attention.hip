@@ -46,6 +46,8 @@ struct AttnArgs {
     const bf16* res;        // [N,256,256] (the AttnBlock's input x)
     float* gn_stats;        // optional: GroupNorm block statistics of the output, [N][8][128][2] (a partial per 32 tokens)
     int xcd;             // XCD-aware block order (round 6): the query blocks of one (image, head) share K / V behind one L2
+    float* lse;          // optional (attention_kernel<D>, attention64_kernel): row log-sum-exp in the log2 domain, [N][heads][T] —
+                         // max + log2(sum) of scale * log2(e) * S, what attn_bwd_dq_kernel otherwise recomputes in a sweep of its own
 };
 
 #ifndef ATTN_WPE
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(256, D == 64 ? ATTN_WPE : 1) void attention_kernel(
 
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.f / l;
+    if (p.lse && qvalid && h == 0) p.lse[((size_t)n * p.heads + hd) * p.T + query] = m + __log2f(l);
     if (qvalid) {
         bf16* orow = p.out + ((size_t)n * p.T + query) * p.C + hd * D;
 #pragma unroll
@@ -408,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void attention64_kernel(AttnArgs p) {
     for (int t = 0; t < 2; ++t) {
         const float lt = l[t] + __shfl_xor(l[t], 32, 64);
         const float inv = 1.f / lt;
+        if (p.lse && h == 0) p.lse[((size_t)n * p.heads + hd) * p.T + query0 + 32 * t] = m[t] + __log2f(lt);
         bf16* orow = p.out + ((size_t)n * p.T + query0 + 32 * t) * p.C + hd * D;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
@@ -799,19 +803,43 @@ extern "C" int dxmi_attention_proj_fwd(const void* qkv, const void* wproj_packed
     a.qkv = (const bf16*)qkv; a.out = (bf16*)out; a.N = N; a.T = T; a.C = C; a.heads = heads;
     a.q_off = 0; a.k_off = C; a.v_off = 2 * C; a.head_stride = C; a.scale = scale;
     a.wproj = (const bf16*)wproj_packed; a.pbias = bias; a.res = (const bf16*)residual; a.gn_stats = gn_stats;
-    a.xcd = 0;
+    a.xcd = 0; a.lse = nullptr;
     return launch_attn256(a, (hipStream_t)stream);
 }
 
+static int attention_fwd_impl(const void* qkv, void* out, float* lse, int32_t N, int32_t T, int32_t C, int32_t heads, float scale, void* stream);
+
 extern "C" int dxmi_attention_fwd(const void* qkv, void* out, int32_t N, int32_t T, int32_t C, int32_t heads,
                                   float scale, void* stream) {
+    return attention_fwd_impl(qkv, out, nullptr, N, T, C, heads, scale, stream);
+}
+
+// 1 when dxmi_attention_fwd_lse serves the shape (the kernels that keep a running (max, sum) per query: every shape but the
+// single-head 256 x 256 one of attention256_kernel).
+extern "C" int dxmi_attention_fwd_lse_supported(int32_t T, int32_t C, int32_t heads) {
+    if (heads <= 0 || C % heads != 0 || T <= 0) return 0;
+    const int D = C / heads;
+    if (D == 256 && T == 256 && heads == 1) return 0;
+    return D == 64 || D == 128 || D == 256;
+}
+
+// The forward that also leaves the row log-sum-exp (log2 domain, fp32 [N][heads][T]) for dxmi_attention_bwd_lse: the saved softmax
+// statistics of autograd's attention node.
+extern "C" int dxmi_attention_fwd_lse(const void* qkv, void* out, float* lse, int32_t N, int32_t T, int32_t C, int32_t heads,
+                                      float scale, void* stream) {
+    DXMI_CHECK_ARG(lse, "dxmi_attention_fwd_lse: null lse pointer");
+    DXMI_CHECK_ARG(dxmi_attention_fwd_lse_supported(T, C, heads), "dxmi_attention_fwd_lse: shape T=%d C=%d heads=%d not served", T, C, heads);
+    return attention_fwd_impl(qkv, out, lse, N, T, C, heads, scale, stream);
+}
+
+static int attention_fwd_impl(const void* qkv, void* out, float* lse, int32_t N, int32_t T, int32_t C, int32_t heads, float scale, void* stream) {
     DXMI_CHECK_ARG(qkv && out, "dxmi_attention_fwd: null pointer");
     DXMI_CHECK_ARG(N > 0 && T > 0 && heads > 0 && C % heads == 0, "dxmi_attention_fwd: bad shape N=%d T=%d C=%d heads=%d", N, T, C, heads);
     const int D = C / heads;
     AttnArgs a;
     a.qkv = (const bf16*)qkv; a.out = (bf16*)out; a.N = N; a.T = T; a.C = C; a.heads = heads;
     a.q_off = 0; a.k_off = C; a.v_off = 2 * C; a.head_stride = D; a.scale = scale;
-    a.wproj = nullptr; a.pbias = nullptr; a.res = nullptr; a.gn_stats = nullptr;
+    a.wproj = nullptr; a.pbias = nullptr; a.res = nullptr; a.gn_stats = nullptr; a.lse = lse;
     static const int xcd_env = getenv("DXMI_ATTN_XCD") ? atoi(getenv("DXMI_ATTN_XCD")) : 1;      // 0: hardware block order (A/B timing)
     a.xcd = xcd_env;
     hipStream_t st = (hipStream_t)stream;

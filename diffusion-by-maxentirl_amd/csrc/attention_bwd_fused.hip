@@ -43,6 +43,7 @@ struct AttnBwdArgs {
     bf16* dqkv;          // [N, T, 3C]
     float* lse;          // [N, heads, T]
     float* delta;        // [N, heads, T]
+    const float* lse_in; // optional: the forward's row log-sum-exp (dxmi_attention_fwd_lse) — sweep 1 of attn_bwd_dq_kernel is then skipped
     int N, T, C, heads;
     float scale;
     int xcd;             // XCD-aware block order: the query / key blocks of one (image, head) behind one L2 (see attention.hip)
@@ -127,9 +128,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     delta += __shfl_xor(delta, 32, 64);
 
     const int nkb = (p.T + AB_KB - 1) / AB_KB;
-    // ---- sweep 1: row log-sum-exp
+    // ---- sweep 1: row log-sum-exp (skipped when the forward saved it: launch-uniform branch)
     float m = -INFINITY, l = 0.f;
-    for (int kb = 0; kb < nkb; ++kb) {
+    for (int kb = 0; kb < (p.lse_in ? 0 : nkb); ++kb) {
         __syncthreads();
         stage_block(base + kc, C3, kb * AB_KB, p.T, kimg, nullptr, tid);
         __syncthreads();
@@ -163,9 +164,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
         m = m_new;
     }
     l += __shfl_xor(l, 32, 64);
-    const float lse = m + __log2f(l);          // log2 domain throughout (both kernels): P = exp2(sc2 S - L)
+    const size_t si = ((size_t)n * p.heads + hd) * p.T + (qvalid ? query : 0);
+    const float lse = p.lse_in ? p.lse_in[si] : m + __log2f(l);          // log2 domain throughout (both kernels): P = exp2(sc2 S - L)
     if (qvalid && h == 0) {
-        const size_t si = ((size_t)n * p.heads + hd) * p.T + query;
         p.lse[si] = lse;
         p.delta[si] = delta;
     }
@@ -351,14 +352,30 @@ extern "C" int64_t dxmi_attention_bwd_workspace_bytes(int32_t N, int32_t T, int3
     return (int64_t)2 * N * heads * T * 4;
 }
 
+static int attention_bwd_impl(const void* qkv, const void* o, const void* dout, void* dqkv, const float* lse_fwd, void* workspace, int32_t N,
+                              int32_t T, int32_t C, int32_t heads, float scale, void* stream);
+
 extern "C" int dxmi_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, void* workspace, int32_t N, int32_t T,
                                   int32_t C, int32_t heads, float scale, void* stream) {
+    return attention_bwd_impl(qkv, o, dout, dqkv, nullptr, workspace, N, T, C, heads, scale, stream);
+}
+
+// lse_fwd: what dxmi_attention_fwd_lse left for these qkv and this scale ([N][heads][T], log2 domain): the backward then runs three
+// sweeps over the keys instead of four (autograd's saved softmax statistics).
+extern "C" int dxmi_attention_bwd_lse(const void* qkv, const void* o, const void* dout, void* dqkv, const float* lse_fwd, void* workspace,
+                                      int32_t N, int32_t T, int32_t C, int32_t heads, float scale, void* stream) {
+    DXMI_CHECK_ARG(lse_fwd, "dxmi_attention_bwd_lse: null lse pointer");
+    return attention_bwd_impl(qkv, o, dout, dqkv, lse_fwd, workspace, N, T, C, heads, scale, stream);
+}
+
+static int attention_bwd_impl(const void* qkv, const void* o, const void* dout, void* dqkv, const float* lse_fwd, void* workspace, int32_t N,
+                              int32_t T, int32_t C, int32_t heads, float scale, void* stream) {
     DXMI_CHECK_ARG(qkv && o && dout && dqkv && workspace, "dxmi_attention_bwd: null pointer");
     DXMI_CHECK_ARG(N > 0 && T > 0 && heads > 0 && C > 0 && C % heads == 0, "dxmi_attention_bwd: bad shape N=%d T=%d C=%d heads=%d", N, T, C, heads);
     DXMI_CHECK_ARG(dxmi_attention_bwd_supported(T, C, heads), "dxmi_attention_bwd: head dimension %d unsupported (64)", C / heads);
     AttnBwdArgs a;
     a.qkv = (const bf16*)qkv; a.o = (const bf16*)o; a.dout = (const bf16*)dout; a.dqkv = (bf16*)dqkv;
-    a.lse = (float*)workspace; a.delta = a.lse + (size_t)N * heads * T;
+    a.lse = (float*)workspace; a.delta = a.lse + (size_t)N * heads * T; a.lse_in = lse_fwd;
     a.N = N; a.T = T; a.C = C; a.heads = heads; a.scale = scale;
     static const int xcd_env = getenv("DXMI_ATTN_XCD") ? atoi(getenv("DXMI_ATTN_XCD")) : 1;      // 0: hardware block order (A/B timing)
     a.xcd = xcd_env;

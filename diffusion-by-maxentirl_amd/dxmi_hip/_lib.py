@@ -54,6 +54,9 @@ SIGNATURES = {
     "dxmi_groupnorm_apply_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                            c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dxmi_gn_blockstats_to_generic": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "dxmi_attention_fwd_lse_supported": (c_int, [c_int, c_int, c_int]),
+    "dxmi_attention_fwd_lse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "dxmi_attention_bwd_lse": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "dxmi_gn_ss_grads": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dxmi_fid_stats_workspace_bytes": (c_int64, [c_int64, c_int]),
     "dxmi_fid_stats": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

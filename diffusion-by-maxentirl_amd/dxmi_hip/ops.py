@@ -655,10 +655,11 @@ def bgemm(A, B, C, M, N, K, a_strides, a_ld, a_kc, b_strides, b_ld, b_kc, c_stri
 FUSED_ATTENTION_BWD = True      # A-B switch: False keeps the five-GEMM path for every head size
 
 
-def attention_bwd(qkv, do, heads, scale, o=None):
+def attention_bwd(qkv, do, heads, scale, o=None, lse=None):
     """qkv [N,T,3C] ([q|k|v], heads = contiguous channel blocks), do [N,T,C] -> dqkv [N,T,3C] (bf16).
-    o: the forward pass's attention output [N,T,C]; with it, 64-wide heads take the fused kernels (no [T,T] tensor in HBM)."""
-    _need_cuda(qkv, do, o)
+    o: the forward pass's attention output [N,T,C]; with it, 64-wide heads take the fused kernels (no [T,T] tensor in HBM).
+    lse: what attention(want_lse=True) returned for these qkv: the fused backward skips its log-sum-exp sweep."""
+    _need_cuda(qkv, do, o, lse)
     N, T, C3 = qkv.shape
     C = C3 // 3
     D = C // heads
@@ -668,6 +669,12 @@ def attention_bwd(qkv, do, heads, scale, o=None):
         assert o.dtype == torch.bfloat16 and o.is_contiguous() and o.numel() == N * T * C
         dqkv = torch.empty_like(qkv)
         ws = _workspace(max(256, load().dxmi_attention_bwd_workspace_bytes(N, T, heads)), dev)
+        if lse is not None:
+            assert lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == (N, heads, T)
+            _prof("attention_bwd", f"T{T}_D{D}", 14.0 * N * T * T * C, 2.0 * (2 * qkv.numel() + 2 * do.numel()) * 2, lambda: check(
+                load().dxmi_attention_bwd_lse(_ptr(qkv), _ptr(o), _ptr(do), _ptr(dqkv), _ptr(lse), _ptr(ws), N, T, C, heads, float(scale),
+                                              _stream()), "dxmi_attention_bwd_lse"))
+            return dqkv
         _prof("attention_bwd", f"T{T}_D{D}", 16.0 * N * T * T * C, 2.0 * (2 * qkv.numel() + 2 * do.numel()) * 2, lambda: check(
             load().dxmi_attention_bwd(_ptr(qkv), _ptr(o), _ptr(do), _ptr(dqkv), _ptr(ws), N, T, C, heads, float(scale), _stream()),
             "dxmi_attention_bwd"))
@@ -873,17 +880,24 @@ def edm_step(x, model_out, z, sigma, sigma_down, sigma_up, sigma_data=0.5, outs=
     return sample, mean
 
 
-def attention(qkv, heads, scale, out=None):
-    """qkv: [N, T, 3C] bf16 laid out [q|k|v]; returns [N, T, C] bf16."""
+def attention(qkv, heads, scale, out=None, want_lse=False):
+    """qkv: [N, T, 3C] bf16 laid out [q|k|v]; returns [N, T, C] bf16.  want_lse: -> (out, lse | None): the row log-sum-exp the
+    kernel leaves for attention_bwd(lse=...) (fp32 [N, heads, T], log2 domain; None for the shapes that have no such kernel)."""
     _need_cuda(qkv, out)
     N, T, C3 = qkv.shape
     C = C3 // 3
     assert qkv.dtype == torch.bfloat16 and qkv.is_contiguous()
     if out is None:
         out = torch.empty((N, T, C), dtype=torch.bfloat16, device=qkv.device)
+    lib = load()
+    if want_lse and lib.dxmi_attention_fwd_lse_supported(T, C, heads):
+        lse = torch.empty((N, heads, T), dtype=torch.float32, device=qkv.device)
+        _prof("attention", f"T{T}_D{C // heads}", 4.0 * N * T * T * C, 2.0 * N * T * 4 * C, lambda: check(
+            lib.dxmi_attention_fwd_lse(_ptr(qkv), _ptr(out), _ptr(lse), N, T, C, heads, float(scale), _stream()), "dxmi_attention_fwd_lse"))
+        return out, lse
     _prof("attention", f"T{T}_D{C // heads}", 4.0 * N * T * T * C, 2.0 * N * T * 4 * C, lambda: check(
-        load().dxmi_attention_fwd(_ptr(qkv), _ptr(out), N, T, C, heads, float(scale), _stream()), "dxmi_attention_fwd"))
-    return out
+        lib.dxmi_attention_fwd(_ptr(qkv), _ptr(out), N, T, C, heads, float(scale), _stream()), "dxmi_attention_fwd"))
+    return (out, None) if want_lse else out
 
 
 def attention_proj_supported(T, C, heads):

@@ -72,6 +72,8 @@ def _pack_t(net):
 # Training forward: GroupNorm on the producers' block statistics (streaming apply) where the inference path uses them; 0 = the generic
 # statistics + apply pair everywhere (rounds 3-5).
 STREAM_GN = os.environ.get("DXMI_TRAIN_STREAM_GN", "1") == "1"
+# Training forward keeps the attention rows' log-sum-exp for the backward (dxmi_attention_fwd_lse / _bwd_lse); 0 = the backward recomputes it.
+SAVE_LSE = os.environ.get("DXMI_ATTN_SAVE_LSE", "1") == "1"
 
 
 def _up_sum(g):
@@ -143,9 +145,11 @@ class _EDMUNetFn(torch.autograd.Function):
             N, H, W, C = xa.shape
             hn, sn = gn_fwd(m.norm, xa, sx, silu=False)
             qkv = ops.conv2d(hn, pk[id(m), "qkv"], bias=m.qkv.bias)
-            a = ops.attention(qkv.view(N, H * W, 3 * C), heads=m.num_heads, scale=1.0 / math.sqrt(C // m.num_heads))
+            # the row log-sum-exp rides along (autograd's saved softmax statistics): the backward skips its own sweep for it
+            a, lse = ops.attention(qkv.view(N, H * W, 3 * C), heads=m.num_heads, scale=1.0 / math.sqrt(C // m.num_heads), want_lse=True)
+            lse = lse if SAVE_LSE else None
             out = ops.conv2d(a.view(N, H, W, C), pk[id(m), "proj"], bias=m.proj_out.bias, residual=xa)
-            tape.append(("attn", m, xa, hn, qkv, a, sn))
+            tape.append(("attn", m, xa, hn, qkv, a, sn, lse))
             return out, stats_of(out)
 
         def seq(mods, h, skip, sh, sskip):
@@ -268,12 +272,12 @@ class _EDMUNetFn(torch.autograd.Function):
             return d_x0, None
 
         def attn_bwd(entry, g):
-            _, m, xa, hn, qkv, a, sn = entry
+            _, m, xa, hn, qkv, a, sn, lse = entry
             Nn, Hh, Ww, C = xa.shape
             conv_wb(m.proj_out, a.view(Nn, Hh, Ww, C), g, 1)
             d_a = ops.conv2d(g, pkt[id(m), "proj"])
             d_qkv = ops.attention_bwd(qkv.view(Nn, Hh * Ww, 3 * C), d_a.view(Nn, Hh * Ww, C), m.num_heads,
-                                      1.0 / math.sqrt(C // m.num_heads), o=a.view(Nn, Hh * Ww, C)).view(Nn, Hh, Ww, 3 * C)
+                                      1.0 / math.sqrt(C // m.num_heads), o=a.view(Nn, Hh * Ww, C), lse=lse).view(Nn, Hh, Ww, 3 * C)
             conv_wb(m.qkv, hn, d_qkv, 1)
             d_hn = ops.conv2d(d_qkv, pkt[id(m), "qkv"])
             d_x, _, _ = gn_bwd(m.norm, xa, d_hn, add0=g, silu=False, fwd_stats=sn)

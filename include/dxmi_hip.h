@@ -222,6 +222,15 @@ int64_t dxmi_attention_bwd_workspace_bytes(int32_t N, int32_t T, int32_t heads);
 int dxmi_attention_bwd(const void* qkv, const void* o, const void* dout, void* dqkv, void* workspace, int32_t N, int32_t T,
                        int32_t C, int32_t heads, float scale, void* stream);
 
+/* The saved softmax statistics of autograd's attention node (round 6): dxmi_attention_fwd_lse is dxmi_attention_fwd that also leaves the
+ * row log-sum-exp of the scaled logits (log2 domain: max + log2(sum) of scale * log2(e) * q.k; fp32 [N][heads][T]); dxmi_attention_bwd_lse
+ * is dxmi_attention_bwd taking it, one sweep over the keys shorter.  _supported: every shape of dxmi_attention_fwd except the
+ * single-head 256-token x 256-channel block.  Replaces models/cm/unet.py:413-441 under autograd. */
+int dxmi_attention_fwd_lse_supported(int32_t T, int32_t C, int32_t heads);
+int dxmi_attention_fwd_lse(const void* qkv, void* out, float* lse, int32_t N, int32_t T, int32_t C, int32_t heads, float scale, void* stream);
+int dxmi_attention_bwd_lse(const void* qkv, const void* o, const void* dout, void* dqkv, const float* lse_fwd, void* workspace, int32_t N,
+                           int32_t T, int32_t C, int32_t heads, float scale, void* stream);
+
 /* Backward of dxmi_pool_act: din = (pool ? 0.25 * upsample2(g) : g), g = dout * (act_out > 0 ? 1 : slope);
  * dout/act_out: [N,OH,OW,C], din: [N,H,W,C] (H = 2*OH when pool). */
 int dxmi_pool_act_bwd(const void* dout, const void* act_out, void* din, int32_t N, int32_t H, int32_t W,

@@ -171,6 +171,9 @@ int main(void) {
         expect_einval("gn_blockstats_to_generic(second part without stats)", dxmi_gn_blockstats_to_generic((const float*)FAKE(1), 4, 192, NULL, 0, 192, (float*)FAKE(2), 4, 1024, 32, NULL));
         expect_einval("gn_ss_grads(NULL g)", dxmi_gn_ss_grads(NULL, (const float*)FAKE(1), 768, (const float*)FAKE(2), (const float*)FAKE(3), (float*)FAKE(4), (float*)FAKE(5), (float*)FAKE(6), 16, 384, NULL));
         expect_einval("gn_ss_grads(ss_ld < 2C)", dxmi_gn_ss_grads((const float*)FAKE(7), (const float*)FAKE(1), 384, (const float*)FAKE(2), (const float*)FAKE(3), (float*)FAKE(4), (float*)FAKE(5), (float*)FAKE(6), 16, 384, NULL));
+        expect_einval("attention_fwd_lse(NULL lse)", dxmi_attention_fwd_lse(FAKE(1), FAKE(2), NULL, 2, 256, 384, 6, 0.125f, NULL));
+        expect_einval("attention_fwd_lse(256 x 256 single head)", dxmi_attention_fwd_lse(FAKE(1), FAKE(2), (float*)FAKE(3), 2, 256, 256, 1, 0.0625f, NULL));
+        expect_einval("attention_bwd_lse(NULL lse)", dxmi_attention_bwd_lse(FAKE(1), FAKE(2), FAKE(3), FAKE(4), NULL, FAKE(5), 2, 256, 384, 6, 0.125f, NULL));
         expect_einval("td_loss(B = 0)", dxmi_td_loss((const float*)FAKE(1), (const float*)FAKE(2), NULL, (float*)FAKE(3), (float*)FAKE(4), 0, NULL));
         expect_einval("value_head_pgrad(NULL dy)", dxmi_value_head_pgrad((const float*)FAKE(1), (const float*)FAKE(2), (const float*)FAKE(3), NULL, NULL, (float*)FAKE(4), 32, 256, NULL));
         expect_einval("gconv_fwd(Cin % 16 != 0)", dxmi_gconv_fwd(FAKE(1), FAKE(2), (const float*)FAKE(3), FAKE(4), 2, 35, 35, 40, 64, 5, 5, 1, 1, 2, 2, 64, 0, 1, NULL));

@@ -355,6 +355,34 @@ def test_gn_ss_grads_vs_torch():
         torch.testing.assert_close(dgb[1], (g[0] * one_s).sum(0), rtol=1e-5, atol=1e-5)
 
 
+def test_attention_backward_with_the_forwards_log_sum_exp():
+    """dxmi_attention_fwd_lse / dxmi_attention_bwd_lse (round 6): the forward's row log-sum-exp equals log2(sum exp(scale q.k)) of an fp32
+    restatement, its output is bitwise dxmi_attention_fwd's, and the backward that takes it agrees with the backward that recomputes it
+    (64-wide heads at the ADM nets' token counts: both forward kernels, a ragged T)."""
+    import math
+    import torch
+    from dxmi_hip import ops
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(4)
+    for (N, T, heads) in [(3, 1024, 6), (2, 256, 9), (5, 64, 12), (2, 100, 3)]:
+        C = 64 * heads
+        qkv = (torch.randn(N, T, 3 * C, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+        do = torch.randn(N, T, C, generator=g).to(torch.bfloat16).to(dev)
+        scale = 1.0 / math.sqrt(64)
+        o_plain = ops.attention(qkv, heads, scale)
+        o, lse = ops.attention(qkv, heads, scale, want_lse=True)
+        assert lse is not None and torch.equal(o, o_plain)
+        q, k = qkv[:, :, :C].float().view(N, T, heads, 64), qkv[:, :, C:2 * C].float().view(N, T, heads, 64)
+        s = torch.einsum("nthd,nshd->nhts", q, k) * scale
+        ref = torch.logsumexp(s, dim=-1) / math.log(2.0)
+        torch.testing.assert_close(lse, ref, rtol=1e-4, atol=2e-3)
+        a = ops.attention_bwd(qkv, do, heads, scale, o=o)
+        b = ops.attention_bwd(qkv, do, heads, scale, o=o, lse=lse)
+        rel = float((a.float() - b.float()).norm() / a.float().norm())
+        assert rel < 2e-3, (N, T, heads, rel)
+    assert ops.attention(torch.zeros(1, 256, 768, dtype=torch.bfloat16, device=dev), 1, 1.0, want_lse=True)[1] is None     # attention256_kernel: no lse
+
+
 def test_var_and_edm_step_backward_vs_torch_autograd():
     """dxmi_var_step_bwd / dxmi_edm_step_bwd (round 6) against torch autograd over the reference's elementwise expressions
     (var_sampler.py:357-408 incl. the log-prob with x' detached; openai_diffusion.py:71-94), every output contributing to the loss."""
