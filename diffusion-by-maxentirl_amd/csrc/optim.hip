@@ -140,27 +140,49 @@ __global__ __launch_bounds__(MT_BLOCK) void mt_adam_kernel(MtTable t, AdamScalar
 // ---------------------------------------------------------------------------------------------------------
 // squared gradient norm: one fp32 partial per workgroup (fixed order inside the block), written to
 // partials[part_offset + block]; dxmi_clip_coef reduces them in a fixed order -> run-to-run reproducible.
-__global__ __launch_bounds__(MT_BLOCK) void mt_sqnorm_kernel(MtTable t, float* __restrict__ partials, int part_offset) {
-    __shared__ float red[MT_BLOCK / 64];
-    const int ti = mt_find(t, blockIdx.x);
-    const int64_t n = t.numel[ti];
-    const int64_t base = (int64_t)(blockIdx.x - t.first_block[ti]) * MT_CHUNK;
-    const float* __restrict__ G = (const float*)t.ptr[1][ti];
-    float acc = 0.f;
-    if ((((uintptr_t)G) & 15) == 0 && base + MT_CHUNK <= n) {
+// A workgroup takes SQ_CH consecutive 4096-element chunks and issues the loads of all of them before the first add (one chunk per
+// workgroup was four 16-byte loads per thread and a workgroup that lived for one memory round trip: 2.5 TB/s over the 1.2 GB of
+// gradients of the ImageNet-64 net); every chunk keeps its own partial, formed exactly as before: the norm's bits are unchanged.
+constexpr int SQ_CH = 4;
+__global__ __launch_bounds__(MT_BLOCK) void mt_sqnorm_kernel(MtTable t, float* __restrict__ partials, int part_offset, int nblocks) {
+    __shared__ float red[SQ_CH][MT_BLOCK / 64];
+    constexpr int R = MT_CHUNK / (MT_BLOCK * 4);
+    f32x4 g[SQ_CH][R];
+    bool fast[SQ_CH];
+    float acc[SQ_CH];
 #pragma unroll
-        for (int r = 0; r < MT_CHUNK / (MT_BLOCK * 4); ++r) {
-            const f32x4 g = *(const f32x4*)(G + base + (int64_t)(r * MT_BLOCK + threadIdx.x) * 4);
-            acc += g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + g[3] * g[3];
+    for (int c = 0; c < SQ_CH; ++c) {
+        const int bid = blockIdx.x * SQ_CH + c;
+        acc[c] = 0.f;
+        fast[c] = false;
+        if (bid >= nblocks) continue;
+        const int ti = mt_find(t, bid);
+        const int64_t n = t.numel[ti];
+        const int64_t base = (int64_t)(bid - t.first_block[ti]) * MT_CHUNK;
+        const float* __restrict__ G = (const float*)t.ptr[1][ti];
+        if ((((uintptr_t)G) & 15) == 0 && base + MT_CHUNK <= n) {
+            fast[c] = true;
+#pragma unroll
+            for (int r = 0; r < R; ++r) g[c][r] = *(const f32x4*)(G + base + (int64_t)(r * MT_BLOCK + threadIdx.x) * 4);
+        } else {
+            const int64_t end = base + MT_CHUNK < n ? base + MT_CHUNK : n;
+            for (int64_t i = base + threadIdx.x; i < end; i += MT_BLOCK) acc[c] += G[i] * G[i];
         }
-    } else {
-        const int64_t end = base + MT_CHUNK < n ? base + MT_CHUNK : n;
-        for (int64_t i = base + threadIdx.x; i < end; i += MT_BLOCK) acc += G[i] * G[i];
     }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+#pragma unroll
+    for (int c = 0; c < SQ_CH; ++c) {
+        if (fast[c]) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[c] += g[c][r][0] * g[c][r][0] + g[c][r][1] * g[c][r][1] + g[c][r][2] * g[c][r][2] + g[c][r][3] * g[c][r][3];
+        }
+        const float a = wave_sum(acc[c]);
+        if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = a;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) partials[part_offset + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x < SQ_CH) {
+        const int bid = blockIdx.x * SQ_CH + threadIdx.x;
+        if (bid < nblocks) partials[part_offset + bid] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
 }
 
 // total = sqrt(sum partials); coef = min(1, max_norm / (total + 1e-6))   (torch.nn.utils.clip_grad_norm_);
@@ -408,7 +430,7 @@ extern "C" int dxmi_gradnorm_clip(void* const* grads, const int64_t* numel, int3
         int nb = 0;
         DXMI_CHECK_ARG(fill_table(t, c, nullptr, grads + off, nullptr, nullptr, numel + off, nullptr, &nb),
                        "dxmi_gradnorm_clip: empty tensor in the list");
-        hipLaunchKernelGGL(mt_sqnorm_kernel, dim3(nb), dim3(MT_BLOCK), 0, (hipStream_t)stream, t, partials, total_blocks);
+        hipLaunchKernelGGL(mt_sqnorm_kernel, dim3((nb + SQ_CH - 1) / SQ_CH), dim3(MT_BLOCK), 0, (hipStream_t)stream, t, partials, total_blocks, nb);
         total_blocks += nb;
     }
     hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, total_blocks, max_norm, out3);
