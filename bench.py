@@ -460,12 +460,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("DXMI_BENCH_ONE_DEVICE") == "1":      # tests: every rank on cuda:0 of a 1-GPU box (with DXMI_BENCH_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # RCCL
+        backend = os.environ.get("DXMI_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL; "gloo" only for the world-2-on-one-GPU test of this file
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from dxmi_hip import graph as hip_graph
     from dxmi_hip import ops
@@ -573,15 +579,17 @@ def main():
         assert all(v == v for v in logs[0].values())   # no NaN
         train_sps = args.train_steps / t_train
         t_train_step = t_train / args.train_steps
-        if rank == 0 and not args.no_events:
-            prof = ops.OpProfiler()
+        if not args.no_events:
+            # EVERY rank runs this step (its gradient exchanges are collectives: a step on rank 0 alone would wait for ranks that are
+            # already at the next barrier); the per-launch events are taken on rank 0 only
+            prof = ops.OpProfiler() if rank == 0 else None
             ops.PROFILER = prof
             sampler.use_graph = tr.use_graphs = False
             train_step(tr, sampler, imgs, device, ring)
             torch.cuda.synchronize()
             ops.PROFILER = None
             sampler.use_graph = tr.use_graphs = use_graph
-            train_summ = prof.summary()
+            train_summ = prof.summary() if prof is not None else None
         ops.tune_for_throughput(False)
         sync_all()
 
@@ -609,7 +617,7 @@ def main():
     if world > 1:
         wire = getattr(getattr(tr, "sync_sampler", None), "wire_dtype", None) if args.train_steps > 0 else None
         line["rccl"] = {"world": world, "backend": torch.distributed.get_backend(),
-                        "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                        "nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if torch.distributed.get_backend() == "nccl" else None,
                         "wire_dtype": str(wire or torch.float32).replace("torch.", ""),
                         "collectives_in_generation": 0,
                         "collectives_per_train_step": f"{T + 1} value-net all-reduces (20.5 MB fp32) + the U-Net's ~32 MB buckets (143 MB fp32)"}
