@@ -460,14 +460,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    if os.environ.get("DXMI_BENCH_ONE_DEVICE") == "1":      # tests: every rank on cuda:0 of a 1-GPU box (with DXMI_BENCH_BACKEND=gloo)
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    from dxmi_hip import dist as hip_dist
+    device = torch.device(hip_dist.rank_device(local_rank))     # cuda:<LOCAL_RANK>; DXMI_DIST_ONE_DEVICE=1 (tests): every rank on cuda:0
+    torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("DXMI_BENCH_BACKEND", "nccl")      # "nccl" IS RCCL; "gloo" only for the world-2-on-one-GPU test of this file
+        backend = hip_dist.dist_backend()      # "nccl" IS RCCL; DXMI_DIST_BACKEND=gloo only for the world-2-on-one-GPU test of this file
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:

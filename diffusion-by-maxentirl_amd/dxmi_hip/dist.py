@@ -264,3 +264,17 @@ class FlatGradSync:
         self._reset()
 
     __call__ = sync
+
+
+def rank_device(local_rank):
+    """Device of this rank: cuda:<LOCAL_RANK>, one process per GPU (the reference's torchrun convention).  DXMI_DIST_ONE_DEVICE=1 puts
+    every rank on cuda:0 — the world-size-2 tests of the scripts on a 1-GPU box (with DXMI_DIST_BACKEND=gloo: RCCL refuses two ranks on
+    a device)."""
+    import os
+    return "cuda:0" if os.environ.get("DXMI_DIST_ONE_DEVICE") == "1" else f"cuda:{local_rank}"
+
+
+def dist_backend():
+    """'nccl' (= RCCL on ROCm) unless DXMI_DIST_BACKEND overrides it (tests)."""
+    import os
+    return os.environ.get("DXMI_DIST_BACKEND", "nccl")

@@ -17,6 +17,7 @@ import time
 
 import numpy as np
 import torch
+from dxmi_hip import dist as _dist
 
 import cmd_utils as cmd  # noqa: F401  (kept for CLI parity: unknown --a.b overrides are parsed the same way)
 import dxmi_config
@@ -54,7 +55,7 @@ def main():
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    device = f"cuda:{local_rank}"
+    device = _dist.rank_device(local_rank)
     torch.cuda.set_device(device)
     seed = args.seed
     torch.manual_seed(seed + local_rank)
@@ -105,7 +106,7 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl", init_method="env://")  # RCCL; only the final barrier uses it
+        torch.distributed.init_process_group(backend=_dist.dist_backend(), init_method="env://")  # RCCL; only the final barrier uses it
 
     n_batches = int(args.n_generate / args.batchsize / world)
     i_img = 0

@@ -18,6 +18,7 @@ import time
 
 import numpy as np
 import torch
+from dxmi_hip import dist as _dist
 
 import dxmi_config
 from models.cm.script_util import create_model_and_diffusion
@@ -44,7 +45,7 @@ def main():
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    device = f"cuda:{local_rank}"
+    device = _dist.rank_device(local_rank)
     torch.cuda.set_device(device)
     if args.synthetic:
         import configs_builtin
@@ -85,7 +86,7 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl", init_method="env://")  # RCCL
+        torch.distributed.init_process_group(backend=_dist.dist_backend(), init_method="env://")  # RCCL
 
     from dxmi_hip import graph as hip_graph
     sampler.use_graph = hip_graph.default_enabled() and not args.no_graph        # second batch onwards: one hipGraphLaunch per batch

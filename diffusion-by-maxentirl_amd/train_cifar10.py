@@ -19,6 +19,7 @@ import random
 
 import numpy as np
 import torch
+from dxmi_hip import dist as _dist
 
 import cmd_utils as cmd
 import dxmi_config
@@ -107,7 +108,7 @@ def main():
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    device = f"cuda:{local_rank}"
+    device = _dist.rank_device(local_rank)
     torch.cuda.set_device(device)
     if not args.batch_invariant:
         from dxmi_hip import ops as _ops
@@ -119,7 +120,7 @@ def main():
     random.seed(seed + local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl", init_method="env://")   # RCCL
+        torch.distributed.init_process_group(backend=_dist.dist_backend(), init_method="env://")   # RCCL
 
     net = dxmi_config.instantiate(cfg.sampler_net)
     sampler = dxmi_config.instantiate(cfg.sampler, net=net).to(device)

@@ -20,6 +20,7 @@ import random
 
 import numpy as np
 import torch
+from dxmi_hip import dist as _dist
 from dxmi_hip.optim import Adam, RAdam   # torch.optim subclasses: step() is one multi-tensor HIP kernel series
 
 import cmd_utils as cmd
@@ -96,7 +97,7 @@ def main():
 
     cfg = load_config(args.config, args.dataset, d_cmd_cfg)
 
-    device = f"cuda:{local_rank}"
+    device = _dist.rank_device(local_rank)
     torch.cuda.set_device(device)
     if not args.batch_invariant:
         from dxmi_hip import ops as _ops
@@ -108,7 +109,7 @@ def main():
     random.seed(seed + local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl", init_method="env://")   # RCCL
+        torch.distributed.init_process_group(backend=_dist.dist_backend(), init_method="env://")   # RCCL
 
     unet, diffusion = create_model_and_diffusion(**cfg.diffusion)
     pre = cfg.training.get("pretrained_path")
