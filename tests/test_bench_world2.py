@@ -15,25 +15,25 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("scaling", ["weak", "strong"])
-def test_bench_two_ranks_on_one_gpu(scaling):
+@pytest.mark.parametrize("scaling,world", [("weak", 2), ("strong", 2), ("strong", 4)])
+def test_bench_two_ranks_on_one_gpu(scaling, world):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, DXMI_DIST_BACKEND="gloo", DXMI_DIST_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--batch", "32",
            "--train-steps", "2", "--scaling", scaling]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "rank 0 prints ONE JSON line"
     d = json.loads(lines[0])
-    per_rank = 32 if scaling == "weak" else 16
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == scaling
-    assert d["config"]["images_per_gpu_per_step"] == per_rank and d["config"]["global_batch"] == 2 * per_rank
-    assert d["value"] > 0 and abs(d["value"] - 2 * per_rank * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
-    assert d["train_steps_per_sec"] > 0 and d["rccl"]["world"] == 2 and len(d["per_rank_images_per_sec"]) == 2
+    per_rank = 32 if scaling == "weak" else 32 // world
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == scaling
+    assert d["config"]["images_per_gpu_per_step"] == per_rank and d["config"]["global_batch"] == world * per_rank
+    assert d["value"] > 0 and abs(d["value"] - world * per_rank * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert d["train_steps_per_sec"] > 0 and d["rccl"]["world"] == world and len(d["per_rank_images_per_sec"]) == world
     assert d["hip_graph"] is True and not d.get("hip_graph_errors"), d.get("hip_graph_errors")
     assert "roofline" in d and d["roofline"]["kernel"].startswith("conv")
 
